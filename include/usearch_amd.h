@@ -1,0 +1,154 @@
+/**
+ *  include/usearch_amd.h — C ABI of the MI355X-native batched HNSW search engine (the additive, GPU-specific part).
+ *
+ *  This is the boundary a binding links against. Types and conventions are those of the reference C ABI
+ *  (/root/reference/c/usearch.h:20-62): `usearch_key_t` = uint64, `usearch_distance_t` = float, errors are reported
+ *  through `usearch_error_t* error` — the callee stores a pointer to a static NUL-terminated string on failure and leaves
+ *  it untouched on success (reference convention, c/usearch.h:24-28, c/test.c:56-59). Scalar kinds use the reference's
+ *  C enumerators (c/usearch.h:54-62), not the on-disk values.
+ *
+ *  A *snapshot* is an immutable HBM-resident copy of one serialized index (`.usearch` v2 image, as produced by the
+ *  reference's `usearch_save` / `usearch_save_buffer`, c/usearch.h:162,195): dense aligned vector matrix + fixed-stride
+ *  level-0 neighbour rows + compact upper-level lists + keys. Searching it reproduces `usearch_search`
+ *  (c/usearch.h:371-374 → c/lib.cpp:398-411 → index_dense.hpp:2053-2085 → index.hpp:3016-3075) for a whole batch of
+ *  queries per call — the loop the reference leaves to its callers (cpp/bench.cpp:352-377, python/lib.cpp:261-319).
+ *
+ *  The reference-compatible 38 `usearch_*` entry points are declared in `include/usearch.h`.
+ */
+#ifndef USEARCH_AMD_H
+#define USEARCH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef USEARCH_AMD_EXPORT
+#define USEARCH_AMD_EXPORT __attribute__((visibility("default")))
+#endif
+
+typedef void* usearch_amd_snapshot_t;
+typedef uint64_t usearch_amd_key_t;       /* = usearch_key_t, c/usearch.h:21 */
+typedef float usearch_amd_distance_t;     /* = usearch_distance_t, c/usearch.h:22 */
+typedef char const* usearch_amd_error_t;  /* = usearch_error_t, c/usearch.h:28 */
+
+/** Scalar kinds with the values of `usearch_scalar_kind_t` (c/usearch.h:54-62). */
+enum {
+    usearch_amd_scalar_f32_k = 1,
+    usearch_amd_scalar_f64_k = 2,
+    usearch_amd_scalar_f16_k = 3,
+    usearch_amd_scalar_i8_k = 4,
+    usearch_amd_scalar_b1_k = 5,
+    usearch_amd_scalar_bf16_k = 6,
+};
+
+/** Optional knobs of one batched search; zero-initialise for the defaults. */
+typedef struct usearch_amd_tuning_t {
+    uint32_t hash_cap;             /**< visited-set cells per query in LDS (power of two); 0 = from expansion */
+    uint32_t next_cap;             /**< frontier capacity per query in LDS; 0 = from expansion */
+    uint32_t unroll;               /**< 16-byte loads in flight per lane within one row: 4 or 8; 0 = auto */
+    uint32_t force_global_scratch; /**< run every query with the global-memory scratch (exact sizes, slow) */
+} usearch_amd_tuning_t;
+
+/** What a batched search did, for profiling and tests. */
+typedef struct usearch_amd_stats_t {
+    uint32_t passes;         /**< kernel launches (1 = all queries fit the first LDS scratch) */
+    uint32_t retried_lds;    /**< queries rerun with enlarged LDS scratch */
+    uint32_t retried_global; /**< queries rerun with global-memory scratch */
+    float kernel_ms;         /**< HIP-event duration of the search launches (device entry point with timing only) */
+} usearch_amd_stats_t;
+
+/** Number of visible HIP devices; 0 (and an error) when the runtime finds none. */
+USEARCH_AMD_EXPORT int usearch_amd_device_count(usearch_amd_error_t* error);
+
+/**
+ *  Uploads a serialized index image to `device`. Replaces `usearch_load_buffer` (c/usearch.h:204-205, c/lib.cpp:244-250)
+ *  for the search path: the image is parsed on the host and flattened; it is not referenced after the call returns.
+ */
+USEARCH_AMD_EXPORT usearch_amd_snapshot_t usearch_amd_snapshot_from_buffer(void const* image, size_t length, int device,
+                                                                           usearch_amd_error_t* error);
+/** Same from a `.usearch` file (memory-mapped during the call). Replaces `usearch_load` (c/usearch.h:170). */
+USEARCH_AMD_EXPORT usearch_amd_snapshot_t usearch_amd_snapshot_from_file(char const* path, int device,
+                                                                         usearch_amd_error_t* error);
+USEARCH_AMD_EXPORT void usearch_amd_snapshot_free(usearch_amd_snapshot_t snapshot, usearch_amd_error_t* error);
+
+/** Introspection, mirroring `usearch_size/dimensions/connectivity` (c/usearch.h:231-252). */
+USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_size(usearch_amd_snapshot_t snapshot);
+USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_dimensions(usearch_amd_snapshot_t snapshot);
+USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_connectivity(usearch_amd_snapshot_t snapshot);
+USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_max_level(usearch_amd_snapshot_t snapshot);
+USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_bytes_per_vector(usearch_amd_snapshot_t snapshot);
+USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_row_stride(usearch_amd_snapshot_t snapshot);
+/** Bytes of HBM the snapshot occupies (cf. `usearch_memory_usage`, c/usearch.h:139). */
+USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_device_bytes(usearch_amd_snapshot_t snapshot);
+/** Storage scalar kind (C enumerator) and metric kind (`usearch_metric_kind_t` value, c/usearch.h:40-52). */
+USEARCH_AMD_EXPORT int usearch_amd_snapshot_scalar_kind(usearch_amd_snapshot_t snapshot);
+USEARCH_AMD_EXPORT int usearch_amd_snapshot_metric_kind(usearch_amd_snapshot_t snapshot);
+/** Lanes that share one stored row (G): fixes the floating-point summation layout, see DESIGN.md. */
+USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_lanes_per_row(usearch_amd_snapshot_t snapshot);
+
+/**
+ *  Batched search with HOST buffers — `usearch_search` (c/usearch.h:371-374) for `queries_count` queries at once.
+ *
+ *  @param queries        row `i` starts at `(char*)queries + i * queries_stride` and holds `dimensions` scalars of
+ *                        `query_kind`; cast to the storage kind exactly like index_dense.hpp:2058-2064.
+ *  @param wanted         k. Exactly `wanted` keys and distances are written per query; unused tail slots are key 0 and
+ *                        a signalling NaN (index.hpp:2707-2722, c/lib.cpp:410).
+ *  @param expansion      ef; 0 = 64 (index.hpp:3029-3030); the effective value is max(expansion, wanted) (index.hpp:3052).
+ *  @param keys           [queries_count][wanted], may be NULL.
+ *  @param distances      [queries_count][wanted], may be NULL.
+ *  @param counts         [queries_count] found per query (`dump_to`'s return value), may be NULL.
+ *  @param visited        [queries_count] `search_result_t::visited_members` (index.hpp:3071), may be NULL.
+ *  @param computed       [queries_count] `search_result_t::computed_distances` (index.hpp:3072), may be NULL.
+ */
+USEARCH_AMD_EXPORT void usearch_amd_search_many(usearch_amd_snapshot_t snapshot, void const* queries, int query_kind,
+                                                size_t queries_count, size_t queries_stride, size_t wanted,
+                                                size_t expansion, usearch_amd_key_t* keys,
+                                                usearch_amd_distance_t* distances, uint64_t* counts, uint64_t* visited,
+                                                uint64_t* computed, usearch_amd_tuning_t const* tuning,
+                                                usearch_amd_stats_t* stats, usearch_amd_error_t* error);
+
+/**
+ *  Batched search with DEVICE buffers (HBM-resident input and output, the timed path of bench.py). Queries must
+ *  already be in the storage scalar kind; every output pointer is mandatory. `stream` is a `hipStream_t` (NULL = the
+ *  snapshot's own stream); the call returns after the stream has drained. With `timed != 0` the search launches
+ *  are bracketed by HIP events on that stream and `stats->kernel_ms` is filled.
+ */
+USEARCH_AMD_EXPORT void usearch_amd_search_many_device(usearch_amd_snapshot_t snapshot, void const* queries,
+                                                       size_t queries_count, size_t queries_stride, size_t wanted,
+                                                       size_t expansion, usearch_amd_key_t* keys,
+                                                       usearch_amd_distance_t* distances, uint64_t* counts,
+                                                       uint64_t* visited, uint64_t* computed, void* stream,
+                                                       usearch_amd_tuning_t const* tuning, int timed,
+                                                       usearch_amd_stats_t* stats, usearch_amd_error_t* error);
+
+/**
+ *  out[q][j] = metric(query q, stored vector of slot slots[q][j]) — `usearch_distance` (c/usearch.h:441-445) against
+ *  stored rows, host buffers, queries in the storage kind. Exposes the distance arithmetic alone.
+ */
+USEARCH_AMD_EXPORT void usearch_amd_distances(usearch_amd_snapshot_t snapshot, void const* queries,
+                                              size_t queries_count, size_t queries_stride, uint32_t const* slots,
+                                              size_t slots_per_query, usearch_amd_distance_t* out,
+                                              usearch_amd_error_t* error);
+
+/**
+ *  Self-test hook: replays `count` scripted operations on the device-side containers (kind 0 = frontier push of
+ *  {keys[i], slots[i]}, 1 = frontier pop, 2 = insert {keys[i], slots[i]} into the result buffer limited to `limit`) and
+ *  returns what was popped and the final result buffer, each entry packed as (slot << 32 | float bits).
+ */
+USEARCH_AMD_EXPORT void usearch_amd_test_containers(uint32_t const* kinds, float const* keys, uint32_t const* slots,
+                                                    size_t count, size_t limit, uint64_t* popped, size_t* popped_count,
+                                                    uint64_t* top, size_t* top_count, usearch_amd_error_t* error);
+
+/**
+ *  Host-side query cast used by `usearch_amd_search_many` (index_plugins.hpp:1105-1224). Returns 0 when the kinds are
+ *  equal (nothing written), 1 after writing the cast vector.
+ */
+USEARCH_AMD_EXPORT int usearch_amd_cast(int from_kind, int to_kind, void const* input, size_t dimensions, void* output);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* USEARCH_AMD_H */

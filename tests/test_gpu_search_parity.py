@@ -1,0 +1,153 @@
+"""GPU parity proper: batched HNSW search through the C ABI against the oracle (bit-exact, the oracle run in the
+kernels' summation layout) and against the real reference compiled from /root/reference (exact for integer-valued
+metrics, tolerance for float ones), on seeded inputs small enough for the CPU to finish in seconds."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+# (metric, dtype, ndim, n, connectivity, k, expansion, queries)
+CONFIGS = [
+    ("cos", "f32", 128, 3000, 16, 10, 64, 200),       # BASELINE config 1 shape, scaled
+    ("cos", "f16", 768, 1500, 16, 10, 64, 100),       # headline shape (config 3), scaled
+    ("cos", "f32", 768, 800, 16, 10, 64, 50),         # config 2 shape, scaled
+    ("l2sq", "i8", 96, 4000, 16, 10, 64, 200),        # config 4 shape, scaled
+    ("hamming", "b1", 128, 5000, 16, 10, 64, 300),    # config 5 shape, scaled: ties everywhere
+    ("ip", "f32", 64, 1000, 16, 5, 32, 100),
+    ("l2sq", "f32", 3, 500, 3, 3, 8, 100),            # cpp/test.cpp:820-865 "absurd" corners: tiny dims/connectivity
+    ("l2sq", "f16", 100, 1200, 13, 19, 19, 80),       # cpp/test.cpp:652-766 connectivity 13, ragged dims
+    ("cos", "i8", 96, 1500, 16, 10, 128, 80),
+    ("ip", "i8", 40, 800, 8, 7, 64, 60),
+    ("cos", "f32", 32, 2000, 50, 10, 64, 80),         # connectivity 50 ⇒ M0 = 100 ⇒ two neighbour tiles per hop
+    ("hamming", "b1", 1024, 1500, 16, 10, 256, 60),
+    ("hamming", "b1", 8, 300, 2, 1, 1, 60),
+    ("l2sq", "f16", 16, 64, 16, 100, 64, 20),         # k > n
+]
+
+
+def check_against_oracle(index, image, queries, k, dtype, expansion, **search_kwargs):
+    got = index.search(queries, k, expansion=expansion, dtype=dtype, **search_kwargs)
+    keys, dists, counts, visited, computed = util.oracle_search(image, queries, k, dtype, expansion,
+                                                                lanes=index.lanes_per_row)
+    bad = np.nonzero((got.keys != keys).any(axis=1))[0]
+    assert len(bad) == 0, (f"{len(bad)}/{len(queries)} queries differ in keys; first {bad[0]}: "
+                           f"gpu {got.keys[bad[0]]} {got.distances[bad[0]]} oracle {keys[bad[0]]} {dists[bad[0]]}")
+    assert np.array_equal(got.counts, counts)
+    assert util.same_float_bits(got.distances, dists)
+    assert np.array_equal(got.visited_per_query, visited), "visited_members differ"
+    assert np.array_equal(got.computed_per_query, computed), "computed_distances differ"
+    return got
+
+
+@pytest.mark.parametrize("metric,dtype,ndim,n,connectivity,k,expansion,nq", CONFIGS)
+def test_search_matches_oracle_and_reference(reference, metric, dtype, ndim, n, connectivity, k, expansion, nq):
+    from usearch_amd import Index
+    image, vectors, ref_index = util.build_image(n, ndim, metric, dtype, seed=11, connectivity=connectivity)
+    queries = util.make_vectors(nq, ndim, dtype, seed=12)
+    queries[: nq // 4] = vectors[: nq // 4]  # some in-sample queries: self must come back first (cpp/test.cpp:232-236)
+    index = Index.restore(image)
+    assert len(index) == n and index.ndim == ndim and index.connectivity == connectivity
+    got = check_against_oracle(index, image, queries, k, dtype, expansion)
+    assert got.stats.passes == 1, "default scratch sizing should not overflow on these shapes"
+
+    # the real reference, same image, same queries
+    ref_index.expansion_search = expansion
+    rkeys, rdists, rcounts, rvisited, rcomputed = ref_index.search(queries, k, dtype=dtype, threads=1)
+    assert np.array_equal(got.counts, rcounts)
+    if dtype in ("i8", "b1") and metric != "cos":
+        assert np.array_equal(got.keys, rkeys)
+        assert util.same_float_bits(got.distances, rdists)
+        assert np.array_equal(got.visited_per_query, rvisited)
+        assert np.array_equal(got.computed_per_query, rcomputed)
+    else:
+        tolerance = 2e-3 if dtype == "f16" else 1e-5
+        found = np.arange(k)[None, :] < rcounts[:, None]
+        scale = np.maximum(1.0, np.abs(np.where(found, rdists, 0)))
+        assert np.all(np.abs(np.where(found, got.distances - rdists, 0)) <= tolerance * scale)
+        # labels must agree wherever the reference's neighbouring distances are clearly separated
+        agree = (got.keys == rkeys) | ~found
+        assert agree.mean() > 0.98, f"label agreement with the reference {agree.mean():.4f}"
+    # monotone distances (cpp/test.cpp:499-503) and self-hit for in-sample queries
+    for qi in range(nq):
+        c = int(got.counts[qi])
+        assert np.all(np.diff(got.distances[qi, :c]) >= 0)
+        assert np.all(got.keys[qi, c:] == 0) and np.all(np.isnan(got.distances[qi, c:]))
+
+
+def test_empty_index_and_zero_wanted(reference):
+    from usearch_amd import Index
+    image, _, _ = util.build_image(0, 16, "cos", "f32")
+    index = Index.restore(image)
+    assert len(index) == 0
+    got = index.search(np.ones((3, 16), dtype=np.float32), 5)
+    assert np.all(got.counts == 0) and np.all(got.keys == 0) and np.all(np.isnan(got.distances))
+    image, _, _ = util.build_image(10, 16, "cos", "f32")
+    index = Index.restore(image)
+    got = index.search(np.ones((3, 16), dtype=np.float32), 0)
+    assert got.keys.shape == (3, 0)
+
+
+def test_single_vector_and_single_query(reference):
+    from usearch_amd import Index
+    image, vectors, _ = util.build_image(1, 24, "l2sq", "f32", seed=5)
+    index = Index.restore(image)
+    one = index.search(vectors[0], 3)
+    assert len(one) == 1 and one.keys[0] == 1000 and one.distances[0] == 0.0
+
+
+def test_query_casts_match_reference(reference):
+    """Queries handed over in a kind other than the storage kind are cast first (index_dense.hpp:2058-2064)."""
+    from usearch_amd import Index
+    n, ndim = 1200, 64
+    for dtype, metric in (("f16", "cos"), ("i8", "cos"), ("b1", "hamming")):
+        image, _, ref_index = util.build_image(n, ndim, metric, dtype, seed=21)
+        index = Index.restore(image)
+        queries = util.make_vectors(40, ndim, "f32", seed=22)
+        got = index.search(queries, 10, dtype="f32")
+        keys, dists, counts, visited, computed = util.oracle_search(image, queries, 10, "f32", 64,
+                                                                    lanes=index.lanes_per_row)
+        assert np.array_equal(got.keys, keys) and util.same_float_bits(got.distances, dists)
+        assert np.array_equal(got.computed_per_query, computed)
+        rkeys, rdists, *_ = ref_index.search(queries, 10, dtype="f32", threads=1)
+        if dtype != "f16":
+            assert np.array_equal(got.keys, rkeys)
+
+
+def test_tombstones_are_skipped(reference):
+    """Removed entries keep routing the search but never reach the results (index_dense.hpp:2071-2081)."""
+    from usearch_amd import Index
+    n, ndim = 1500, 32
+    removed = np.arange(0, n, 3) + 1000
+    image, vectors, ref_index = util.build_image(n, ndim, "cos", "f32", seed=31, remove=removed)
+    index = Index.restore(image)
+    queries = util.make_vectors(100, ndim, "f32", seed=32)
+    got = check_against_oracle(index, image, queries, 10, "f32", 64)
+    assert not np.isin(got.keys, removed).any()
+    rkeys, *_ = ref_index.search(queries, 10, threads=1)
+    assert (got.keys == rkeys).mean() > 0.98
+
+
+def test_scratch_overflow_retries_give_identical_results(reference):
+    """Tiny LDS scratch forces the retry ladder (bigger LDS, then global memory); results must not change."""
+    from usearch_amd import Index, Tuning
+    for metric, dtype, ndim in (("cos", "f32", 64), ("hamming", "b1", 64)):
+        image, _, _ = util.build_image(3000, ndim, metric, dtype, seed=41)
+        index = Index.restore(image)
+        queries = util.make_vectors(64, ndim, dtype, seed=42)
+        base = check_against_oracle(index, image, queries, 10, dtype, 64)
+        small = check_against_oracle(index, image, queries, 10, dtype, 64, tuning=Tuning(256, 96, 0, 0))
+        assert small.stats.passes >= 2 and small.stats.retried_lds > 0
+        forced = check_against_oracle(index, image, queries, 10, dtype, 64, tuning=Tuning(0, 0, 0, 1))
+        assert forced.stats.retried_global == len(queries)
+        assert np.array_equal(base.keys, small.keys) and np.array_equal(base.keys, forced.keys)
+
+
+def test_large_expansion(reference):
+    from usearch_amd import Index
+    image, _, _ = util.build_image(4000, 48, "l2sq", "f32", seed=51)
+    index = Index.restore(image)
+    queries = util.make_vectors(40, 48, "f32", seed=52)
+    for expansion in (256, 1000):
+        check_against_oracle(index, image, queries, 10, "f32", expansion)

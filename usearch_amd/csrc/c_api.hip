@@ -1,0 +1,287 @@
+/**
+ *  usearch_amd/csrc/c_api.hip — `extern "C"` shim over the engine: the functions declared in include/usearch_amd.h.
+ *  No C++ or HIP types cross this boundary.
+ */
+#include "../../include/usearch_amd.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <new>
+
+#include "casts.hpp"
+#include "engine.hpp"
+#include "kernels.hpp"
+
+using namespace usearch_amd;
+
+namespace {
+
+scalar_kind_t scalar_from_c(int kind) { // c/lib.cpp:61-79
+    switch (kind) {
+    case usearch_amd_scalar_f32_k: return scalar_f32_k;
+    case usearch_amd_scalar_f64_k: return scalar_f64_k;
+    case usearch_amd_scalar_f16_k: return scalar_f16_k;
+    case usearch_amd_scalar_i8_k: return scalar_i8_k;
+    case usearch_amd_scalar_b1_k: return scalar_b1x8_k;
+    case usearch_amd_scalar_bf16_k: return scalar_bf16_k;
+    default: return scalar_unknown_k;
+    }
+}
+
+int scalar_to_c(scalar_kind_t kind) {
+    switch (kind) {
+    case scalar_f32_k: return usearch_amd_scalar_f32_k;
+    case scalar_f64_k: return usearch_amd_scalar_f64_k;
+    case scalar_f16_k: return usearch_amd_scalar_f16_k;
+    case scalar_i8_k: return usearch_amd_scalar_i8_k;
+    case scalar_b1x8_k: return usearch_amd_scalar_b1_k;
+    case scalar_bf16_k: return usearch_amd_scalar_bf16_k;
+    default: return 0;
+    }
+}
+
+int metric_to_c(metric_kind_t kind) { // c/usearch.h:40-52 ← c/lib.cpp:26-59
+    switch (kind) {
+    case metric_cos_k: return 1;
+    case metric_ip_k: return 2;
+    case metric_l2sq_k: return 3;
+    case metric_haversine_k: return 4;
+    case metric_divergence_k: return 5;
+    case metric_pearson_k: return 6;
+    case metric_jaccard_k: return 7;
+    case metric_hamming_k: return 8;
+    case metric_tanimoto_k: return 9;
+    case metric_sorensen_k: return 10;
+    default: return 0;
+    }
+}
+
+search_tuning_t tuning_from_c(usearch_amd_tuning_t const* t) {
+    search_tuning_t out;
+    if (t) {
+        out.hash_cap = t->hash_cap;
+        out.next_cap = t->next_cap;
+        out.unroll = t->unroll;
+        out.force_global_scratch = t->force_global_scratch != 0;
+    }
+    return out;
+}
+
+void stats_to_c(const search_stats_t& s, usearch_amd_stats_t* out) {
+    if (!out)
+        return;
+    out->passes = s.passes;
+    out->retried_lds = s.retried_lds;
+    out->retried_global = s.retried_global;
+    out->kernel_ms = s.kernel_ms;
+}
+
+void fail(usearch_amd_error_t* error, const char* message) {
+    if (error && message)
+        *error = message;
+}
+
+snapshot_t* as_snapshot(usearch_amd_snapshot_t handle) { return static_cast<snapshot_t*>(handle); }
+
+} // namespace
+
+namespace usearch_amd {
+/**
+ *  Container self-test: replays a scripted sequence of heap pushes / pops and sorted inserts on the LDS containers
+ *  and records what comes out, so the GPU tests can compare the tie behaviour with the oracle's containers directly.
+ *  ops[i] = {kind, slot}: kind 0 = push(key = keys[i]), 1 = pop, 2 = sorted_insert(keys[i]) with `limit`.
+ */
+__global__ __launch_bounds__(64) void containers_kernel(const std::uint32_t* kinds, const float* keys,
+                                                        const std::uint32_t* slots, std::uint32_t count,
+                                                        std::uint32_t limit, std::uint32_t capacity,
+                                                        std::uint64_t* popped, std::uint32_t* popped_count,
+                                                        std::uint64_t* top_out, std::uint32_t* top_count) {
+    extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
+    cand_t* heap = reinterpret_cast<cand_t*>(lds);
+    cand_t* top = heap + capacity;
+    std::uint32_t heap_size = 0, top_size = 0, pops = 0;
+    for (std::uint32_t i = 0; i < count; ++i) {
+        const std::uint32_t kind = kinds[i];
+        if (kind == 0 && heap_size < capacity)
+            heap_push<false>(heap, heap_size, keys[i], slots[i]);
+        else if (kind == 1 && heap_size) {
+            const cand_t c = heap_pop<false>(heap, heap_size);
+            if (lane_id() == 0)
+                popped[pops] = c;
+            ++pops;
+        } else if (kind == 2)
+            sorted_insert<false>(top, top_size, limit, keys[i], slots[i]);
+    }
+    for (std::uint32_t i = lane_id(); i < top_size; i += 64)
+        top_out[i] = top[i];
+    if (lane_id() == 0)
+        *popped_count = pops, *top_count = top_size;
+}
+
+} // namespace usearch_amd
+
+extern "C" {
+
+int usearch_amd_device_count(usearch_amd_error_t* error) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) {
+        fail(error, hipGetErrorString(e));
+        return 0;
+    }
+    if (count == 0)
+        fail(error, "No HIP device is visible: the MI355X search engine has no CPU fallback");
+    return count;
+}
+
+usearch_amd_snapshot_t usearch_amd_snapshot_from_buffer(void const* buffer, size_t length, int device,
+                                                        usearch_amd_error_t* error) {
+    image_t image;
+    if (const char* e = image.open(buffer, length)) {
+        fail(error, e);
+        return nullptr;
+    }
+    snapshot_t* snapshot = new (std::nothrow) snapshot_t();
+    if (!snapshot) {
+        fail(error, "Out of memory!");
+        return nullptr;
+    }
+    if (const char* e = snapshot->build(image, device)) {
+        fail(error, e);
+        delete snapshot;
+        return nullptr;
+    }
+    return snapshot;
+}
+
+usearch_amd_snapshot_t usearch_amd_snapshot_from_file(char const* path, int device, usearch_amd_error_t* error) {
+    int fd = ::open(path, O_RDONLY);
+    if (fd < 0) {
+        fail(error, "Can't open file!"); // index_plugins.hpp memory_mapped_file_t wording
+        return nullptr;
+    }
+    struct stat st;
+    if (::fstat(fd, &st) != 0 || st.st_size <= 0) {
+        ::close(fd);
+        fail(error, "Can't infer file size");
+        return nullptr;
+    }
+    void* mapped = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (mapped == MAP_FAILED) {
+        fail(error, "Can't memory-map the file");
+        return nullptr;
+    }
+    usearch_amd_snapshot_t snapshot = usearch_amd_snapshot_from_buffer(mapped, (size_t)st.st_size, device, error);
+    ::munmap(mapped, (size_t)st.st_size);
+    return snapshot;
+}
+
+void usearch_amd_snapshot_free(usearch_amd_snapshot_t snapshot, usearch_amd_error_t*) { delete as_snapshot(snapshot); }
+
+size_t usearch_amd_snapshot_size(usearch_amd_snapshot_t s) { return (size_t)as_snapshot(s)->view().size; }
+size_t usearch_amd_snapshot_dimensions(usearch_amd_snapshot_t s) { return as_snapshot(s)->view().dimensions; }
+size_t usearch_amd_snapshot_connectivity(usearch_amd_snapshot_t s) { return as_snapshot(s)->view().m; }
+size_t usearch_amd_snapshot_max_level(usearch_amd_snapshot_t s) { return as_snapshot(s)->view().max_level; }
+size_t usearch_amd_snapshot_bytes_per_vector(usearch_amd_snapshot_t s) { return as_snapshot(s)->view().bytes_per_vector; }
+size_t usearch_amd_snapshot_row_stride(usearch_amd_snapshot_t s) { return as_snapshot(s)->view().row_stride; }
+size_t usearch_amd_snapshot_device_bytes(usearch_amd_snapshot_t s) { return as_snapshot(s)->device_bytes(); }
+int usearch_amd_snapshot_scalar_kind(usearch_amd_snapshot_t s) { return scalar_to_c(as_snapshot(s)->scalar()); }
+int usearch_amd_snapshot_metric_kind(usearch_amd_snapshot_t s) { return metric_to_c(as_snapshot(s)->metric()); }
+size_t usearch_amd_snapshot_lanes_per_row(usearch_amd_snapshot_t s) { return as_snapshot(s)->lanes_per_row(); }
+
+void usearch_amd_search_many(usearch_amd_snapshot_t snapshot, void const* queries, int query_kind,
+                             size_t queries_count, size_t queries_stride, size_t wanted, size_t expansion,
+                             usearch_amd_key_t* keys, usearch_amd_distance_t* distances, uint64_t* counts,
+                             uint64_t* visited, uint64_t* computed, usearch_amd_tuning_t const* tuning,
+                             usearch_amd_stats_t* stats, usearch_amd_error_t* error) {
+    const scalar_kind_t kind = scalar_from_c(query_kind);
+    if (kind == scalar_unknown_k)
+        return fail(error, "Unknown scalar kind!"); // c/lib.cpp:120
+    search_stats_t s;
+    if (const char* e = as_snapshot(snapshot)->search_host(queries, kind, queries_count, queries_stride, wanted,
+                                                           expansion, keys, distances, counts, visited, computed,
+                                                           tuning_from_c(tuning), &s))
+        return fail(error, e);
+    stats_to_c(s, stats);
+}
+
+void usearch_amd_search_many_device(usearch_amd_snapshot_t snapshot, void const* queries, size_t queries_count,
+                                    size_t queries_stride, size_t wanted, size_t expansion, usearch_amd_key_t* keys,
+                                    usearch_amd_distance_t* distances, uint64_t* counts, uint64_t* visited,
+                                    uint64_t* computed, void* stream, usearch_amd_tuning_t const* tuning, int timed,
+                                    usearch_amd_stats_t* stats, usearch_amd_error_t* error) {
+    if (queries_count && wanted && (!queries || !keys || !distances || !counts || !visited || !computed))
+        return fail(error, "Device entry point needs every buffer");
+    search_stats_t s;
+    if (const char* e = as_snapshot(snapshot)->search_device(queries, queries_count, queries_stride, wanted, expansion,
+                                                             keys, distances, counts, visited, computed,
+                                                             static_cast<hipStream_t>(stream), tuning_from_c(tuning),
+                                                             &s, timed != 0))
+        return fail(error, e);
+    stats_to_c(s, stats);
+}
+
+void usearch_amd_distances(usearch_amd_snapshot_t snapshot, void const* queries, size_t queries_count,
+                           size_t queries_stride, uint32_t const* slots, size_t slots_per_query,
+                           usearch_amd_distance_t* out, usearch_amd_error_t* error) {
+    if (const char* e = as_snapshot(snapshot)->distances_host(queries, queries_count, queries_stride, slots,
+                                                              slots_per_query, out))
+        fail(error, e);
+}
+
+void usearch_amd_test_containers(uint32_t const* kinds, float const* keys, uint32_t const* slots, size_t count,
+                                 size_t limit, uint64_t* popped, size_t* popped_count, uint64_t* top, size_t* top_count,
+                                 usearch_amd_error_t* error) {
+    const size_t capacity = count + 1;
+    uint32_t *d_kinds = nullptr, *d_slots = nullptr, *d_counts = nullptr;
+    float* d_keys = nullptr;
+    uint64_t *d_popped = nullptr, *d_top = nullptr;
+    hipError_t e = hipSuccess;
+    auto check = [&](hipError_t r) {
+        if (e == hipSuccess)
+            e = r;
+    };
+    check(hipMalloc((void**)&d_kinds, count * 4 + 4));
+    check(hipMalloc((void**)&d_slots, count * 4 + 4));
+    check(hipMalloc((void**)&d_keys, count * 4 + 4));
+    check(hipMalloc((void**)&d_popped, capacity * 8));
+    check(hipMalloc((void**)&d_top, (limit + 1) * 8));
+    check(hipMalloc((void**)&d_counts, 8));
+    if (e == hipSuccess) {
+        check(hipMemcpy(d_kinds, kinds, count * 4, hipMemcpyHostToDevice));
+        check(hipMemcpy(d_slots, slots, count * 4, hipMemcpyHostToDevice));
+        check(hipMemcpy(d_keys, keys, count * 4, hipMemcpyHostToDevice));
+        const size_t lds = (capacity + limit + 1) * 8;
+        hipLaunchKernelGGL(containers_kernel, dim3(1), dim3(64), lds, nullptr, d_kinds, d_keys, d_slots,
+                           (uint32_t)count, (uint32_t)limit, (uint32_t)capacity, d_popped, d_counts, d_top,
+                           d_counts + 1);
+        check(hipGetLastError());
+        check(hipDeviceSynchronize());
+        uint32_t host_counts[2] = {0, 0};
+        check(hipMemcpy(host_counts, d_counts, 8, hipMemcpyDeviceToHost));
+        if (e == hipSuccess) {
+            *popped_count = host_counts[0];
+            *top_count = host_counts[1];
+            check(hipMemcpy(popped, d_popped, host_counts[0] * 8, hipMemcpyDeviceToHost));
+            check(hipMemcpy(top, d_top, host_counts[1] * 8, hipMemcpyDeviceToHost));
+        }
+    }
+    for (void* p : {(void*)d_kinds, (void*)d_slots, (void*)d_keys, (void*)d_popped, (void*)d_top, (void*)d_counts})
+        if (p)
+            (void)hipFree(p);
+    if (e != hipSuccess)
+        fail(error, hipGetErrorString(e));
+}
+
+int usearch_amd_cast(int from_kind, int to_kind, void const* input, size_t dimensions, void* output) {
+    return cast_vector(scalar_from_c(from_kind), scalar_from_c(to_kind), static_cast<const std::uint8_t*>(input),
+                       dimensions, static_cast<std::uint8_t*>(output))
+               ? 1
+               : 0;
+}
+
+} // extern "C"

@@ -1,0 +1,111 @@
+/**
+ *  usearch_amd/csrc/common.hpp — shared host/device types of the MI355X search engine.
+ *
+ *  Enumerator VALUES are the reference's on-disk ones (/root/reference/include/usearch/index_plugins.hpp:113-159),
+ *  because the engine is fed from serialized `.usearch` v2 images (index_dense.hpp:42-79 stores them as raw bytes).
+ */
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace usearch_amd {
+
+enum metric_kind_t : std::uint8_t {
+    metric_unknown_k = 0,
+    metric_ip_k = 'i',
+    metric_cos_k = 'c',
+    metric_l2sq_k = 'e',
+    metric_hamming_k = 'b',
+    // present in the reference, no HIP kernel yet: listed so that they are refused by name
+    metric_pearson_k = 'p',
+    metric_haversine_k = 'h',
+    metric_divergence_k = 'd',
+    metric_jaccard_k = 'j',
+    metric_tanimoto_k = 't',
+    metric_sorensen_k = 's',
+};
+
+enum scalar_kind_t : std::uint8_t {
+    scalar_unknown_k = 0,
+    scalar_b1x8_k = 1,
+    scalar_bf16_k = 4,
+    scalar_f64_k = 10,
+    scalar_f32_k = 11,
+    scalar_f16_k = 12,
+    scalar_i8_k = 23,
+    scalar_u64_k = 14, // key kind of index_dense_t (index_dense.hpp:2229)
+    scalar_u32_k = 15, // compressed slot kind of index_dense_t
+};
+
+/// Bytes one stored vector occupies (index_plugins.hpp:1853-1855: bits_per_scalar * dimensions, rounded up to bytes).
+inline std::size_t bytes_per_vector(scalar_kind_t kind, std::size_t dimensions) {
+    switch (kind) {
+    case scalar_b1x8_k: return (dimensions + 7) / 8;
+    case scalar_i8_k: return dimensions;
+    case scalar_f16_k:
+    case scalar_bf16_k: return dimensions * 2;
+    case scalar_f32_k: return dimensions * 4;
+    case scalar_f64_k: return dimensions * 8;
+    default: return 0;
+    }
+}
+
+constexpr std::uint32_t none_slot_k = 0xFFFFFFFFu;             ///< empty neighbour cell / empty hash cell
+constexpr std::uint64_t free_key_k = 0xFFFFFFFFFFFFFFFFull;    ///< tombstone key, index_dense.hpp:513
+constexpr std::uint32_t signaling_nan_bits_k = 0x7FA00000u;    ///< tail padding of distances, index.hpp:2717-2719
+constexpr std::size_t default_expansion_search_k = 64;         ///< index.hpp:3029-3030
+
+/**
+ *  Immutable HBM snapshot of one index, as the kernels see it (passed by value).
+ *
+ *  Layout (all arrays `hipMalloc`ed, slot numbering identical to the reference's so that labels and tie-breaks are
+ *  comparable — replaces the pointer-chased `nodes_[slot]` → tape / `vectors_lookup_[slot]` of index.hpp:2280 and
+ *  index_dense.hpp:456-460):
+ *    vectors   [size][row_stride] bytes   row = the stored vector, zero padded to a multiple of 16*G bytes
+ *    nbr0      [size][m0] u32             level-0 neighbour list in the reference's order, later duplicates removed,
+ *                                         unused cells = none_slot_k (the u32 count of index.hpp:2148-2195 is implied)
+ *    upper_ref [size] u32                 index of the node's level-1 list inside `upper`, none_slot_k for level-0 nodes
+ *    upper     [lists][m] u32             lists of levels 1..L of one node are consecutive; same cell convention
+ *    keys      [size] u64                 node_t::key (index.hpp:2116-2137)
+ */
+struct snapshot_view_t {
+    const std::uint8_t* vectors;
+    const std::uint32_t* nbr0;
+    const std::uint32_t* upper_ref;
+    const std::uint32_t* upper;
+    const std::uint64_t* keys;
+    std::uint64_t size;
+    std::uint32_t row_stride; ///< bytes, multiple of 16*G
+    std::uint32_t chunks;     ///< row_stride / 16
+    std::uint32_t bytes_per_vector;
+    std::uint32_t dimensions;
+    std::uint32_t m, m0;
+    std::uint32_t max_level;
+    std::uint32_t entry_slot;
+    std::uint32_t has_tombstones; ///< any key == free_key_k: the `allow` predicate of index_dense.hpp:2071-2081 must run
+};
+
+/** One batch of queries, everything device-resident. */
+struct search_args_t {
+    const std::uint8_t* queries; ///< storage scalar kind, row `i` at queries + i*query_stride, bytes_per_vector bytes used
+    std::uint64_t query_stride;
+    const std::uint32_t* todo; ///< optional: query indices this launch handles (retry passes); null = identity
+    std::uint32_t count;       ///< launches' grid size (number of queries or of `todo` entries)
+    std::uint32_t wanted;      ///< k
+    std::uint32_t ef;          ///< max(expansion, wanted), index.hpp:3052
+    std::uint64_t* keys;       ///< [Q][wanted]
+    float* distances;          ///< [Q][wanted]
+    std::uint64_t* counts;     ///< [Q]
+    std::uint64_t* visited;    ///< [Q] visited_members  (index.hpp:3071)
+    std::uint64_t* computed;   ///< [Q] computed_distances (index.hpp:3072)
+    std::uint32_t* status;     ///< [Q] 0 = done, 1 = scratch overflow → rerun with bigger scratch
+    std::uint32_t hash_cap;    ///< LDS visited-set cells, power of two
+    std::uint32_t next_cap;    ///< frontier heap capacity
+    // global-scratch variant only:
+    std::uint8_t* scratch;
+    std::uint64_t scratch_stride; ///< bytes per launched wave
+};
+
+enum : std::uint32_t { status_done_k = 0, status_overflow_k = 1 };
+
+} // namespace usearch_amd

@@ -1,0 +1,647 @@
+/**
+ *  usearch_amd/csrc/engine.hip — snapshot construction (flatten a v2 image into HBM arrays) and the batched search
+ *  driver with its scratch-overflow retry ladder. See engine.hpp / kernels.hpp for the design.
+ */
+#include "engine.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+#include "casts.hpp"
+#include "kernels.hpp"
+
+namespace usearch_amd {
+
+namespace {
+
+const char* hip_message(hipError_t e) { return hipGetErrorString(e); } // static strings owned by the runtime
+
+#define UA_HIP(call)                                                                                                   \
+    do {                                                                                                               \
+        hipError_t ua_error_ = (call);                                                                                 \
+        if (ua_error_ != hipSuccess)                                                                                   \
+            return hip_message(ua_error_);                                                                             \
+    } while (0)
+
+std::uint32_t pow2_ceil(std::uint32_t v) {
+    std::uint32_t p = 1;
+    while (p < v)
+        p <<= 1;
+    return p;
+}
+
+std::size_t env_size(const char* name, std::size_t fallback) {
+    const char* v = std::getenv(name);
+    return v && *v ? (std::size_t)std::strtoull(v, nullptr, 10) : fallback;
+}
+
+/// Runs `body(begin, end)` over [0, n) on the host's cores.
+template <typename body_at> void parallel_ranges(std::uint64_t n, body_at&& body) {
+    unsigned workers = std::thread::hardware_concurrency();
+    workers = std::max(1u, std::min(workers, 64u));
+    if (n < 4096 || workers == 1) {
+        body(0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const std::uint64_t step = (n + workers - 1) / workers;
+    for (unsigned w = 0; w < workers; ++w) {
+        const std::uint64_t begin = std::min<std::uint64_t>(n, w * step), end = std::min<std::uint64_t>(n, begin + step);
+        if (begin < end)
+            pool.emplace_back([=, &body] { body(begin, end); });
+    }
+    for (auto& t : pool)
+        t.join();
+}
+
+} // namespace
+
+bool kernel_available(metric_kind_t metric, scalar_kind_t scalar) {
+    const bool numeric_metric = metric == metric_ip_k || metric == metric_cos_k || metric == metric_l2sq_k;
+    switch (scalar) {
+    case scalar_f32_k:
+    case scalar_f16_k:
+    case scalar_i8_k: return numeric_metric;
+    case scalar_b1x8_k: return metric == metric_hamming_k;
+    default: return false;
+    }
+}
+
+snapshot_t::~snapshot_t() { release(); }
+
+void snapshot_t::release() {
+    if (!d_vectors_ && !d_nbr0_ && !d_status_ && !stream_)
+        return;
+    (void)hipSetDevice(device_);
+    for (void* p : {d_vectors_, d_nbr0_, d_upper_ref_, d_upper_, d_keys_, (void*)d_status_, (void*)d_todo_,
+                    (void*)d_scratch_, (void*)d_stage_})
+        if (p)
+            (void)hipFree(p);
+    if (h_status_)
+        (void)hipHostFree(h_status_);
+    if (event_begin_)
+        (void)hipEventDestroy(event_begin_);
+    if (event_end_)
+        (void)hipEventDestroy(event_end_);
+    if (stream_)
+        (void)hipStreamDestroy(stream_);
+    d_vectors_ = d_nbr0_ = d_upper_ref_ = d_upper_ = d_keys_ = nullptr;
+    d_status_ = d_todo_ = h_status_ = nullptr;
+    d_scratch_ = d_stage_ = nullptr;
+    event_begin_ = event_end_ = nullptr;
+    stream_ = nullptr;
+}
+
+const char* snapshot_t::build(const image_t& image, int device) {
+    if (!kernel_available(image.metric, image.scalar))
+        return "No MI355X kernel for this metric / scalar kind combination";
+    device_ = device;
+    UA_HIP(hipSetDevice(device));
+    metric_ = image.metric;
+    scalar_ = image.scalar;
+    count_present_ = image.count_present;
+
+    const std::uint64_t n = image.size;
+    const std::uint32_t m = (std::uint32_t)image.connectivity, m0 = (std::uint32_t)image.connectivity_base;
+    const std::uint32_t bpv = (std::uint32_t)image.cols;
+
+    // lanes per row: the smallest power of two covering the row's 16-byte chunks, at most 8 (= one 128-byte line per load)
+    const std::uint32_t raw_chunks = std::max<std::uint32_t>(1, (bpv + 15) / 16);
+    lanes_ = std::min<std::uint32_t>(8, pow2_ceil(raw_chunks));
+    const std::uint32_t row_stride = (bpv + 16 * lanes_ - 1) / (16 * lanes_) * (16 * lanes_);
+
+    // ---- host pass 1: tape offsets (sequential prefix) and the number of upper-level lists
+    std::vector<std::uint64_t> offsets(n + 1);
+    std::vector<std::uint32_t> upper_ref(n);
+    std::uint64_t offset = 0, lists = 0;
+    for (std::uint64_t i = 0; i < n; ++i) {
+        offsets[i] = offset;
+        const std::int16_t level = image.level(i);
+        if (level < 0)
+            return "Failed to pull nodes from the stream";
+        upper_ref[i] = level ? (std::uint32_t)lists : none_slot_k;
+        lists += (std::uint64_t)level;
+        offset += image.node_bytes(level);
+    }
+    offsets[n] = offset;
+    if (offset > image.tapes_length)
+        return "Failed to pull nodes from the stream";
+    if (lists >= none_slot_k)
+        return "Too many upper-level lists for 32-bit references";
+    upper_lists_ = lists;
+
+    // ---- host pass 2: keys, level-0 rows, upper lists (parallel over nodes)
+    std::vector<std::uint64_t> keys(n);
+    std::vector<std::uint32_t> nbr0((std::size_t)n * m0, none_slot_k);
+    std::vector<std::uint32_t> upper((std::size_t)std::max<std::uint64_t>(lists, 1) * m, none_slot_k);
+    std::atomic<bool> corrupt{false}, tombstones{false};
+    parallel_ranges(n, [&](std::uint64_t begin, std::uint64_t end) {
+        for (std::uint64_t i = begin; i < end; ++i) {
+            const std::uint8_t* tape = image.tapes + offsets[i];
+            const std::uint64_t key = image_t::load<std::uint64_t>(tape);
+            keys[i] = key;
+            if (key == free_key_k)
+                tombstones.store(true, std::memory_order_relaxed);
+            const std::int16_t level = image_t::load<std::int16_t>(tape + 8);
+            if (level != image.level(i)) {
+                corrupt.store(true);
+                return;
+            }
+            const std::uint8_t* list = tape + 10;
+            // level 0: keep the reference's order; a slot that re-appears later in the same list could only ever be
+            // seen as "already visited" there (index.hpp:4229), so dropping it preserves the traversal exactly
+            std::uint32_t count = image_t::load<std::uint32_t>(list);
+            if (count > m0) {
+                corrupt.store(true);
+                return;
+            }
+            std::uint32_t* row = nbr0.data() + (std::size_t)i * m0;
+            std::uint32_t kept = 0;
+            for (std::uint32_t j = 0; j < count; ++j) {
+                const std::uint32_t s = image_t::load<std::uint32_t>(list + 4 + 4 * j);
+                if (s >= n) {
+                    corrupt.store(true);
+                    return;
+                }
+                bool seen = false;
+                for (std::uint32_t k = 0; k < kept && !seen; ++k)
+                    seen = row[k] == s;
+                if (!seen)
+                    row[kept++] = s;
+            }
+            list += 4 + 4 * (std::size_t)m0;
+            // upper levels: no visited set is consulted there (index.hpp:3976-4001): keep lists verbatim
+            for (std::int16_t l = 1; l <= level; ++l, list += 4 + 4 * (std::size_t)m) {
+                count = image_t::load<std::uint32_t>(list);
+                if (count > m) {
+                    corrupt.store(true);
+                    return;
+                }
+                std::uint32_t* cells = upper.data() + ((std::size_t)upper_ref[i] + (l - 1)) * m;
+                for (std::uint32_t j = 0; j < count; ++j) {
+                    const std::uint32_t s = image_t::load<std::uint32_t>(list + 4 + 4 * j);
+                    if (s >= n || image.level(s) < l) {
+                        corrupt.store(true);
+                        return;
+                    }
+                    cells[j] = s;
+                }
+            }
+        }
+    });
+    if (corrupt.load())
+        return "Failed to pull nodes from the stream";
+    if (n && image.level(image.entry_slot) < (std::int16_t)image.max_level)
+        return "Failed to pull the header from the stream";
+
+    // ---- upload
+    release();
+    device_ = device;
+    const std::size_t vectors_bytes = (std::size_t)n * row_stride;
+    auto allocate = [&](void** p, std::size_t bytes) -> hipError_t {
+        device_bytes_ += std::max<std::size_t>(bytes, 16);
+        return hipMalloc(p, std::max<std::size_t>(bytes, 16));
+    };
+    device_bytes_ = 0;
+    UA_HIP(allocate(&d_vectors_, vectors_bytes));
+    UA_HIP(allocate(&d_nbr0_, nbr0.size() * 4));
+    UA_HIP(allocate(&d_upper_ref_, upper_ref.size() * 4));
+    UA_HIP(allocate(&d_upper_, upper.size() * 4));
+    UA_HIP(allocate(&d_keys_, keys.size() * 8));
+    if (n) {
+        if (row_stride == bpv) {
+            UA_HIP(hipMemcpy(d_vectors_, image.vectors, vectors_bytes, hipMemcpyHostToDevice));
+        } else {
+            // re-pitch on the host in bounded blocks (rows zero padded to the stride), then plain copies
+            const std::uint64_t block_rows = std::max<std::uint64_t>(1, ((std::uint64_t)256 << 20) / row_stride);
+            std::vector<std::uint8_t> block((std::size_t)std::min<std::uint64_t>(block_rows, n) * row_stride);
+            for (std::uint64_t first = 0; first < n; first += block_rows) {
+                const std::uint64_t rows = std::min<std::uint64_t>(block_rows, n - first);
+                std::memset(block.data(), 0, (std::size_t)rows * row_stride);
+                parallel_ranges(rows, [&](std::uint64_t begin, std::uint64_t end) {
+                    for (std::uint64_t r = begin; r < end; ++r)
+                        std::memcpy(block.data() + r * row_stride, image.vectors + (first + r) * bpv, bpv);
+                });
+                UA_HIP(hipMemcpy(static_cast<std::uint8_t*>(d_vectors_) + first * row_stride, block.data(),
+                                 (std::size_t)rows * row_stride, hipMemcpyHostToDevice));
+            }
+        }
+        UA_HIP(hipMemcpy(d_nbr0_, nbr0.data(), nbr0.size() * 4, hipMemcpyHostToDevice));
+        UA_HIP(hipMemcpy(d_upper_ref_, upper_ref.data(), upper_ref.size() * 4, hipMemcpyHostToDevice));
+        UA_HIP(hipMemcpy(d_keys_, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
+    }
+    UA_HIP(hipMemcpy(d_upper_, upper.data(), upper.size() * 4, hipMemcpyHostToDevice));
+
+    view_.vectors = static_cast<const std::uint8_t*>(d_vectors_);
+    view_.nbr0 = static_cast<const std::uint32_t*>(d_nbr0_);
+    view_.upper_ref = static_cast<const std::uint32_t*>(d_upper_ref_);
+    view_.upper = static_cast<const std::uint32_t*>(d_upper_);
+    view_.keys = static_cast<const std::uint64_t*>(d_keys_);
+    view_.size = n;
+    view_.row_stride = row_stride;
+    view_.chunks = row_stride / 16;
+    view_.bytes_per_vector = bpv;
+    view_.dimensions = (std::uint32_t)image.dimensions;
+    view_.m = m;
+    view_.m0 = m0;
+    view_.max_level = (std::uint32_t)image.max_level;
+    view_.entry_slot = (std::uint32_t)image.entry_slot;
+    view_.has_tombstones = tombstones.load() ? 1u : 0u;
+
+    UA_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    UA_HIP(hipEventCreate(&event_begin_));
+    UA_HIP(hipEventCreate(&event_end_));
+    return nullptr;
+}
+
+const char* snapshot_t::ensure_workspace(std::size_t queries, std::size_t scratch_bytes) {
+    if (queries > workspace_queries_) {
+        if (d_status_)
+            (void)hipFree(d_status_);
+        if (d_todo_)
+            (void)hipFree(d_todo_);
+        if (h_status_)
+            (void)hipHostFree(h_status_);
+        d_status_ = d_todo_ = h_status_ = nullptr;
+        workspace_queries_ = 0;
+        UA_HIP(hipMalloc((void**)&d_status_, queries * 4));
+        UA_HIP(hipMalloc((void**)&d_todo_, queries * 4));
+        UA_HIP(hipHostMalloc((void**)&h_status_, queries * 4, hipHostMallocDefault));
+        workspace_queries_ = queries;
+    }
+    if (scratch_bytes > scratch_bytes_) {
+        if (d_scratch_)
+            (void)hipFree(d_scratch_);
+        d_scratch_ = nullptr;
+        scratch_bytes_ = 0;
+        UA_HIP(hipMalloc((void**)&d_scratch_, scratch_bytes));
+        scratch_bytes_ = scratch_bytes;
+    }
+    return nullptr;
+}
+
+const char* snapshot_t::ensure_staging(std::size_t query_bytes, std::size_t count, std::size_t wanted) {
+    // queries | keys | distances | counts | visited | computed, each 256-byte aligned
+    auto pad = [](std::size_t b) { return (b + 255) & ~(std::size_t)255; };
+    const std::size_t need = pad(query_bytes * count) + pad(count * wanted * 8) + pad(count * wanted * 4) + 3 * pad(count * 8);
+    if (need > stage_bytes_) {
+        if (d_stage_)
+            (void)hipFree(d_stage_);
+        d_stage_ = nullptr;
+        stage_bytes_ = 0;
+        UA_HIP(hipMalloc((void**)&d_stage_, need));
+        stage_bytes_ = need;
+    }
+    return nullptr;
+}
+
+static hipError_t launch_search(scalar_kind_t scalar, const launch_params_t& p, const snapshot_view_t& view,
+                                const search_args_t& args) {
+    switch (scalar) {
+    case scalar_f32_k: return launch_search_f32(p, view, args);
+    case scalar_f16_k: return launch_search_f16(p, view, args);
+    case scalar_i8_k: return launch_search_i8(p, view, args);
+    case scalar_b1x8_k: return launch_search_b1(p, view, args);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+/// Fills the outputs of queries that cannot produce anything (empty index): count 0, key 0 / signalling NaN padding.
+__global__ void fill_empty_kernel(std::uint64_t* keys, std::uint32_t* distance_bits, std::uint64_t* counts,
+                                  std::uint64_t* visited, std::uint64_t* computed, std::uint64_t queries,
+                                  std::uint64_t wanted) {
+    const std::uint64_t i = blockIdx.x * (std::uint64_t)blockDim.x + threadIdx.x;
+    if (i < queries * wanted)
+        keys[i] = 0, distance_bits[i] = signaling_nan_bits_k;
+    if (i < queries)
+        counts[i] = 0, visited[i] = 0, computed[i] = 0;
+}
+
+const char* snapshot_t::search_device(const void* queries, std::size_t count, std::size_t stride_bytes,
+                                      std::size_t wanted, std::size_t expansion, std::uint64_t* keys,
+                                      float* distances, std::uint64_t* counts, std::uint64_t* visited,
+                                      std::uint64_t* computed, hipStream_t stream, const search_tuning_t& tuning,
+                                      search_stats_t* stats, bool timed) {
+    if (stats)
+        *stats = search_stats_t{};
+    if (!count || !wanted) // index.hpp:3025-3027: nothing wanted, nothing found
+        return nullptr;
+    if (count >= none_slot_k || wanted >= (1u << 24))
+        return "Batch is too large";
+    std::lock_guard<std::mutex> lock(mutex_);
+    UA_HIP(hipSetDevice(device_));
+    if (!stream)
+        stream = stream_;
+
+    if (view_.size == 0) { // index.hpp:3034-3037
+        const std::uint64_t cells = std::max<std::uint64_t>(count * wanted, count);
+        hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, keys,
+                           reinterpret_cast<std::uint32_t*>(distances), counts, visited, computed,
+                           (std::uint64_t)count, (std::uint64_t)wanted);
+        UA_HIP(hipGetLastError());
+        UA_HIP(hipStreamSynchronize(stream));
+        return nullptr;
+    }
+
+    if (!expansion)
+        expansion = default_expansion_search_k;
+    const std::uint32_t ef = (std::uint32_t)std::max(expansion, wanted); // index.hpp:3052
+
+    // ---- scratch sizing. A hop marks at most m0 slots and pushes at most m0 candidates, so hops·m0 bounds both; hops ≈ ef
+    // in practice (73-84 pops, 1.2-2.1 k distances at ef = 64), hence the generous multiples below.
+    const std::uint32_t query_lds = view_.chunks * (scalar_ == scalar_f16_k ? 32u : 16u);
+    const std::uint32_t lds_budget = (std::uint32_t)env_size("USEARCH_AMD_LDS_BUDGET", 160 * 1024);
+    std::uint32_t hash_cap = tuning.hash_cap ? tuning.hash_cap : (std::uint32_t)env_size("USEARCH_AMD_HASH_CAP", 0);
+    if (!hash_cap)
+        hash_cap = std::max<std::uint32_t>(1024, ef * 64);
+    hash_cap = pow2_ceil(hash_cap);
+    std::uint32_t next_cap = tuning.next_cap ? tuning.next_cap : (std::uint32_t)env_size("USEARCH_AMD_NEXT_CAP", 0);
+    if (!next_cap)
+        next_cap = std::max<std::uint32_t>(256, ef * 8);
+    // never larger than the index could possibly need
+    hash_cap = std::min<std::uint32_t>(hash_cap, pow2_ceil((std::uint32_t)std::min<std::uint64_t>(view_.size * 2 + 128, 1u << 30)));
+    next_cap = (std::uint32_t)std::min<std::uint64_t>(next_cap, view_.size + 64);
+    const std::uint32_t unroll = tuning.unroll ? tuning.unroll : (std::uint32_t)env_size("USEARCH_AMD_UNROLL", view_.chunks / lanes_ >= 8 ? 8 : 4);
+
+    const bool force_global = tuning.force_global_scratch || env_size("USEARCH_AMD_FORCE_GLOBAL", 0) != 0;
+    if (const char* e = ensure_workspace(count, 0))
+        return e;
+
+    search_args_t args{};
+    args.queries = static_cast<const std::uint8_t*>(queries);
+    args.query_stride = stride_bytes;
+    args.wanted = (std::uint32_t)wanted;
+    args.ef = ef;
+    args.keys = keys;
+    args.distances = distances;
+    args.counts = counts;
+    args.visited = visited;
+    args.computed = computed;
+    args.status = d_status_;
+
+    launch_params_t params{};
+    params.metric = metric_;
+    params.lanes = lanes_;
+    params.unroll = unroll;
+    params.stream = stream;
+
+    float total_ms = 0.f;
+    auto timed_launch = [&](const launch_params_t& p, const search_args_t& a) -> const char* {
+        if (timed)
+            UA_HIP(hipEventRecord(event_begin_, stream));
+        UA_HIP(launch_search(scalar_, p, view_, a));
+        if (timed) {
+            UA_HIP(hipEventRecord(event_end_, stream));
+            UA_HIP(hipEventSynchronize(event_end_));
+            float ms = 0.f;
+            UA_HIP(hipEventElapsedTime(&ms, event_begin_, event_end_));
+            total_ms += ms;
+        }
+        return nullptr;
+    };
+    /// Collects the indices of overflowed queries among `pending` into h_status_/d_todo_; returns how many.
+    auto collect_overflow = [&](const std::vector<std::uint32_t>* previous, std::vector<std::uint32_t>& todo) -> const char* {
+        UA_HIP(hipMemcpyAsync(h_status_, d_status_, count * 4, hipMemcpyDeviceToHost, stream));
+        UA_HIP(hipStreamSynchronize(stream));
+        todo.clear();
+        if (previous) {
+            for (std::uint32_t q : *previous)
+                if (h_status_[q] == status_overflow_k)
+                    todo.push_back(q);
+        } else {
+            for (std::uint32_t q = 0; q < count; ++q)
+                if (h_status_[q] == status_overflow_k)
+                    todo.push_back(q);
+        }
+        if (!todo.empty())
+            UA_HIP(hipMemcpyAsync(d_todo_, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, stream));
+        return nullptr;
+    };
+
+    std::vector<std::uint32_t> todo, todo_next;
+    std::uint32_t passes = 0;
+    bool have_todo = false;
+
+    // ---- pass 1 (+2): LDS scratch, second time with everything LDS can hold
+    if (!force_global) {
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            scratch_layout_t layout = scratch_layout(ef, next_cap, hash_cap * 4);
+            if (query_lds + layout.total > lds_budget) {
+                if (attempt == 0) {
+                    // shrink to what fits; if even the minimum does not fit, go global
+                    while (hash_cap > 1024 && query_lds + scratch_layout(ef, next_cap, hash_cap * 4).total > lds_budget)
+                        hash_cap /= 2;
+                    while (next_cap > 128 && query_lds + scratch_layout(ef, next_cap, hash_cap * 4).total > lds_budget)
+                        next_cap /= 2;
+                    layout = scratch_layout(ef, next_cap, hash_cap * 4);
+                }
+                if (query_lds + layout.total > lds_budget)
+                    break;
+            }
+            args.hash_cap = hash_cap;
+            args.next_cap = next_cap;
+            args.todo = have_todo ? d_todo_ : nullptr;
+            args.count = have_todo ? (std::uint32_t)todo.size() : (std::uint32_t)count;
+            params.global_scratch = false;
+            params.lds_bytes = (std::uint32_t)(query_lds + layout.total);
+            if (stats && attempt == 1)
+                stats->retried_lds = args.count;
+            if (const char* e = timed_launch(params, args))
+                return e;
+            ++passes;
+            if (const char* e = collect_overflow(have_todo ? &todo : nullptr, todo_next))
+                return e;
+            todo.swap(todo_next);
+            have_todo = true;
+            if (todo.empty())
+                break;
+            // enlarge for the second attempt: ×8 cells, ×8 frontier, clipped to the LDS budget
+            std::uint32_t bigger_hash = hash_cap, bigger_next = next_cap;
+            for (int grow = 0; grow < 3; ++grow) {
+                if (query_lds + scratch_layout(ef, bigger_next * 2, bigger_hash * 4).total <= lds_budget)
+                    bigger_next *= 2;
+                if (query_lds + scratch_layout(ef, bigger_next, bigger_hash * 2 * 4).total <= lds_budget)
+                    bigger_hash *= 2;
+            }
+            if (bigger_hash == hash_cap && bigger_next == next_cap)
+                break;
+            hash_cap = bigger_hash;
+            next_cap = bigger_next;
+        }
+    }
+
+    // ---- pass 3: global-memory scratch — exact sizes (one bit per slot, one frontier cell per slot), cannot overflow
+    if (force_global || (have_todo && !todo.empty())) {
+        if (!have_todo) {
+            todo.resize(count);
+            for (std::uint32_t q = 0; q < count; ++q)
+                todo[q] = q;
+        }
+        if (stats)
+            stats->retried_global = (std::uint32_t)todo.size();
+        const std::uint64_t bitmap_bytes = ((view_.size + 31) / 32) * 4;
+        const std::uint32_t frontier = (std::uint32_t)std::min<std::uint64_t>(view_.size + 64, 0xFFFFFFF0u);
+        const scratch_layout_t layout = scratch_layout(ef, frontier, bitmap_bytes);
+        const std::size_t slab = (layout.total + 255) & ~(std::size_t)255;
+        const std::size_t budget = env_size("USEARCH_AMD_GLOBAL_SCRATCH_BYTES", (std::size_t)2 << 30);
+        const std::size_t waves = std::max<std::size_t>(1, std::min<std::size_t>(todo.size(), budget / slab));
+        if (const char* e = ensure_workspace(count, waves * slab))
+            return e;
+        for (std::size_t begin = 0; begin < todo.size(); begin += waves) {
+            const std::size_t chunk = std::min(waves, todo.size() - begin);
+            UA_HIP(hipMemcpyAsync(d_todo_, todo.data() + begin, chunk * 4, hipMemcpyHostToDevice, stream));
+            // only the bitmaps need zeroing
+            UA_HIP(hipMemset2DAsync(d_scratch_ + layout.visits, slab, 0, bitmap_bytes, chunk, stream));
+            args.hash_cap = 0;
+            args.next_cap = frontier;
+            args.todo = d_todo_;
+            args.count = (std::uint32_t)chunk;
+            args.scratch = d_scratch_;
+            args.scratch_stride = slab;
+            params.global_scratch = true;
+            params.lds_bytes = query_lds;
+            if (const char* e = timed_launch(params, args))
+                return e;
+            ++passes;
+            UA_HIP(hipStreamSynchronize(stream));
+        }
+        UA_HIP(hipMemcpyAsync(h_status_, d_status_, count * 4, hipMemcpyDeviceToHost, stream));
+        UA_HIP(hipStreamSynchronize(stream));
+        for (std::uint32_t q : todo)
+            if (h_status_[q] != status_done_k)
+                return "Search scratch overflow in the global-memory pass";
+    }
+    if (stats) {
+        stats->passes = passes;
+        stats->kernel_ms = total_ms;
+    }
+    return nullptr;
+}
+
+const char* snapshot_t::search_host(const void* queries, scalar_kind_t query_kind, std::size_t count,
+                                    std::size_t stride_bytes, std::size_t wanted, std::size_t expansion,
+                                    std::uint64_t* keys, float* distances, std::uint64_t* counts,
+                                    std::uint64_t* visited, std::uint64_t* computed, const search_tuning_t& tuning,
+                                    search_stats_t* stats) {
+    if (stats)
+        *stats = search_stats_t{};
+    if (!count || !wanted)
+        return nullptr;
+    const std::size_t bpv = view_.bytes_per_vector ? view_.bytes_per_vector : bytes_per_vector(scalar_, view_.dimensions);
+    const std::size_t dims = view_.dimensions;
+
+    // cast (or gather strided rows) into a dense host block in the storage kind — index_dense.hpp:2058-2064
+    std::vector<std::uint8_t> dense;
+    const std::uint8_t* source = static_cast<const std::uint8_t*>(queries);
+    if (query_kind != scalar_) {
+        const std::size_t query_bytes = bytes_per_vector(query_kind, dims);
+        if (query_bytes == 0)
+            return "Unsupported query scalar kind";
+        if (count > 1 && stride_bytes < query_bytes)
+            return "Query stride is smaller than one query";
+        dense.assign(count * bpv, 0);
+        parallel_ranges(count, [&](std::uint64_t begin, std::uint64_t end) {
+            for (std::uint64_t q = begin; q < end; ++q)
+                cast_vector(query_kind, scalar_, source + q * stride_bytes, dims, dense.data() + q * bpv);
+        });
+        source = dense.data();
+    } else if (count > 1 && stride_bytes != bpv) {
+        if (stride_bytes < bpv)
+            return "Query stride is smaller than one query";
+        dense.resize(count * bpv);
+        parallel_ranges(count, [&](std::uint64_t begin, std::uint64_t end) {
+            for (std::uint64_t q = begin; q < end; ++q)
+                std::memcpy(dense.data() + q * bpv, source + q * stride_bytes, bpv);
+        });
+        source = dense.data();
+    }
+
+    std::lock_guard<std::mutex> host_lock(host_mutex_); // the staging block below is shared
+    UA_HIP(hipSetDevice(device_));
+    if (const char* e = ensure_staging(bpv, count, wanted))
+        return e;
+    auto pad = [](std::size_t b) { return (b + 255) & ~(std::size_t)255; };
+    std::uint8_t* d_queries = d_stage_;
+    std::uint64_t* d_keys = reinterpret_cast<std::uint64_t*>(d_queries + pad(bpv * count));
+    float* d_distances = reinterpret_cast<float*>(reinterpret_cast<std::uint8_t*>(d_keys) + pad(count * wanted * 8));
+    std::uint64_t* d_counts = reinterpret_cast<std::uint64_t*>(reinterpret_cast<std::uint8_t*>(d_distances) + pad(count * wanted * 4));
+    std::uint64_t* d_visited = reinterpret_cast<std::uint64_t*>(reinterpret_cast<std::uint8_t*>(d_counts) + pad(count * 8));
+    std::uint64_t* d_computed = reinterpret_cast<std::uint64_t*>(reinterpret_cast<std::uint8_t*>(d_visited) + pad(count * 8));
+
+    UA_HIP(hipMemcpy(d_queries, source, bpv * count, hipMemcpyHostToDevice));
+    if (const char* e = search_device(d_queries, count, bpv, wanted, expansion, d_keys, d_distances, d_counts, d_visited,
+                                      d_computed, nullptr, tuning, stats, false))
+        return e;
+    if (keys)
+        UA_HIP(hipMemcpy(keys, d_keys, count * wanted * 8, hipMemcpyDeviceToHost));
+    if (distances)
+        UA_HIP(hipMemcpy(distances, d_distances, count * wanted * 4, hipMemcpyDeviceToHost));
+    if (counts)
+        UA_HIP(hipMemcpy(counts, d_counts, count * 8, hipMemcpyDeviceToHost));
+    if (visited)
+        UA_HIP(hipMemcpy(visited, d_visited, count * 8, hipMemcpyDeviceToHost));
+    if (computed)
+        UA_HIP(hipMemcpy(computed, d_computed, count * 8, hipMemcpyDeviceToHost));
+    return nullptr;
+}
+
+const char* snapshot_t::distances_host(const void* queries, std::size_t count, std::size_t stride_bytes,
+                                       const std::uint32_t* slots, std::size_t slots_per_query, float* out) {
+    if (!count || !slots_per_query)
+        return nullptr;
+    std::lock_guard<std::mutex> lock(mutex_);
+    UA_HIP(hipSetDevice(device_));
+    const std::size_t bpv = view_.bytes_per_vector;
+    std::uint8_t* d_queries = nullptr;
+    std::uint32_t* d_slots = nullptr;
+    float* d_out = nullptr;
+    UA_HIP(hipMalloc((void**)&d_queries, bpv * count));
+    UA_HIP(hipMalloc((void**)&d_slots, count * slots_per_query * 4));
+    UA_HIP(hipMalloc((void**)&d_out, count * slots_per_query * 4));
+    const char* error = nullptr;
+    do {
+        std::vector<std::uint8_t> dense(count * bpv);
+        for (std::size_t q = 0; q < count; ++q)
+            std::memcpy(dense.data() + q * bpv, static_cast<const std::uint8_t*>(queries) + q * stride_bytes, bpv);
+        hipError_t e = hipMemcpy(d_queries, dense.data(), bpv * count, hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = hipMemcpy(d_slots, slots, count * slots_per_query * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            error = hip_message(e);
+            break;
+        }
+        distances_params_t p{};
+        p.metric = metric_;
+        p.lanes = lanes_;
+        p.lds_bytes = view_.chunks * (scalar_ == scalar_f16_k ? 32u : 16u) + 512;
+        p.stream = stream_;
+        p.queries = d_queries;
+        p.query_stride = bpv;
+        p.slots = d_slots;
+        p.slots_per_query = (std::uint32_t)slots_per_query;
+        p.count = (std::uint32_t)count;
+        p.out = d_out;
+        switch (scalar_) {
+        case scalar_f32_k: e = launch_distances_f32(p, view_); break;
+        case scalar_f16_k: e = launch_distances_f16(p, view_); break;
+        case scalar_i8_k: e = launch_distances_i8(p, view_); break;
+        case scalar_b1x8_k: e = launch_distances_b1(p, view_); break;
+        default: e = hipErrorInvalidValue; break;
+        }
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(stream_);
+        if (e == hipSuccess)
+            e = hipMemcpy(out, d_out, count * slots_per_query * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            error = hip_message(e);
+    } while (false);
+    (void)hipFree(d_queries);
+    (void)hipFree(d_slots);
+    (void)hipFree(d_out);
+    return error;
+}
+
+} // namespace usearch_amd

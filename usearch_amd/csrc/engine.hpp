@@ -1,0 +1,142 @@
+/**
+ *  usearch_amd/csrc/engine.hpp — host side of the MI355X search engine: an immutable HBM snapshot of one index and the
+ *  batched search over it.
+ *
+ *  Replaces, for the search path only, what `index_dense_gt` owns on the CPU (/root/reference/include/usearch/
+ *  index_dense.hpp:419-460 `metric_proxy_t` + `vectors_lookup_`, index.hpp:2280 `nodes_`) and what its callers loop over
+ *  (`cpp/bench.cpp:352-377`, `python/lib.cpp:261-319`): one call = one batch of independent queries.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+#include "image.hpp"
+
+namespace usearch_amd {
+
+/// Tunables of one search launch; zeros mean "choose for me".
+struct search_tuning_t {
+    std::uint32_t hash_cap = 0; ///< LDS visited-set cells (power of two)
+    std::uint32_t next_cap = 0; ///< LDS frontier capacity
+    std::uint32_t unroll = 0;   ///< 16-byte loads in flight per lane inside one row (4 or 8)
+    bool force_global_scratch = false;
+};
+
+struct search_stats_t {
+    std::uint32_t passes = 0;            ///< launches needed (1 = every query fit its LDS scratch)
+    std::uint32_t retried_lds = 0;       ///< queries rerun with the enlarged LDS scratch
+    std::uint32_t retried_global = 0;    ///< queries rerun with the global-memory scratch
+    float kernel_ms = 0.f;               ///< HIP-event time of the search launches of this call (when `timed`)
+};
+
+class snapshot_t {
+  public:
+    snapshot_t() = default;
+    ~snapshot_t();
+    snapshot_t(const snapshot_t&) = delete;
+    snapshot_t& operator=(const snapshot_t&) = delete;
+
+    /// Flattens `image` into the HBM layout of `snapshot_view_t` on `device`. Returns nullptr or a static message.
+    const char* build(const image_t& image, int device);
+
+    const snapshot_view_t& view() const { return view_; }
+    metric_kind_t metric() const { return metric_; }
+    scalar_kind_t scalar() const { return scalar_; }
+    std::uint32_t lanes_per_row() const { return lanes_; }
+    int device() const { return device_; }
+    std::size_t device_bytes() const { return device_bytes_; }
+    std::uint64_t count_present() const { return count_present_; }
+    std::uint64_t upper_lists() const { return upper_lists_; }
+
+    /**
+     *  Batched search, all pointers device-resident, queries already in the storage scalar kind.
+     *  Enqueues on `stream` and waits for it (the retry ladder needs the per-query status).
+     */
+    const char* search_device(const void* queries, std::size_t count, std::size_t stride_bytes, std::size_t wanted,
+                              std::size_t expansion, std::uint64_t* keys, float* distances, std::uint64_t* counts,
+                              std::uint64_t* visited, std::uint64_t* computed, hipStream_t stream,
+                              const search_tuning_t& tuning, search_stats_t* stats, bool timed);
+
+    /// Same with host buffers and a query scalar kind that may differ from the storage kind (cast first).
+    const char* search_host(const void* queries, scalar_kind_t query_kind, std::size_t count, std::size_t stride_bytes,
+                            std::size_t wanted, std::size_t expansion, std::uint64_t* keys, float* distances,
+                            std::uint64_t* counts, std::uint64_t* visited, std::uint64_t* computed,
+                            const search_tuning_t& tuning, search_stats_t* stats);
+
+    /// out[q][j] = metric(query q, stored row slots[q][j]); host buffers, queries in storage kind.
+    const char* distances_host(const void* queries, std::size_t count, std::size_t stride_bytes,
+                               const std::uint32_t* slots, std::size_t slots_per_query, float* out);
+
+  private:
+    const char* ensure_workspace(std::size_t queries, std::size_t scratch_bytes);
+    const char* ensure_staging(std::size_t query_bytes, std::size_t count, std::size_t wanted);
+    void release();
+
+    snapshot_view_t view_{};
+    metric_kind_t metric_ = metric_unknown_k;
+    scalar_kind_t scalar_ = scalar_unknown_k;
+    std::uint32_t lanes_ = 1;
+    int device_ = 0;
+    std::size_t device_bytes_ = 0;
+    std::uint64_t count_present_ = 0, upper_lists_ = 0;
+
+    void* d_vectors_ = nullptr;
+    void* d_nbr0_ = nullptr;
+    void* d_upper_ref_ = nullptr;
+    void* d_upper_ = nullptr;
+    void* d_keys_ = nullptr;
+
+    std::mutex mutex_;      ///< one batch at a time per snapshot: the workspace below is shared
+    std::mutex host_mutex_; ///< serialises `search_host` callers around the staging block
+    std::uint32_t* d_status_ = nullptr;
+    std::uint32_t* d_todo_ = nullptr;
+    std::uint32_t* h_status_ = nullptr; ///< pinned
+    std::size_t workspace_queries_ = 0;
+    std::uint8_t* d_scratch_ = nullptr;
+    std::size_t scratch_bytes_ = 0;
+    // staging for search_host
+    std::uint8_t* d_stage_ = nullptr;
+    std::size_t stage_bytes_ = 0;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t event_begin_ = nullptr, event_end_ = nullptr;
+};
+
+/// Per-scalar-kind launchers, one translation unit each (compile time): defined in search_<kind>.hip.
+struct launch_params_t {
+    metric_kind_t metric;
+    std::uint32_t lanes;
+    std::uint32_t unroll;
+    bool global_scratch;
+    std::uint32_t lds_bytes;
+    hipStream_t stream;
+};
+hipError_t launch_search_f32(const launch_params_t&, const snapshot_view_t&, const search_args_t&);
+hipError_t launch_search_f16(const launch_params_t&, const snapshot_view_t&, const search_args_t&);
+hipError_t launch_search_i8(const launch_params_t&, const snapshot_view_t&, const search_args_t&);
+hipError_t launch_search_b1(const launch_params_t&, const snapshot_view_t&, const search_args_t&);
+
+struct distances_params_t {
+    metric_kind_t metric;
+    std::uint32_t lanes;
+    std::uint32_t lds_bytes;
+    hipStream_t stream;
+    const std::uint8_t* queries;
+    std::uint64_t query_stride;
+    const std::uint32_t* slots;
+    std::uint32_t slots_per_query;
+    std::uint32_t count;
+    float* out;
+};
+hipError_t launch_distances_f32(const distances_params_t&, const snapshot_view_t&);
+hipError_t launch_distances_f16(const distances_params_t&, const snapshot_view_t&);
+hipError_t launch_distances_i8(const distances_params_t&, const snapshot_view_t&);
+hipError_t launch_distances_b1(const distances_params_t&, const snapshot_view_t&);
+
+/// Is there a HIP kernel for this (metric, scalar) pair?
+bool kernel_available(metric_kind_t metric, scalar_kind_t scalar);
+
+} // namespace usearch_amd

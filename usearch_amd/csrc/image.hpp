@@ -1,0 +1,115 @@
+/**
+ *  usearch_amd/csrc/image.hpp — host-side reader of a serialized USearch v2 index image.
+ *
+ *  Byte layout, as written by the reference (`/root/reference/include/usearch/…`):
+ *    index_dense.hpp:1004-1030   [u32 rows][u32 cols = bytes per vector][rows × cols vector bytes]
+ *    index_dense.hpp:42-79       64-byte head: "usearch" magic(7) | u16×3 version | u8 metric | u8 scalar | u8 key kind |
+ *                                u8 slot kind | u64 present | u64 deleted | u64 dimensions | u8 multi | zero padding
+ *    index.hpp:1863-1869         5 × u64: size, connectivity, connectivity_base, max_level, entry_slot
+ *    index.hpp:3298-3305         i16 level per node
+ *    index.hpp:3308-3314         node tapes back to back, each (index.hpp:2085, 3731-3748):
+ *                                u64 key | i16 level | {u32 count, u32 × M0} | level × {u32 count, u32 × M}
+ *  Everything after the matrix is unaligned, hence the memcpy loads. The image is borrowed, never copied.
+ */
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+
+namespace usearch_amd {
+
+struct image_t {
+    const std::uint8_t* bytes = nullptr;
+    std::size_t length = 0;
+
+    std::uint64_t rows = 0, cols = 0;
+    const std::uint8_t* vectors = nullptr;
+
+    std::uint16_t version[3] = {0, 0, 0};
+    metric_kind_t metric = metric_unknown_k;
+    scalar_kind_t scalar = scalar_unknown_k;
+    std::uint64_t count_present = 0, count_deleted = 0, dimensions = 0;
+    bool multi = false;
+
+    std::uint64_t size = 0, connectivity = 0, connectivity_base = 0, max_level = 0, entry_slot = 0;
+    const std::uint8_t* levels = nullptr;
+    const std::uint8_t* tapes = nullptr; ///< first node tape
+    std::size_t tapes_length = 0;
+
+    template <typename scalar_at> static scalar_at load(const std::uint8_t* p) {
+        scalar_at v;
+        std::memcpy(&v, p, sizeof(v));
+        return v;
+    }
+
+    std::size_t node_bytes(std::int16_t level) const {
+        return 10 + (4 + 4 * connectivity_base) + (std::size_t)level * (4 + 4 * connectivity);
+    }
+
+    /// Parses the fixed-size parts. Returns nullptr on success or a static message (the reference's wording where
+    /// the reference has one: index_dense.hpp:1102-1146, index.hpp:3330-3370).
+    const char* open(const void* image, std::size_t image_length) {
+        bytes = static_cast<const std::uint8_t*>(image);
+        length = image_length;
+        const std::uint8_t* p = bytes;
+        const std::uint8_t* const end = bytes + length;
+        if (length < 8)
+            return "Failed to read 32-bit dimensions of the matrix";
+        rows = load<std::uint32_t>(p);
+        cols = load<std::uint32_t>(p + 4);
+        p += 8;
+        if ((std::uint64_t)(end - p) < rows * cols)
+            return "Failed to read vectors";
+        vectors = p;
+        p += rows * cols;
+        if ((std::size_t)(end - p) < 64)
+            return "Failed to read the index ";
+        if (std::memcmp(p, "usearch", 7) != 0)
+            return "Magic header mismatch - the file isn't an index";
+        version[0] = load<std::uint16_t>(p + 7);
+        version[1] = load<std::uint16_t>(p + 9);
+        version[2] = load<std::uint16_t>(p + 11);
+        if (version[0] != 2)
+            return "File format may be different, please rebuild";
+        metric = (metric_kind_t)p[13];
+        scalar = (scalar_kind_t)p[14];
+        if (p[15] != scalar_u64_k)
+            return "Key type doesn't match, consider rebuilding";
+        if (p[16] != scalar_u32_k)
+            return "Slot type doesn't match, consider rebuilding";
+        count_present = load<std::uint64_t>(p + 17);
+        count_deleted = load<std::uint64_t>(p + 25);
+        dimensions = load<std::uint64_t>(p + 33);
+        multi = p[41] != 0;
+        p += 64;
+        if ((std::size_t)(end - p) < 40)
+            return "Failed to pull the header from the stream";
+        size = load<std::uint64_t>(p);
+        connectivity = load<std::uint64_t>(p + 8);
+        connectivity_base = load<std::uint64_t>(p + 16);
+        max_level = load<std::uint64_t>(p + 24);
+        entry_slot = load<std::uint64_t>(p + 32);
+        p += 40;
+        if (size != rows)
+            return "Index size and the number of vectors doesn't match";
+        if (size >= none_slot_k)
+            return "Index is too large for 32-bit slots";
+        if ((std::uint64_t)(end - p) < size * 2)
+            return "Failed to pull nodes levels from the stream";
+        levels = p;
+        p += size * 2;
+        tapes = p;
+        tapes_length = (std::size_t)(end - p);
+        if (size && (entry_slot >= size || connectivity == 0 || connectivity_base == 0))
+            return "Failed to pull the header from the stream";
+        if (cols != bytes_per_vector(scalar, dimensions))
+            return "Vector size doesn't match the scalar kind and dimensions";
+        return nullptr;
+    }
+
+    std::int16_t level(std::uint64_t slot) const { return load<std::int16_t>(levels + 2 * slot); }
+};
+
+} // namespace usearch_amd

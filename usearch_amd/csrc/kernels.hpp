@@ -1,0 +1,713 @@
+/**
+ *  usearch_amd/csrc/kernels.hpp — CDNA4 (gfx950) device code of the batched HNSW search.
+ *
+ *  One 64-lane wavefront (= one workgroup) walks one query: the greedy descent over the upper levels
+ *  (reference `index_gt::search_for_one_`, /root/reference/include/usearch/index.hpp:3964-4003) and the best-first
+ *  beam search on level 0 (`search_to_find_in_base_`, index.hpp:4176-4246). Its `top` (sorted_buffer_gt,
+ *  index.hpp:845-956), `next` (max_heap_gt, index.hpp:664-835) and `visits` (growing_hash_set_gt, index.hpp:1085-1211)
+ *  live in LDS; a second instantiation keeps them in a per-wave global scratch slab for queries that outgrow LDS.
+ *
+ *  Result parity with the reference is by construction, not by luck:
+ *    * distances of all not-yet-visited neighbours of the popped node are evaluated wave-parallel (that is the
+ *      HBM-bound part), but they are COMMITTED to `next`/`top` one by one in neighbour-list order with exactly the
+ *      reference's comparisons (strict `<` / `>`), so `radius` evolves as on the CPU;
+ *    * `top` keeps lower_bound placement (new before equal), `next` is a real binary heap with the reference's
+ *      sift rules, so the pop order among equal distances — the norm for Hamming / i8 — is the reference's;
+ *    * `visits` is an exact set.
+ *  Floating-point sums use a fixed, documented layout (16-byte chunk `c` of a row belongs to lane `c % G` of the
+ *  G-lane group that owns the row; one fused-multiply-add chain per lane in chunk order; XOR butterfly G/2…1) which
+ *  the CPU oracle restates (`oracle/usearch_oracle.c`, `lanes = G`), so float results are bit-reproducible too.
+ *
+ *  No MFMA on purpose: every query gathers different rows (no operand reuse), ~3 FLOP per fetched byte.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+
+namespace usearch_amd {
+
+#define UA_DEVICE __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------------------------------
+//  Wave-level helpers (wave = 64 lanes = the whole workgroup)
+// ---------------------------------------------------------------------------------------------------------------------
+
+UA_DEVICE std::uint32_t lane_id() { return threadIdx.x; }
+
+/**
+ *  Orders this wave's scratch accesses across lanes: later reads see earlier writes of any lane. The LDS flavour
+ *  fences the local address space only, so global loads that are still in flight are not waited for.
+ */
+template <bool global_ak> UA_DEVICE void wave_sync() {
+    if constexpr (global_ak) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    }
+}
+
+UA_DEVICE std::uint32_t uniform_u32(std::uint32_t v) { return (std::uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+UA_DEVICE float uniform_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+UA_DEVICE std::uint32_t read_lane_u32(std::uint32_t v, std::uint32_t lane) {
+    return (std::uint32_t)__builtin_amdgcn_readlane((int)v, (int)uniform_u32(lane));
+}
+UA_DEVICE float read_lane_f32(float v, std::uint32_t lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)uniform_u32(lane)));
+}
+UA_DEVICE std::uint64_t ballot(bool p) { return __ballot(p); }
+UA_DEVICE std::uint32_t popcount64(std::uint64_t m) { return (std::uint32_t)__popcll(m); }
+UA_DEVICE std::uint32_t rank_below(std::uint64_t m, std::uint32_t lane) {
+    return popcount64(m & ((1ull << lane) - 1ull)); // lane < 64
+}
+
+/// {float distance; u32 slot} of index.hpp:2097-2101, packed so that one 8-byte LDS access moves it.
+using cand_t = std::uint64_t;
+UA_DEVICE cand_t make_cand(float d, std::uint32_t slot) {
+    return (cand_t)__builtin_bit_cast(std::uint32_t, d) | ((cand_t)slot << 32);
+}
+UA_DEVICE float cand_distance(cand_t c) { return __builtin_bit_cast(float, (std::uint32_t)c); }
+UA_DEVICE std::uint32_t cand_slot(cand_t c) { return (std::uint32_t)(c >> 32); }
+
+/**
+ *  Scratch accessors. LDS: plain accesses (one wave, in-order LDS pipe). Global slab: agent-scope relaxed atomics, so
+ *  that lanes of the wave exchange data through L2 instead of a possibly stale per-CU L1 line.
+ */
+template <bool global_ak> struct scratch_gt {
+    static UA_DEVICE std::uint32_t load(const std::uint32_t* p) {
+        if constexpr (global_ak)
+            return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            return *p;
+    }
+    static UA_DEVICE void store(std::uint32_t* p, std::uint32_t v) {
+        if constexpr (global_ak)
+            __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            *p = v;
+    }
+    static UA_DEVICE cand_t load(const cand_t* p) {
+        if constexpr (global_ak)
+            return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            return *p;
+    }
+    static UA_DEVICE void store(cand_t* p, cand_t v) {
+        if constexpr (global_ak)
+            __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            *p = v;
+    }
+    static UA_DEVICE float load(const float* p) {
+        return __builtin_bit_cast(float, load(reinterpret_cast<const std::uint32_t*>(p)));
+    }
+    static UA_DEVICE void store(float* p, float v) {
+        store(reinterpret_cast<std::uint32_t*>(p), __builtin_bit_cast(std::uint32_t, v));
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+//  `next`: binary max-heap on the NEGATED distance — index.hpp:664-835
+// ---------------------------------------------------------------------------------------------------------------------
+
+/**
+ *  insert + shift_up (index.hpp:765-770, 808-811: swap while parent < child, strictly). The ancestors of the new leaf
+ *  are non-decreasing towards the root, so the ones the new key overtakes form a prefix of the path: every lane reads
+ *  one ancestor, a ballot finds the prefix length, the overtaken ancestors move one step down in parallel.
+ */
+template <bool global_ak>
+UA_DEVICE void heap_push(cand_t* heap, std::uint32_t& size, float key, std::uint32_t slot) {
+    using mem = scratch_gt<global_ak>;
+    const std::uint32_t lane = lane_id();
+    const std::uint32_t leaf1 = size + 1;                     // 1-based index of the new leaf
+    const std::uint32_t depth = 31u - (std::uint32_t)__clz((int)leaf1); // number of ancestors
+    const bool has = lane >= 1 && lane <= depth;
+    cand_t ancestor = 0;
+    if (has)
+        ancestor = mem::load(heap + ((leaf1 >> lane) - 1));
+    const std::uint64_t overtaken = ballot(has && cand_distance(ancestor) < key);
+    const std::uint32_t rises = popcount64(overtaken);
+    if (has && lane <= rises)
+        mem::store(heap + ((leaf1 >> (lane - 1)) - 1), ancestor);
+    if (lane == 0)
+        mem::store(heap + ((leaf1 >> rises) - 1), make_cand(key, slot));
+    size = leaf1;
+    wave_sync<global_ak>();
+}
+
+/**
+ *  pop + shift_down (index.hpp:786-794, 819-834): the last element replaces the root and sinks; at every level the left
+ *  child wins unless the right one is strictly greater. Inherently sequential: executed wave-uniformly.
+ */
+template <bool global_ak> UA_DEVICE cand_t heap_pop(cand_t* heap, std::uint32_t& size) {
+    using mem = scratch_gt<global_ak>;
+    const std::uint32_t lane = lane_id();
+    const cand_t root = mem::load(heap);
+    const std::uint32_t n = size - 1;
+    const cand_t last = mem::load(heap + n);
+    const float last_key = uniform_f32(cand_distance(last));
+    std::uint32_t i = 0;
+    for (;;) {
+        const std::uint32_t left = 2 * i + 1, right = left + 1;
+        if (left >= n)
+            break;
+        const cand_t l = mem::load(heap + left);
+        const cand_t r = mem::load(heap + (right < n ? right : left));
+        const float lk = uniform_f32(cand_distance(l)), rk = uniform_f32(cand_distance(r));
+        std::uint32_t best = i;
+        float best_key = last_key;
+        cand_t best_cand = last;
+        if (best_key < lk)
+            best = left, best_key = lk, best_cand = l;
+        if (right < n && best_key < rk)
+            best = right, best_key = rk, best_cand = r;
+        if (best == i)
+            break;
+        if (lane == 0)
+            mem::store(heap + i, best_cand);
+        i = best;
+    }
+    if (lane == 0 && n)
+        mem::store(heap + i, last);
+    size = n;
+    wave_sync<global_ak>();
+    return root;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+//  `top`: ascending sorted buffer — index.hpp:845-956
+// ---------------------------------------------------------------------------------------------------------------------
+
+/**
+ *  insert(element, limit) (index.hpp:928-939): position = lower_bound by distance (so the new element lands BEFORE equal
+ *  ones), the worst element falls off when full, an element not better than a full buffer's worst is refused.
+ */
+template <bool global_ak>
+UA_DEVICE bool sorted_insert(cand_t* top, std::uint32_t& size, std::uint32_t limit, float d, std::uint32_t slot) {
+    using mem = scratch_gt<global_ak>;
+    const std::uint32_t lane = lane_id();
+    std::uint32_t position = 0;
+    for (std::uint32_t base = 0; base < size; base += 64) {
+        const std::uint32_t j = base + lane;
+        const bool less = j < size && cand_distance(mem::load(top + j)) < d;
+        position += popcount64(ballot(less));
+    }
+    if (position == limit)
+        return false;
+    const bool full = size == limit;
+    const std::uint32_t end = size - (full ? 1u : 0u); // entries [position, end) move one cell up
+    if (end > position) {
+        const std::uint32_t tiles = (end - position + 63) / 64;
+        for (std::uint32_t t = tiles; t-- > 0;) { // highest tile first: its destination cells are already free
+            const std::uint32_t j = position + t * 64 + lane;
+            cand_t moved = 0;
+            if (j < end)
+                moved = mem::load(top + j);
+            wave_sync<global_ak>();
+            if (j < end)
+                mem::store(top + j + 1, moved);
+            wave_sync<global_ak>();
+        }
+    }
+    if (lane == 0)
+        mem::store(top + position, make_cand(d, slot));
+    size += full ? 0u : 1u;
+    wave_sync<global_ak>();
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+//  `visits`: exact set of slots — index.hpp:1085-1211. LDS: open addressing (CAS); global slab: one bit per slot.
+// ---------------------------------------------------------------------------------------------------------------------
+
+UA_DEVICE std::uint32_t hash_slot(std::uint32_t slot) {
+    const std::uint32_t h = slot * 2654435761u;
+    return h ^ (h >> 15);
+}
+
+/// Returns true for lanes whose `slot` was NOT in the set before (and now is). Inactive lanes return false.
+template <bool global_ak>
+UA_DEVICE bool visits_set(std::uint32_t* cells, std::uint32_t mask_or_words, std::uint32_t slot, bool active) {
+    bool fresh = false;
+    if constexpr (global_ak) {
+        if (active) {
+            const std::uint32_t bit = 1u << (slot & 31);
+            const std::uint32_t old = atomicOr(cells + (slot >> 5), bit);
+            fresh = (old & bit) == 0;
+        }
+    } else {
+        if (active) {
+            std::uint32_t h = hash_slot(slot) & mask_or_words;
+            for (;;) {
+                const std::uint32_t old = atomicCAS(cells + h, none_slot_k, slot);
+                if (old == none_slot_k) {
+                    fresh = true;
+                    break;
+                }
+                if (old == slot)
+                    break;
+                h = (h + 1) & mask_or_words;
+            }
+        }
+    }
+    return fresh;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+//  Distances — index_plugins.hpp:1309-1414 (ip, cos, l2sq, hamming) and 1583-1630 (cos_i8, l2sq_i8)
+// ---------------------------------------------------------------------------------------------------------------------
+
+UA_DEVICE float half_bits_to_float(std::uint32_t bits16) {
+    return (float)__builtin_bit_cast(_Float16, (std::uint16_t)bits16);
+}
+
+/// What one lane accumulates for one row; which members are live depends on (metric, scalar).
+struct partial_t {
+    float fx = 0.f, fy = 0.f; // float kinds: fx = Σab (ip, cos) or Σ(a-b)² (l2sq); fy = Σb² (cos)
+    int ix = 0, iy = 0;       // i8: ix = Σab, iy = Σb²;  b1: ix = Σpopcount(a^b)
+};
+
+template <int metric_ak> UA_DEVICE void accumulate_float(partial_t& p, float a, float b) {
+    if constexpr (metric_ak == metric_cos_k) {
+        p.fx = __builtin_fmaf(a, b, p.fx);
+        p.fy = __builtin_fmaf(b, b, p.fy);
+    } else if constexpr (metric_ak == metric_ip_k) {
+        p.fx = __builtin_fmaf(a, b, p.fx);
+    } else {
+        const float t = a - b;
+        p.fx = __builtin_fmaf(t, t, p.fx);
+    }
+}
+
+/// LDS bytes the query occupies per 16-byte row chunk: f16 queries are widened to f32 once, at load time.
+template <int scalar_ak> constexpr std::uint32_t query_chunk_bytes() { return scalar_ak == scalar_f16_k ? 32u : 16u; }
+
+/// Folds one 16-byte chunk `v` of a stored row against chunk `c` of the query (already in LDS).
+template <int metric_ak, int scalar_ak>
+UA_DEVICE void accumulate_chunk(partial_t& p, const std::uint8_t* query_lds, std::uint32_t c, uint4 v) {
+    const std::uint8_t* q = query_lds + (std::size_t)c * query_chunk_bytes<scalar_ak>();
+    if constexpr (scalar_ak == scalar_f32_k) {
+        const float4 a = *reinterpret_cast<const float4*>(q);
+        accumulate_float<metric_ak>(p, a.x, __builtin_bit_cast(float, v.x));
+        accumulate_float<metric_ak>(p, a.y, __builtin_bit_cast(float, v.y));
+        accumulate_float<metric_ak>(p, a.z, __builtin_bit_cast(float, v.z));
+        accumulate_float<metric_ak>(p, a.w, __builtin_bit_cast(float, v.w));
+    } else if constexpr (scalar_ak == scalar_f16_k) {
+        const float4 a0 = *reinterpret_cast<const float4*>(q);
+        const float4 a1 = *reinterpret_cast<const float4*>(q + 16);
+        accumulate_float<metric_ak>(p, a0.x, half_bits_to_float(v.x & 0xFFFFu));
+        accumulate_float<metric_ak>(p, a0.y, half_bits_to_float(v.x >> 16));
+        accumulate_float<metric_ak>(p, a0.z, half_bits_to_float(v.y & 0xFFFFu));
+        accumulate_float<metric_ak>(p, a0.w, half_bits_to_float(v.y >> 16));
+        accumulate_float<metric_ak>(p, a1.x, half_bits_to_float(v.z & 0xFFFFu));
+        accumulate_float<metric_ak>(p, a1.y, half_bits_to_float(v.z >> 16));
+        accumulate_float<metric_ak>(p, a1.z, half_bits_to_float(v.w & 0xFFFFu));
+        accumulate_float<metric_ak>(p, a1.w, half_bits_to_float(v.w >> 16));
+    } else if constexpr (scalar_ak == scalar_i8_k) {
+        const uint4 a = *reinterpret_cast<const uint4*>(q);
+        p.ix = __builtin_amdgcn_sdot4((int)a.x, (int)v.x, p.ix, false);
+        p.ix = __builtin_amdgcn_sdot4((int)a.y, (int)v.y, p.ix, false);
+        p.ix = __builtin_amdgcn_sdot4((int)a.z, (int)v.z, p.ix, false);
+        p.ix = __builtin_amdgcn_sdot4((int)a.w, (int)v.w, p.ix, false);
+        if constexpr (metric_ak != metric_ip_k) {
+            p.iy = __builtin_amdgcn_sdot4((int)v.x, (int)v.x, p.iy, false);
+            p.iy = __builtin_amdgcn_sdot4((int)v.y, (int)v.y, p.iy, false);
+            p.iy = __builtin_amdgcn_sdot4((int)v.z, (int)v.z, p.iy, false);
+            p.iy = __builtin_amdgcn_sdot4((int)v.w, (int)v.w, p.iy, false);
+        }
+    } else { // b1x8, hamming
+        const uint4 a = *reinterpret_cast<const uint4*>(q);
+        p.ix += __popc(a.x ^ v.x) + __popc(a.y ^ v.y) + __popc(a.z ^ v.z) + __popc(a.w ^ v.w);
+    }
+}
+
+/// XOR butterfly over the `lanes_ak` lanes that share a row (offsets lanes/2 … 1).
+template <int scalar_ak, int lanes_ak> UA_DEVICE void reduce_partial(partial_t& p) {
+#pragma unroll
+    for (int offset = lanes_ak / 2; offset >= 1; offset >>= 1) {
+        if constexpr (scalar_ak == scalar_f32_k || scalar_ak == scalar_f16_k) {
+            p.fx += __shfl_xor(p.fx, offset, 64);
+            p.fy += __shfl_xor(p.fy, offset, 64);
+        } else {
+            p.ix += __shfl_xor(p.ix, offset, 64);
+            p.iy += __shfl_xor(p.iy, offset, 64);
+        }
+    }
+}
+
+/// Query-side constants of a distance: Σa² in the same summation layout (float cos) or exact (i8).
+struct query_norm_t {
+    float f = 0.f;
+    int i = 0;
+};
+
+template <int metric_ak, int scalar_ak> UA_DEVICE float finalize_distance(partial_t p, query_norm_t a2) {
+    if constexpr (scalar_ak == scalar_f32_k || scalar_ak == scalar_f16_k) {
+        if constexpr (metric_ak == metric_cos_k) { // metric_cos_gt, index_plugins.hpp:1334-1359
+            if (a2.f == 0.f && p.fy == 0.f)
+                return 0.f;
+            if (a2.f == 0.f || p.fy == 0.f)
+                return 1.f;
+            return 1.f - p.fx / (__builtin_sqrtf(a2.f) * __builtin_sqrtf(p.fy));
+        } else if constexpr (metric_ak == metric_ip_k) { // metric_ip_gt 1309-1326
+            return 1.f - p.fx;
+        } else { // metric_l2sq_gt 1365-1385
+            return p.fx;
+        }
+    } else if constexpr (scalar_ak == scalar_i8_k) {
+        if constexpr (metric_ak == metric_cos_k) { // metric_cos_i8_t 1583-1607, incl. `ab == 0 → 0`
+            const float a2f = __builtin_sqrtf((float)a2.i), b2f = __builtin_sqrtf((float)p.iy);
+            return p.ix != 0 ? 1.f - (float)p.ix / (a2f * b2f) : 0.f;
+        } else if constexpr (metric_ak == metric_ip_k) { // metric_ip_gt<i8_t, f32_t>: exact while |Σ| < 2^24
+            return 1.f - (float)p.ix;
+        } else { // metric_l2sq_i8_t 1613-1630: Σ(a-b)² = Σa² + Σb² - 2Σab, exact in int32
+            return (float)(a2.i + p.iy - 2 * p.ix);
+        }
+    } else { // metric_hamming_gt<b1x8_t> 1392-1414
+        return (float)p.ix;
+    }
+}
+
+/**
+ *  Distances from the query (in LDS) to `count` rows whose slots sit in `slots[0..count)`; results to `out[0..count)`.
+ *  The wave is split into 64/G groups of G lanes, one row per group per round; each lane streams 16-byte chunks
+ *  `sub, sub+G, …` of its row with `unroll_ak` loads in flight before the first use.
+ */
+template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, bool global_ak>
+UA_DEVICE void measure_rows(const snapshot_view_t& ix, const std::uint8_t* query_lds, query_norm_t a2,
+                            const std::uint32_t* slots, float* out, std::uint32_t count) {
+    using mem = scratch_gt<global_ak>;
+    constexpr std::uint32_t rows_per_round = 64 / lanes_ak;
+    const std::uint32_t lane = lane_id();
+    const std::uint32_t group = lane / lanes_ak, sub = lane % lanes_ak;
+    const std::uint32_t chunks_per_lane = ix.chunks / lanes_ak; // row_stride is a multiple of 16*G
+    for (std::uint32_t base = 0; base < count; base += rows_per_round) {
+        const std::uint32_t ci = base + group;
+        if (ci < count) { // a group is active or idle as a whole, so the butterfly below stays inside active lanes
+            const std::uint32_t slot = mem::load(slots + ci);
+            const uint4* row = reinterpret_cast<const uint4*>(ix.vectors + (std::uint64_t)slot * ix.row_stride) + sub;
+            partial_t p;
+            std::uint32_t it = 0;
+            for (; it + unroll_ak <= chunks_per_lane; it += unroll_ak) {
+                uint4 v[unroll_ak];
+#pragma unroll
+                for (int u = 0; u < unroll_ak; ++u)
+                    v[u] = row[(std::size_t)(it + u) * lanes_ak];
+#pragma unroll
+                for (int u = 0; u < unroll_ak; ++u)
+                    accumulate_chunk<metric_ak, scalar_ak>(p, query_lds, sub + (it + u) * lanes_ak, v[u]);
+            }
+            if (it < chunks_per_lane) { // ragged tail: still issue every load before the first use
+                uint4 v[unroll_ak];
+#pragma unroll
+                for (int u = 0; u < unroll_ak; ++u)
+                    if (it + u < chunks_per_lane)
+                        v[u] = row[(std::size_t)(it + u) * lanes_ak];
+#pragma unroll
+                for (int u = 0; u < unroll_ak; ++u)
+                    if (it + u < chunks_per_lane)
+                        accumulate_chunk<metric_ak, scalar_ak>(p, query_lds, sub + (it + u) * lanes_ak, v[u]);
+            }
+            reduce_partial<scalar_ak, lanes_ak>(p);
+            if (sub == 0)
+                mem::store(out + ci, finalize_distance<metric_ak, scalar_ak>(p, a2));
+        }
+    }
+    wave_sync<global_ak>();
+}
+
+/// Copies query `q` into LDS (zero padded to the row stride; f16 widened to f32) and derives its norm.
+template <int metric_ak, int scalar_ak, int lanes_ak>
+UA_DEVICE query_norm_t stage_query(const snapshot_view_t& ix, const std::uint8_t* query, std::uint8_t* query_lds) {
+    const std::uint32_t lane = lane_id();
+    if constexpr (scalar_ak == scalar_f16_k) {
+        float* dst = reinterpret_cast<float*>(query_lds);
+        const std::uint32_t scalars = ix.chunks * 8;
+        for (std::uint32_t e = lane; e < scalars; e += 64) {
+            float value = 0.f;
+            if (e < ix.dimensions)
+                value = half_bits_to_float((std::uint32_t)query[2 * e] | ((std::uint32_t)query[2 * e + 1] << 8));
+            dst[e] = value;
+        }
+    } else {
+        const std::uint32_t bytes = ix.chunks * 16;
+        for (std::uint32_t b = lane; b < bytes; b += 64)
+            query_lds[b] = b < ix.bytes_per_vector ? query[b] : (std::uint8_t)0;
+    }
+    wave_sync<false>();
+
+    query_norm_t a2;
+    if constexpr ((scalar_ak == scalar_f32_k || scalar_ak == scalar_f16_k) && metric_ak == metric_cos_k) {
+        // Σa² with the row layout: lane `sub` owns chunks sub, sub+G, …; every group computes the same value
+        const std::uint32_t sub = lane % lanes_ak;
+        float sum = 0.f;
+        for (std::uint32_t c = sub; c < ix.chunks; c += lanes_ak) {
+            const float* a = reinterpret_cast<const float*>(query_lds + (std::size_t)c * query_chunk_bytes<scalar_ak>());
+            constexpr int per_chunk = scalar_ak == scalar_f16_k ? 8 : 4;
+#pragma unroll
+            for (int e = 0; e < per_chunk; ++e)
+                sum = __builtin_fmaf(a[e], a[e], sum);
+        }
+#pragma unroll
+        for (int offset = lanes_ak / 2; offset >= 1; offset >>= 1)
+            sum += __shfl_xor(sum, offset, 64);
+        a2.f = sum;
+    } else if constexpr (scalar_ak == scalar_i8_k && metric_ak != metric_ip_k) {
+        int sum = 0;
+        for (std::uint32_t c = lane; c < ix.chunks; c += 64) {
+            const uint4 a = *reinterpret_cast<const uint4*>(query_lds + (std::size_t)c * 16);
+            sum = __builtin_amdgcn_sdot4((int)a.x, (int)a.x, sum, false);
+            sum = __builtin_amdgcn_sdot4((int)a.y, (int)a.y, sum, false);
+            sum = __builtin_amdgcn_sdot4((int)a.z, (int)a.z, sum, false);
+            sum = __builtin_amdgcn_sdot4((int)a.w, (int)a.w, sum, false);
+        }
+#pragma unroll
+        for (int offset = 32; offset >= 1; offset >>= 1)
+            sum += __shfl_xor(sum, offset, 64);
+        a2.i = sum;
+    }
+    return a2;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+//  The search kernel
+// ---------------------------------------------------------------------------------------------------------------------
+
+/// Byte offsets of the per-wave scratch areas; the same arithmetic runs on the host to size LDS / the global slab.
+struct scratch_layout_t {
+    std::uint64_t top, next, visits, cand_slots, cand_distances, total;
+};
+
+inline __host__ __device__ std::uint64_t align16(std::uint64_t v) { return (v + 15u) & ~(std::uint64_t)15u; }
+
+/// LDS variant: query | top | next | hash | candidates. Global variant: LDS holds only the query and the candidates.
+inline __host__ __device__ scratch_layout_t scratch_layout(std::uint64_t ef, std::uint64_t next_cap,
+                                                           std::uint64_t visits_bytes) {
+    scratch_layout_t l;
+    l.top = 0;
+    l.next = l.top + align16(ef * 8);
+    l.visits = l.next + align16(next_cap * 8);
+    l.cand_slots = l.visits + align16(visits_bytes);
+    l.cand_distances = l.cand_slots + 256;
+    l.total = l.cand_distances + 256;
+    return l;
+}
+
+template <int scalar_ak> inline __host__ __device__ std::uint32_t query_lds_bytes(std::uint32_t chunks) {
+    return chunks * (scalar_ak == scalar_f16_k ? 32u : 16u); // a multiple of 16
+}
+
+template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, bool global_ak>
+__global__ __launch_bounds__(64) void search_kernel(const snapshot_view_t ix, const search_args_t args) {
+    extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
+    using mem = scratch_gt<global_ak>;
+    const std::uint32_t lane = lane_id();
+    const std::uint32_t q = args.todo ? args.todo[blockIdx.x] : blockIdx.x;
+    const std::uint32_t ef = args.ef, wanted = args.wanted;
+
+    // ---- carve the scratch
+    std::uint8_t* query_lds = lds;
+    const std::uint32_t query_bytes = query_lds_bytes<scalar_ak>(ix.chunks);
+    const std::uint64_t visits_bytes = global_ak ? ((ix.size + 31) / 32) * 4 : (std::uint64_t)args.hash_cap * 4;
+    const scratch_layout_t layout = scratch_layout(ef, args.next_cap, visits_bytes);
+    std::uint8_t* slab = global_ak ? args.scratch + (std::uint64_t)blockIdx.x * args.scratch_stride
+                                   : lds + query_bytes;
+    cand_t* top = reinterpret_cast<cand_t*>(slab + layout.top);
+    cand_t* next = reinterpret_cast<cand_t*>(slab + layout.next);
+    std::uint32_t* visits = reinterpret_cast<std::uint32_t*>(slab + layout.visits);
+    std::uint32_t* cand_slots = reinterpret_cast<std::uint32_t*>(slab + layout.cand_slots);
+    float* cand_distances = reinterpret_cast<float*>(slab + layout.cand_distances);
+    const std::uint32_t visits_mask = global_ak ? 0u : args.hash_cap - 1;
+    const std::uint32_t visits_limit = global_ak ? 0xFFFFFFFFu : args.hash_cap - args.hash_cap / 4; // 75 % load
+
+    const query_norm_t a2 = stage_query<metric_ak, scalar_ak, lanes_ak>(
+        ix, args.queries + (std::uint64_t)q * args.query_stride, query_lds);
+
+    if constexpr (!global_ak) { // the global bitmap is zeroed by the host before the launch
+        uint4* cells = reinterpret_cast<uint4*>(visits);
+        const uint4 empty = {none_slot_k, none_slot_k, none_slot_k, none_slot_k};
+        for (std::uint32_t i = lane; i < args.hash_cap / 4; i += 64)
+            cells[i] = empty;
+        wave_sync<global_ak>();
+    }
+
+    std::uint32_t computed = 0, cycles = 0; // context_t counters, index.hpp:2208-2211
+    auto measure = [&](std::uint32_t count) {
+        measure_rows<metric_ak, scalar_ak, lanes_ak, unroll_ak, global_ak>(ix, query_lds, a2, cand_slots,
+                                                                           cand_distances, count);
+        computed += count;
+    };
+    auto allowed = [&](std::uint32_t slot) -> bool { // index_dense.hpp:2071-2081 without a user predicate
+        return !ix.has_tombstones || ix.keys[slot] != free_key_k;
+    };
+
+    // ---- search_for_one_: greedy descent through levels max_level … 1 (index.hpp:3964-4003)
+    std::uint32_t closest = ix.entry_slot;
+    if (lane == 0)
+        mem::store(cand_slots, closest);
+    wave_sync<global_ak>();
+    measure(1);
+    float closest_distance = uniform_f32(mem::load(cand_distances));
+    for (std::uint32_t level = ix.max_level; level > 0; --level) {
+        bool changed;
+        do {
+            changed = false;
+            const std::uint32_t* list = ix.upper + (std::uint64_t)(ix.upper_ref[closest] + (level - 1)) * ix.m;
+            for (std::uint32_t tile = 0; tile < ix.m; tile += 64) {
+                const std::uint32_t cell = tile + lane;
+                const std::uint32_t neighbor = cell < ix.m ? list[cell] : none_slot_k;
+                const std::uint32_t count = popcount64(ballot(neighbor != none_slot_k)); // lists are prefix-compact
+                if (!count)
+                    break;
+                if (lane < count)
+                    mem::store(cand_slots + lane, neighbor);
+                wave_sync<global_ak>();
+                measure(count);
+                // strict `<` while scanning in list order ⇒ the FIRST occurrence of the minimum wins
+                const float mine = lane < count ? mem::load(cand_distances + lane) : __builtin_inff();
+                float best = mine;
+#pragma unroll
+                for (int offset = 32; offset >= 1; offset >>= 1)
+                    best = fminf(best, __shfl_xor(best, offset, 64));
+                if (best < closest_distance) {
+                    const std::uint32_t winner = (std::uint32_t)__ffsll((long long)ballot(lane < count && mine == best)) - 1;
+                    closest_distance = best;
+                    closest = read_lane_u32(neighbor, winner);
+                    changed = true;
+                }
+                wave_sync<global_ak>();
+            }
+            ++cycles;
+        } while (changed);
+    }
+
+    // ---- search_to_find_in_base_: best-first beam on level 0 (index.hpp:4176-4246)
+    std::uint32_t top_size = 0, next_size = 0, visits_count = 0;
+    bool overflow = false;
+    if (lane == 0)
+        mem::store(cand_slots, closest);
+    wave_sync<global_ak>();
+    measure(1);
+    float radius = uniform_f32(mem::load(cand_distances));
+    heap_push<global_ak>(next, next_size, -radius, closest);
+    visits_set<global_ak>(visits, visits_mask, closest, lane == 0);
+    visits_count = 1;
+    wave_sync<global_ak>();
+    if (allowed(closest))
+        sorted_insert<global_ak>(top, top_size, ef, radius, closest);
+
+    while (next_size) {
+        const cand_t candidate = mem::load(next);
+        const float candidate_distance = -uniform_f32(cand_distance(candidate));
+        if (candidate_distance > radius && top_size == ef) // index.hpp:4210, strict `>`
+            break;
+        heap_pop<global_ak>(next, next_size);
+        ++cycles;
+        const std::uint32_t expanded = uniform_u32(cand_slot(candidate));
+        const std::uint32_t* list = ix.nbr0 + (std::uint64_t)expanded * ix.m0;
+        for (std::uint32_t tile = 0; tile < ix.m0; tile += 64) {
+            const std::uint32_t cell = tile + lane;
+            const std::uint32_t neighbor = cell < ix.m0 ? list[cell] : none_slot_k;
+            const bool present = neighbor != none_slot_k;
+            const std::uint32_t present_count = popcount64(ballot(present));
+            if (!present_count)
+                break;
+            if (visits_count + present_count > visits_limit || next_size + present_count > args.next_cap) {
+                overflow = true;
+                break;
+            }
+            // visits.set(successor) for the whole tile at once; duplicates inside a list were removed on upload
+            const bool fresh = visits_set<global_ak>(visits, visits_mask, neighbor, present);
+            const std::uint64_t fresh_mask = ballot(fresh);
+            const std::uint32_t count = popcount64(fresh_mask);
+            visits_count += count;
+            if (!count)
+                continue;
+            if (fresh)
+                mem::store(cand_slots + rank_below(fresh_mask, lane), neighbor); // keeps list order
+            wave_sync<global_ak>();
+            measure(count);
+
+            // commit in list order with the reference's tests (index.hpp:4233-4240)
+            const float mine = lane < count ? mem::load(cand_distances + lane) : 0.f;
+            const std::uint32_t mine_slot = lane < count ? mem::load(cand_slots + lane) : 0u;
+            std::uint64_t pending = ballot(lane < count && (top_size < ef || mine < radius)); // radius only shrinks
+            while (pending) {
+                const std::uint32_t i = (std::uint32_t)__ffsll((long long)pending) - 1;
+                pending &= pending - 1;
+                const float d = read_lane_f32(mine, i);
+                if (!(top_size < ef || d < radius))
+                    continue;
+                const std::uint32_t successor = read_lane_u32(mine_slot, i);
+                heap_push<global_ak>(next, next_size, -d, successor);
+                if (allowed(successor)) {
+                    sorted_insert<global_ak>(top, top_size, ef, d, successor);
+                    radius = uniform_f32(cand_distance(mem::load(top + (top_size - 1)))); // top.top() = worst kept
+                }
+            }
+            wave_sync<global_ak>();
+        }
+        if (overflow)
+            break;
+    }
+
+    // ---- results: shrink to `wanted`, dump_to with padding (index.hpp:3067-3073, 2707-2722)
+    if (overflow) {
+        if (lane == 0)
+            args.status[q] = status_overflow_k;
+        return;
+    }
+    const std::uint32_t found = top_size < wanted ? top_size : wanted;
+    for (std::uint32_t i = lane; i < wanted; i += 64) {
+        std::uint64_t key = 0;
+        std::uint32_t distance_bits = signaling_nan_bits_k;
+        if (i < found) {
+            const cand_t c = mem::load(top + i);
+            key = ix.keys[cand_slot(c)];
+            distance_bits = (std::uint32_t)c;
+        }
+        args.keys[(std::uint64_t)q * wanted + i] = key;
+        reinterpret_cast<std::uint32_t*>(args.distances)[(std::uint64_t)q * wanted + i] = distance_bits;
+    }
+    if (lane == 0) {
+        args.counts[q] = found;
+        args.visited[q] = cycles;
+        args.computed[q] = computed;
+        args.status[q] = status_done_k;
+    }
+}
+
+/**
+ *  Plain distance evaluation, one wave per query row: out[q][j] = metric(query q, row slots[q][j]). Serves `usearch_distance`-
+ *  style checks of the arithmetic alone and is the building block of exact search.
+ */
+template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak>
+__global__ __launch_bounds__(64) void distances_kernel(const snapshot_view_t ix, const std::uint8_t* queries,
+                                                       std::uint64_t query_stride, const std::uint32_t* slots,
+                                                       std::uint32_t slots_per_query, float* out) {
+    extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
+    const std::uint32_t lane = lane_id();
+    const std::uint32_t q = blockIdx.x;
+    std::uint8_t* query_lds = lds;
+    std::uint32_t* cand_slots = reinterpret_cast<std::uint32_t*>(lds + query_lds_bytes<scalar_ak>(ix.chunks));
+    float* cand_distances = reinterpret_cast<float*>(cand_slots + 64);
+    const query_norm_t a2 = stage_query<metric_ak, scalar_ak, lanes_ak>(ix, queries + (std::uint64_t)q * query_stride, query_lds);
+    for (std::uint32_t base = 0; base < slots_per_query; base += 64) {
+        const std::uint32_t count = slots_per_query - base < 64 ? slots_per_query - base : 64;
+        if (lane < count)
+            cand_slots[lane] = slots[(std::uint64_t)q * slots_per_query + base + lane];
+        wave_sync<false>();
+        measure_rows<metric_ak, scalar_ak, lanes_ak, unroll_ak, false>(ix, query_lds, a2, cand_slots, cand_distances, count);
+        if (lane < count)
+            out[(std::uint64_t)q * slots_per_query + base + lane] = cand_distances[lane];
+        wave_sync<false>();
+    }
+}
+
+} // namespace usearch_amd

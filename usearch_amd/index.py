@@ -1,0 +1,345 @@
+"""Python host side of the MI355X search engine: a thin ctypes binding over the C ABI of `include/usearch_amd.h`.
+
+It mirrors the *search* surface of the reference's Python package (`/root/reference/python/usearch/index.py`):
+`Index.restore(path_or_buffer)` (index.py:574-630) gives an object whose `search(vectors, count, ...)` has the argument
+meaning of `Index.search` (index.py:700-748) and returns `Matches` / `BatchMatches` shaped like index.py:291-385 —
+row-major `keys[Q, k]` (u64), `distances[Q, k]` (f32), `counts[Q]`, plus the two traversal counters. Everything else of
+that package (add / remove / cluster / join …) stays with the reference: this engine consumes the index files it writes.
+
+There is no CPU fallback: without `libusearch_amd.so` or without a HIP device, constructing an `Index` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional, Union
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_PATH = os.path.join(HERE, "lib", "libusearch_amd.so")
+
+# `usearch_scalar_kind_t` / `usearch_metric_kind_t` of c/usearch.h:40-62
+SCALAR_KINDS = {"f32": 1, "f64": 2, "f16": 3, "i8": 4, "b1": 5, "bf16": 6}
+SCALAR_NAMES = {v: k for k, v in SCALAR_KINDS.items()}
+METRIC_NAMES = {1: "cos", 2: "ip", 3: "l2sq", 4: "haversine", 5: "divergence", 6: "pearson", 7: "jaccard",
+                8: "hamming", 9: "tanimoto", 10: "sorensen"}
+NUMPY_DTYPES = {"f32": np.float32, "f64": np.float64, "f16": np.float16, "i8": np.int8, "b1": np.uint8}
+
+
+class Tuning(C.Structure):
+    """`usearch_amd_tuning_t`."""
+    _fields_ = [("hash_cap", C.c_uint32), ("next_cap", C.c_uint32), ("unroll", C.c_uint32),
+                ("force_global_scratch", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    """`usearch_amd_stats_t`."""
+    _fields_ = [("passes", C.c_uint32), ("retried_lds", C.c_uint32), ("retried_global", C.c_uint32),
+                ("kernel_ms", C.c_float)]
+
+
+_library = None
+
+EXPORTED_SYMBOLS = [
+    "usearch_amd_device_count", "usearch_amd_snapshot_from_buffer", "usearch_amd_snapshot_from_file",
+    "usearch_amd_snapshot_free", "usearch_amd_snapshot_size", "usearch_amd_snapshot_dimensions",
+    "usearch_amd_snapshot_connectivity", "usearch_amd_snapshot_max_level", "usearch_amd_snapshot_bytes_per_vector",
+    "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_scalar_kind",
+    "usearch_amd_snapshot_metric_kind", "usearch_amd_snapshot_lanes_per_row", "usearch_amd_search_many",
+    "usearch_amd_search_many_device", "usearch_amd_distances", "usearch_amd_test_containers", "usearch_amd_cast",
+]
+
+
+def library() -> C.CDLL:
+    """Loads `usearch_amd/lib/libusearch_amd.so` (built by `make -C usearch_amd/csrc` / `__graft_entry__.build()`)."""
+    global _library
+    if _library is not None:
+        return _library
+    if not os.path.exists(LIBRARY_PATH):
+        raise RuntimeError(f"{LIBRARY_PATH} is missing: build it with `make -C usearch_amd/csrc` "
+                           "(hipcc, gfx950). The engine has no CPU fallback.")
+    L = C.CDLL(LIBRARY_PATH, mode=os.RTLD_LOCAL)
+    err_p = C.POINTER(C.c_char_p)
+    L.usearch_amd_device_count.restype = C.c_int
+    L.usearch_amd_device_count.argtypes = [err_p]
+    L.usearch_amd_snapshot_from_buffer.restype = C.c_void_p
+    L.usearch_amd_snapshot_from_buffer.argtypes = [C.c_void_p, C.c_size_t, C.c_int, err_p]
+    L.usearch_amd_snapshot_from_file.restype = C.c_void_p
+    L.usearch_amd_snapshot_from_file.argtypes = [C.c_char_p, C.c_int, err_p]
+    L.usearch_amd_snapshot_free.argtypes = [C.c_void_p, err_p]
+    for name in ("size", "dimensions", "connectivity", "max_level", "bytes_per_vector", "row_stride", "device_bytes",
+                 "lanes_per_row"):
+        f = getattr(L, f"usearch_amd_snapshot_{name}")
+        f.restype = C.c_size_t
+        f.argtypes = [C.c_void_p]
+    for name in ("scalar_kind", "metric_kind"):
+        f = getattr(L, f"usearch_amd_snapshot_{name}")
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p]
+    L.usearch_amd_search_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
+                                          C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(Tuning), C.POINTER(Stats), err_p]
+    L.usearch_amd_search_many_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                                 C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.POINTER(Tuning), C.c_int,
+                                                 C.POINTER(Stats), err_p]
+    L.usearch_amd_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, err_p]
+    L.usearch_amd_test_containers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                              C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), err_p]
+    L.usearch_amd_cast.restype = C.c_int
+    L.usearch_amd_cast.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    _library = L
+    return L
+
+
+def _raise(err: C.c_char_p, what: str) -> None:
+    if err.value:
+        raise RuntimeError(f"{what}: {err.value.decode()}")
+
+
+def _pointer(array: Optional[np.ndarray]):
+    return C.c_void_p(array.ctypes.data) if array is not None else None
+
+
+@dataclass
+class Matches:
+    """Results of one query — `usearch.index.Matches` (index.py:303-331)."""
+    keys: np.ndarray
+    distances: np.ndarray
+    visited_members: int = 0
+    computed_distances: int = 0
+
+    def __len__(self) -> int:
+        return len(self.keys)
+
+    def to_list(self):
+        return [(int(k), float(d)) for k, d in zip(self.keys, self.distances)]
+
+
+@dataclass
+class BatchMatches:
+    """Results of a batch — `usearch.index.BatchMatches` (index.py:334-385); counters kept per query as well."""
+    keys: np.ndarray
+    distances: np.ndarray
+    counts: np.ndarray
+    visited_members: int = 0
+    computed_distances: int = 0
+    visited_per_query: Optional[np.ndarray] = None
+    computed_per_query: Optional[np.ndarray] = None
+    stats: Optional[Stats] = None
+
+    def __len__(self) -> int:
+        return len(self.counts)
+
+    def __getitem__(self, index: int) -> Matches:
+        if isinstance(index, int) and index < len(self):
+            n = int(self.counts[index])
+            return Matches(self.keys[index, :n], self.distances[index, :n],
+                           int(self.visited_per_query[index]), int(self.computed_per_query[index]))
+        raise IndexError(f"`index` must be an integer under {len(self)}")
+
+    def count_matches(self, expected: np.ndarray, count: Optional[int] = None) -> int:
+        assert len(expected) == len(self)
+        count = self.keys.shape[1] if count is None else count
+        if count == 1:
+            return int(np.sum(self.keys[:, 0] == expected))
+        return int(sum(expected[i] in self.keys[i, :count] for i in range(len(self))))
+
+    def mean_recall(self, expected: np.ndarray, count: Optional[int] = None) -> float:
+        return self.count_matches(expected, count=count) / len(expected)
+
+
+class Index:
+    """An immutable HBM-resident snapshot of a serialized USearch index, searchable in batches on one MI355X."""
+
+    def __init__(self, handle: int, expansion_search: int = 0):
+        self._handle = handle
+        self.expansion_search = expansion_search  # 0 = the reference's default of 64 (index.hpp:3029-3030)
+
+    @classmethod
+    def restore(cls, source: Union[str, os.PathLike, bytes, bytearray, memoryview, np.ndarray], device: int = 0,
+                expansion_search: int = 0) -> "Index":
+        """Uploads a `.usearch` file or an in-memory image (`usearch_save` / `usearch_save_buffer` output)."""
+        L = library()
+        err = C.c_char_p()
+        if isinstance(source, (str, os.PathLike)):
+            handle = L.usearch_amd_snapshot_from_file(os.fspath(source).encode(), device, C.byref(err))
+        else:
+            image = np.ascontiguousarray(np.frombuffer(source, dtype=np.uint8)
+                                         if not isinstance(source, np.ndarray) else source, dtype=np.uint8)
+            handle = L.usearch_amd_snapshot_from_buffer(_pointer(image), image.size, device, C.byref(err))
+        _raise(err, "usearch_amd snapshot")
+        if not handle:
+            raise RuntimeError("usearch_amd snapshot: failed without a message")
+        return cls(handle, expansion_search)
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            err = C.c_char_p()
+            library().usearch_amd_snapshot_free(self._handle, C.byref(err))
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- introspection (names of usearch.index.Index properties, index.py:1180-1300)
+    def __len__(self) -> int:
+        return library().usearch_amd_snapshot_size(self._handle)
+
+    @property
+    def size(self) -> int:
+        return len(self)
+
+    @property
+    def ndim(self) -> int:
+        return library().usearch_amd_snapshot_dimensions(self._handle)
+
+    @property
+    def connectivity(self) -> int:
+        return library().usearch_amd_snapshot_connectivity(self._handle)
+
+    @property
+    def max_level(self) -> int:
+        return library().usearch_amd_snapshot_max_level(self._handle)
+
+    @property
+    def dtype(self) -> str:
+        return SCALAR_NAMES[library().usearch_amd_snapshot_scalar_kind(self._handle)]
+
+    @property
+    def metric_kind(self) -> str:
+        return METRIC_NAMES[library().usearch_amd_snapshot_metric_kind(self._handle)]
+
+    @property
+    def bytes_per_vector(self) -> int:
+        return library().usearch_amd_snapshot_bytes_per_vector(self._handle)
+
+    @property
+    def row_stride(self) -> int:
+        return library().usearch_amd_snapshot_row_stride(self._handle)
+
+    @property
+    def memory_usage(self) -> int:
+        return library().usearch_amd_snapshot_device_bytes(self._handle)
+
+    @property
+    def lanes_per_row(self) -> int:
+        return library().usearch_amd_snapshot_lanes_per_row(self._handle)
+
+    @property
+    def hardware_acceleration(self) -> str:
+        return "gfx950"
+
+    # ---- search
+    def search(self, vectors: np.ndarray, count: int = 10, *, expansion: Optional[int] = None,
+               dtype: Optional[str] = None, tuning: Optional[Tuning] = None) -> Union[Matches, BatchMatches]:
+        """`Index.search` (index.py:700-748): one vector → `Matches`, a 2-D batch → `BatchMatches`.
+
+        `dtype` names the scalar kind of `vectors` when numpy cannot tell (bit-packed `b1` rows are `uint8`);
+        by default it is derived from the array's dtype, `uint8` meaning bits."""
+        vectors = np.asarray(vectors)
+        single = vectors.ndim == 1
+        if single:
+            vectors = vectors[None, :]
+        if vectors.ndim != 2:
+            raise ValueError("Expects a matrix or a vector")
+        if dtype is None:
+            dtype = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64", np.dtype(np.float16): "f16",
+                     np.dtype(np.int8): "i8", np.dtype(np.uint8): "b1"}.get(vectors.dtype)
+            if dtype is None:
+                raise ValueError(f"Unsupported dtype {vectors.dtype}")
+        expected_columns = (self.ndim + 7) // 8 if dtype == "b1" else self.ndim
+        if vectors.shape[1] != expected_columns:
+            raise ValueError(f"The number of columns {vectors.shape[1]} must match the index ({expected_columns})")
+        if vectors.strides[1] != vectors.itemsize:  # rows may be strided (python/lib.cpp:415-461), scalars may not
+            vectors = np.ascontiguousarray(vectors)
+        q = vectors.shape[0]
+        keys = np.zeros((q, count), dtype=np.uint64)
+        distances = np.zeros((q, count), dtype=np.float32)
+        counts = np.zeros(q, dtype=np.uint64)
+        visited = np.zeros(q, dtype=np.uint64)
+        computed = np.zeros(q, dtype=np.uint64)
+        stats = Stats()
+        err = C.c_char_p()
+        ef = self.expansion_search if expansion is None else expansion
+        library().usearch_amd_search_many(self._handle, _pointer(vectors), SCALAR_KINDS[dtype], q,
+                                          vectors.shape[1] * vectors.itemsize if q <= 1 else vectors.strides[0],
+                                          count, ef, _pointer(keys),
+                                          _pointer(distances), _pointer(counts), _pointer(visited),
+                                          _pointer(computed), C.byref(tuning) if tuning is not None else None,
+                                          C.byref(stats), C.byref(err))
+        _raise(err, "usearch_amd_search_many")
+        batch = BatchMatches(keys, distances, counts, int(visited.sum()), int(computed.sum()), visited, computed,
+                             stats)
+        return batch[0] if single else batch
+
+    def search_device(self, queries_ptr: int, queries_count: int, queries_stride: int, count: int, expansion: int,
+                      keys_ptr: int, distances_ptr: int, counts_ptr: int, visited_ptr: int, computed_ptr: int,
+                      stream: int = 0, timed: bool = False, tuning: Optional[Tuning] = None) -> Stats:
+        """HBM-resident batch: raw device addresses in and out (e.g. `torch.Tensor.data_ptr()`), storage scalar kind."""
+        stats = Stats()
+        err = C.c_char_p()
+        library().usearch_amd_search_many_device(self._handle, C.c_void_p(queries_ptr), queries_count, queries_stride,
+                                                 count, expansion, C.c_void_p(keys_ptr), C.c_void_p(distances_ptr),
+                                                 C.c_void_p(counts_ptr), C.c_void_p(visited_ptr),
+                                                 C.c_void_p(computed_ptr), C.c_void_p(stream),
+                                                 C.byref(tuning) if tuning is not None else None, int(timed),
+                                                 C.byref(stats), C.byref(err))
+        _raise(err, "usearch_amd_search_many_device")
+        return stats
+
+    def distances(self, queries: np.ndarray, slots: np.ndarray) -> np.ndarray:
+        """out[q, j] = metric(queries[q], stored vector of slot slots[q, j]); queries in the storage kind."""
+        queries = np.ascontiguousarray(queries)
+        slots = np.ascontiguousarray(slots, dtype=np.uint32)
+        assert queries.ndim == 2 and slots.ndim == 2 and len(queries) == len(slots)
+        out = np.zeros(slots.shape, dtype=np.float32)
+        err = C.c_char_p()
+        library().usearch_amd_distances(self._handle, _pointer(queries), len(queries), queries.strides[0],
+                                        _pointer(slots), slots.shape[1], _pointer(out), C.byref(err))
+        _raise(err, "usearch_amd_distances")
+        return out
+
+
+def device_count() -> int:
+    err = C.c_char_p()
+    n = library().usearch_amd_device_count(C.byref(err))
+    return n
+
+
+def cast(vector: np.ndarray, from_dtype: str, to_dtype: str, ndim: int) -> Optional[np.ndarray]:
+    """Host-side query cast (`usearch_amd_cast`); None when the kinds are equal."""
+    vector = np.ascontiguousarray(vector)
+    nbytes = {"b1": (ndim + 7) // 8, "i8": ndim, "f16": 2 * ndim, "bf16": 2 * ndim, "f32": 4 * ndim,
+              "f64": 8 * ndim}[to_dtype]
+    out = np.zeros(nbytes, dtype=np.uint8)
+    done = library().usearch_amd_cast(SCALAR_KINDS[from_dtype], SCALAR_KINDS[to_dtype], _pointer(vector), ndim,
+                                      _pointer(out))
+    return out if done else None
+
+
+def test_containers(kinds: np.ndarray, keys: np.ndarray, slots: np.ndarray, limit: int):
+    """Device container self-test hook → (popped[(key, slot)], top[(distance, slot)])."""
+    kinds = np.ascontiguousarray(kinds, dtype=np.uint32)
+    keys = np.ascontiguousarray(keys, dtype=np.float32)
+    slots = np.ascontiguousarray(slots, dtype=np.uint32)
+    n = len(kinds)
+    popped = np.zeros(n + 1, dtype=np.uint64)
+    top = np.zeros(limit + 1, dtype=np.uint64)
+    popped_count, top_count = C.c_size_t(), C.c_size_t()
+    err = C.c_char_p()
+    library().usearch_amd_test_containers(_pointer(kinds), _pointer(keys), _pointer(slots), n, limit, _pointer(popped),
+                                          C.byref(popped_count), _pointer(top), C.byref(top_count), C.byref(err))
+    _raise(err, "usearch_amd_test_containers")
+
+    def unpack(a):
+        bits = (a & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        return bits.view(np.float32), (a >> np.uint64(32)).astype(np.uint32)
+
+    return unpack(popped[: popped_count.value]), unpack(top[: top_count.value])
