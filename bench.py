@@ -80,6 +80,9 @@ def main() -> None:
     parser.add_argument("--cpu-seconds", type=float, default=12.0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--sharded", action="store_true")
+    parser.add_argument("--build-threads", type=int, default=int(os.environ.get("BENCH_BUILD_THREADS", 0)))
+    parser.add_argument("--cache-dir", default=os.environ.get("BENCH_CACHE_DIR", ""),
+                        help="keep the reference-built index image here between runs (e.g. /dev/shm)")
     args = parser.parse_args()
     metric = args.metric or ("hamming" if args.dtype == "b1" else "l2sq" if args.dtype == "i8" else "cos")
 
@@ -98,6 +101,10 @@ def main() -> None:
     import usearch_amd
     from oracle import refbind  # the reference builds the index and is the cpu_baseline; never on the timed GPU path
 
+    cache_path = None
+    if args.cache_dir:
+        cache_path = os.path.join(args.cache_dir, f"usearch_amd_{args.n}x{args.dim}{args.dtype}_{metric}_m{args.connectivity}"
+                                                  f"_efa{args.expansion_add}.usearch")
     # ---- the index: built once by the reference on the host cores (rank 0), shared with the other ranks through /dev/shm
     image_path = f"/dev/shm/usearch_amd_bench_{os.environ.get('MASTER_PORT', '0')}_{args.n}x{args.dim}{args.dtype}.usearch"
     build_seconds = 0.0
@@ -114,15 +121,22 @@ def main() -> None:
         build_seconds = time.time() - t0
         image = ref_index.save_buffer()
     else:
-        if rank == 0:
+        if rank == 0 and cache_path and os.path.exists(cache_path):
+            image = np.fromfile(cache_path, dtype=np.uint8)
+            ref_index = refbind.RefIndex.from_buffer(image, view=False, dtype=args.dtype)
+            log(f"[bench] reusing the reference-built index {cache_path}")
+        elif rank == 0:
             vectors = synthetic_vectors(args.n, args.dim, args.dtype, seed=42)
             ref_index = refbind.RefIndex(args.dim, metric, args.dtype, args.connectivity, args.expansion_add, 64)
             t0 = time.time()
-            ref_index.add(np.arange(args.n, dtype=np.uint64), vectors, threads=0)
+            ref_index.add(np.arange(args.n, dtype=np.uint64), vectors, threads=args.build_threads)
             build_seconds = time.time() - t0
             log(f"[bench] reference built {args.n}x{args.dim} {args.dtype} in {build_seconds:.1f}s "
-                f"on {refbind.max_threads()} threads")
+                f"on {args.build_threads or refbind.max_threads()} threads")
             image = ref_index.save_buffer()
+            if cache_path:
+                image.tofile(cache_path)
+        if rank == 0:
             if world > 1:
                 image.tofile(image_path)
         if world > 1:
@@ -244,7 +258,9 @@ def main() -> None:
                                    f"M={args.connectivity}, ef_construction={args.expansion_add}, ef={expansion}",
                        "vectors": args.n, "dimensions": args.dim, "expansion_search": expansion,
                        "recall_at_k": recall, "parallelism": ("shards" if args.sharded else "replicas") + str(world),
-                       "index_build_seconds": round(build_seconds, 1), "kernel_passes": passes},
+                       "index_build_seconds": round(build_seconds, 1), "kernel_passes": passes,
+                       "scratch_mode": {1: "lds", 2: "global-hash", 3: "global"}.get(stats.mode, "?"),
+                       "persistent_waves": stats.grid, "lds_bytes_per_wave": stats.lds_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": "search_kernel", "kernel_ms": kernel_s * 1e3,

@@ -46,10 +46,12 @@ enum {
 
 /** Optional knobs of one batched search; zero-initialise for the defaults. */
 typedef struct usearch_amd_tuning_t {
-    uint32_t hash_cap;             /**< visited-set cells per query in LDS (power of two); 0 = from expansion */
-    uint32_t next_cap;             /**< frontier capacity per query in LDS; 0 = from expansion */
-    uint32_t unroll;               /**< 16-byte loads in flight per lane within one row: 4 or 8; 0 = auto */
-    uint32_t force_global_scratch; /**< run every query with the global-memory scratch (exact sizes, slow) */
+    uint32_t hash_cap;     /**< visited-set cells per query (power of two); 0 = 48 × expansion */
+    uint32_t next_cap;     /**< frontier capacity per query; 0 = 4 × expansion */
+    uint32_t unroll;       /**< 16-byte loads in flight per lane within one row: 4 or 8; 0 = auto */
+    uint32_t mode;         /**< scratch placement: 0 = auto, 1 = visited set in LDS, 2 = visited set in a per-wave global
+                                hash (heaps stay in LDS), 3 = everything in global memory with exact sizes (slow) */
+    uint32_t waves_per_cu; /**< persistent waves per compute unit; 0 = as many as LDS and registers admit (≤ 16) */
 } usearch_amd_tuning_t;
 
 /** What a batched search did, for profiling and tests. */
@@ -58,6 +60,9 @@ typedef struct usearch_amd_stats_t {
     uint32_t retried_lds;    /**< queries rerun with enlarged LDS scratch */
     uint32_t retried_global; /**< queries rerun with global-memory scratch */
     float kernel_ms;         /**< HIP-event duration of the search launches (device entry point with timing only) */
+    uint32_t mode;           /**< scratch placement of the last launch (values of usearch_amd_tuning_t::mode) */
+    uint32_t grid;           /**< persistent waves of the last launch */
+    uint32_t lds_bytes;      /**< LDS bytes per wave of the last launch */
 } usearch_amd_stats_t;
 
 /** Number of visible HIP devices; 0 (and an error) when the runtime finds none. */
@@ -123,6 +128,13 @@ USEARCH_AMD_EXPORT void usearch_amd_search_many_device(usearch_amd_snapshot_t sn
                                                        uint64_t* visited, uint64_t* computed, void* stream,
                                                        usearch_amd_tuning_t const* tuning, int timed,
                                                        usearch_amd_stats_t* stats, usearch_amd_error_t* error);
+
+/**
+ *  Telemetry of the most recent search on this snapshot: out[q] = {peak frontier size, visited-set size} for the first
+ *  `queries_count` queries — what DESIGN.md's scratch sizing is derived from.
+ */
+USEARCH_AMD_EXPORT void usearch_amd_last_peaks(usearch_amd_snapshot_t snapshot, uint32_t* out, size_t queries_count,
+                                               usearch_amd_error_t* error);
 
 /**
  *  out[q][j] = metric(query q, stored vector of slot slots[q][j]) — `usearch_distance` (c/usearch.h:441-445) against

@@ -415,10 +415,17 @@ static int heap_reserve(heap_t* h, size_t n) {
     return 1;
 }
 
+/* Sizing statistics of the last uo_search call on this thread (how big `next` and `visits` got): used by the
+ * tests / DESIGN.md to size the device scratch, not part of the restated algorithm. */
+static __thread size_t stat_peak_next = 0, stat_visits = 0;
+size_t uo_last_peak_next(void) { return stat_peak_next; }
+size_t uo_last_visits(void) { return stat_visits; }
+
 static void heap_insert(heap_t* h, cand_t c) {
     /* insert_reserved + shift_up (index.hpp:765-770, 808-811): swap while parent < child, strictly */
     heap_reserve(h, h->size + 1);
     size_t i = h->size++;
+    if (h->size > stat_peak_next) stat_peak_next = h->size;
     h->e[i] = c;
     while (i && h->e[(i - 1) / 2].distance < h->e[i].distance) {
         cand_t t = h->e[(i - 1) / 2];
@@ -575,6 +582,7 @@ static size_t search_with_ctx(ctx_t* c, const void* query, uint8_t query_kind, s
     const uo_index_t* ix = c->ix;
     size_t count = 0;
     c->computed_distances = c->iteration_cycles = 0;
+    stat_peak_next = 0;
     /* index_dense.hpp:2058-2064: cast the query into the storage kind first */
     size_t bpv = uo_bytes_per_vector(ix->scalar_kind, ix->dimensions);
     uint8_t* casted = (uint8_t*)calloc(bpv + 16, 1);
@@ -606,6 +614,7 @@ static size_t search_with_ctx(ctx_t* c, const void* query, uint8_t query_kind, s
     }
     if (visited) *visited = c->iteration_cycles;
     if (computed) *computed = c->computed_distances;
+    stat_visits = c->visits.touched_count;
     free(casted);
     return count;
 }

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""scripts/sweep.py — tuning sweep of the search kernel on one GPU: builds (or reuses) one reference-built index and times
+the batched search under different scratch placements / persistent-wave counts / unroll depths.
+
+    python scripts/sweep.py --n 500000 --dim 768 --dtype f16 --cache-dir /dev/shm --ef 64 256 \
+        --modes 1 2 --waves 4 8 16 --unrolls 4 8
+
+Development tool (not part of the product or of the test-suite); prints one line per variant to stdout.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--n", type=int, default=500_000)
+    p.add_argument("--dim", type=int, default=768)
+    p.add_argument("--dtype", default="f16")
+    p.add_argument("--queries", type=int, default=10_000)
+    p.add_argument("--k", type=int, default=10)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--ef", type=int, nargs="+", default=[64, 256])
+    p.add_argument("--modes", type=int, nargs="+", default=[1, 2])
+    p.add_argument("--waves", type=int, nargs="+", default=[0])
+    p.add_argument("--unrolls", type=int, nargs="+", default=[0])
+    p.add_argument("--cache-dir", default="/dev/shm")
+    p.add_argument("--build-threads", type=int, default=0)
+    args = p.parse_args()
+    metric = "hamming" if args.dtype == "b1" else "l2sq" if args.dtype == "i8" else "cos"
+
+    import torch
+    import usearch_amd
+    from oracle import refbind
+
+    path = os.path.join(args.cache_dir, f"usearch_amd_{args.n}x{args.dim}{args.dtype}_{metric}_m16_efa128.usearch")
+    if os.path.exists(path):
+        image = np.fromfile(path, dtype=np.uint8)
+    else:
+        vectors = bench.synthetic_vectors(args.n, args.dim, args.dtype, seed=42)
+        ref = refbind.RefIndex(args.dim, metric, args.dtype, 16, 128, 64)
+        t0 = time.time()
+        ref.add(np.arange(args.n, dtype=np.uint64), vectors, threads=args.build_threads)
+        print(f"built {args.n} in {time.time() - t0:.1f}s ({args.build_threads or refbind.max_threads()} threads)", flush=True)
+        image = ref.save_buffer()
+        image.tofile(path)
+        del ref, vectors
+    index = usearch_amd.Index.restore(image)
+    del image
+    device = torch.device("cuda", 0)
+    queries_host = bench.synthetic_vectors(args.queries, args.dim, args.dtype, seed=43)
+    queries = torch.from_numpy(queries_host.view(np.uint8).reshape(args.queries, -1)).to(device)
+    keys = torch.zeros((args.queries, args.k), dtype=torch.int64, device=device)
+    dists = torch.zeros((args.queries, args.k), dtype=torch.float32, device=device)
+    counts = torch.zeros(args.queries, dtype=torch.int64, device=device)
+    visited = torch.zeros(args.queries, dtype=torch.int64, device=device)
+    computed = torch.zeros(args.queries, dtype=torch.int64, device=device)
+    bpv, m0 = index.bytes_per_vector, 2 * index.connectivity
+    reference_keys = {}
+    for ef in args.ef:
+        for mode in args.modes:
+            for waves in args.waves:
+                for unroll in args.unrolls:
+                    tuning = usearch_amd.Tuning(mode=mode, waves_per_cu=waves, unroll=unroll)
+                    ms = []
+                    for step in range(args.steps + 1):
+                        stats = index.search_device(queries.data_ptr(), args.queries, queries.stride(0), args.k, ef,
+                                                    keys.data_ptr(), dists.data_ptr(), counts.data_ptr(),
+                                                    visited.data_ptr(), computed.data_ptr(), timed=True, tuning=tuning)
+                        if step:
+                            ms.append(stats.kernel_ms)
+                    c = computed.cpu().numpy().astype(np.float64)
+                    v = visited.cpu().numpy().astype(np.float64)
+                    step_bytes = float(np.sum(c * bpv + v * 4 * m0 + args.k * 8 + bpv))
+                    best = min(ms)
+                    k_host = keys.cpu().numpy()
+                    same = reference_keys.setdefault(ef, k_host)
+                    peaks = index.last_peaks(args.queries)
+                    print(f"ef={ef:4d} mode={stats.mode} waves/cu={waves:2d} grid={stats.grid:5d} lds={stats.lds_bytes:6d} "
+                          f"unroll={unroll} passes={stats.passes} ms={best:8.3f} (mean {np.mean(ms):8.3f}) "
+                          f"qps={args.queries / best * 1e3:10.0f} GB/s={step_bytes / best / 1e6:8.1f} "
+                          f"dist/q={c.mean():.0f} hops/q={v.mean():.0f} peak_next={peaks[:, 0].max()} "
+                          f"visits_max={peaks[:, 1].max()} identical={np.array_equal(same, k_host)}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -130,18 +130,40 @@ def test_tombstones_are_skipped(reference):
 
 
 def test_scratch_overflow_retries_give_identical_results(reference):
-    """Tiny LDS scratch forces the retry ladder (bigger LDS, then global memory); results must not change."""
+    """Tiny scratch forces the retry ladder (bigger scratch with a global visited hash, then all-global memory); every
+    scratch placement must give the very same results."""
     from usearch_amd import Index, Tuning
     for metric, dtype, ndim in (("cos", "f32", 64), ("hamming", "b1", 64)):
         image, _, _ = util.build_image(3000, ndim, metric, dtype, seed=41)
         index = Index.restore(image)
         queries = util.make_vectors(64, ndim, dtype, seed=42)
         base = check_against_oracle(index, image, queries, 10, dtype, 64)
-        small = check_against_oracle(index, image, queries, 10, dtype, 64, tuning=Tuning(256, 96, 0, 0))
+        in_lds = check_against_oracle(index, image, queries, 10, dtype, 64, tuning=Tuning(mode=1))
+        assert in_lds.stats.mode == 1 and in_lds.stats.passes == 1
+        hashed = check_against_oracle(index, image, queries, 10, dtype, 64, tuning=Tuning(mode=2))
+        assert hashed.stats.mode == 2 and hashed.stats.passes == 1
+        small = check_against_oracle(index, image, queries, 10, dtype, 64, tuning=Tuning(hash_cap=256, next_cap=96, mode=1))
         assert small.stats.passes >= 2 and small.stats.retried_lds > 0
-        forced = check_against_oracle(index, image, queries, 10, dtype, 64, tuning=Tuning(0, 0, 0, 1))
+        tiny = check_against_oracle(index, image, queries, 10, dtype, 64, tuning=Tuning(hash_cap=64, next_cap=40, mode=2))
+        assert tiny.stats.passes >= 3 and tiny.stats.retried_global > 0
+        forced = check_against_oracle(index, image, queries, 10, dtype, 64, tuning=Tuning(mode=3))
         assert forced.stats.retried_global == len(queries)
-        assert np.array_equal(base.keys, small.keys) and np.array_equal(base.keys, forced.keys)
+        few_waves = check_against_oracle(index, image, queries, 10, dtype, 64, tuning=Tuning(mode=2, waves_per_cu=1))
+        for other in (in_lds, hashed, small, tiny, forced, few_waves):
+            assert np.array_equal(base.keys, other.keys)
+
+
+def test_persistent_waves_cover_large_batches(reference):
+    """More queries than resident waves: the ticket queue must hand every query to exactly one wave."""
+    from usearch_amd import Index, Tuning
+    image, _, _ = util.build_image(2000, 32, "l2sq", "i8", seed=61)
+    index = Index.restore(image)
+    queries = util.make_vectors(9000, 32, "i8", seed=62)
+    for mode in (1, 2):
+        got = check_against_oracle(index, image, queries, 5, "i8", 16, tuning=Tuning(mode=mode, waves_per_cu=2))
+        assert got.stats.grid <= 2 * 256 < len(queries)
+        peaks = index.last_peaks(len(queries))
+        assert peaks[:, 0].max() <= 4 * 64 and np.all(peaks[:, 1] >= 1)
 
 
 def test_large_expansion(reference):
@@ -150,4 +172,5 @@ def test_large_expansion(reference):
     index = Index.restore(image)
     queries = util.make_vectors(40, 48, "f32", seed=52)
     for expansion in (256, 1000):
-        check_against_oracle(index, image, queries, 10, "f32", expansion)
+        got = check_against_oracle(index, image, queries, 10, "f32", expansion)
+        assert got.stats.mode == 2  # the visited set no longer fits LDS next to 8 waves per CU

@@ -65,7 +65,8 @@ search_tuning_t tuning_from_c(usearch_amd_tuning_t const* t) {
         out.hash_cap = t->hash_cap;
         out.next_cap = t->next_cap;
         out.unroll = t->unroll;
-        out.force_global_scratch = t->force_global_scratch != 0;
+        out.mode = t->mode;
+        out.waves_per_cu = t->waves_per_cu;
     }
     return out;
 }
@@ -77,6 +78,9 @@ void stats_to_c(const search_stats_t& s, usearch_amd_stats_t* out) {
     out->retried_lds = s.retried_lds;
     out->retried_global = s.retried_global;
     out->kernel_ms = s.kernel_ms;
+    out->mode = s.mode;
+    out->grid = s.grid;
+    out->lds_bytes = s.lds_bytes;
 }
 
 void fail(usearch_amd_error_t* error, const char* message) {
@@ -223,6 +227,12 @@ void usearch_amd_search_many_device(usearch_amd_snapshot_t snapshot, void const*
                                                              &s, timed != 0))
         return fail(error, e);
     stats_to_c(s, stats);
+}
+
+void usearch_amd_last_peaks(usearch_amd_snapshot_t snapshot, uint32_t* out, size_t queries_count,
+                            usearch_amd_error_t* error) {
+    if (const char* e = as_snapshot(snapshot)->last_peaks(out, queries_count))
+        fail(error, e);
 }
 
 void usearch_amd_distances(usearch_amd_snapshot_t snapshot, void const* queries, size_t queries_count,

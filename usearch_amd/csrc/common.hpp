@@ -99,10 +99,11 @@ struct search_args_t {
     std::uint64_t* visited;    ///< [Q] visited_members  (index.hpp:3071)
     std::uint64_t* computed;   ///< [Q] computed_distances (index.hpp:3072)
     std::uint32_t* status;     ///< [Q] 0 = done, 1 = scratch overflow → rerun with bigger scratch
+    std::uint32_t* queue;      ///< one zeroed counter: persistent waves draw query tickets from it
+    std::uint32_t* peaks;      ///< optional [Q][2]: peak size of `next`, final size of `visits` (scratch-sizing telemetry)
     std::uint32_t hash_cap;    ///< LDS visited-set cells, power of two
     std::uint32_t next_cap;    ///< frontier heap capacity
-    // global-scratch variant only:
-    std::uint8_t* scratch;
+    std::uint8_t* scratch;        ///< per-wave global slabs (visited hash, or everything in the fallback mode)
     std::uint64_t scratch_stride; ///< bytes per launched wave
 };
 

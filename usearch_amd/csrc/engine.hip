@@ -77,7 +77,7 @@ void snapshot_t::release() {
         return;
     (void)hipSetDevice(device_);
     for (void* p : {d_vectors_, d_nbr0_, d_upper_ref_, d_upper_, d_keys_, (void*)d_status_, (void*)d_todo_,
-                    (void*)d_scratch_, (void*)d_stage_})
+                    (void*)d_queue_, (void*)d_peaks_, (void*)d_scratch_, (void*)d_stage_})
         if (p)
             (void)hipFree(p);
     if (h_status_)
@@ -89,8 +89,9 @@ void snapshot_t::release() {
     if (stream_)
         (void)hipStreamDestroy(stream_);
     d_vectors_ = d_nbr0_ = d_upper_ref_ = d_upper_ = d_keys_ = nullptr;
-    d_status_ = d_todo_ = h_status_ = nullptr;
+    d_status_ = d_todo_ = d_queue_ = d_peaks_ = h_status_ = nullptr;
     d_scratch_ = d_stage_ = nullptr;
+    workspace_queries_ = scratch_bytes_ = stage_bytes_ = 0;
     event_begin_ = event_end_ = nullptr;
     stream_ = nullptr;
 }
@@ -251,6 +252,9 @@ const char* snapshot_t::build(const image_t& image, int device) {
     view_.entry_slot = (std::uint32_t)image.entry_slot;
     view_.has_tombstones = tombstones.load() ? 1u : 0u;
 
+    hipDeviceProp_t properties;
+    UA_HIP(hipGetDeviceProperties(&properties, device));
+    compute_units_ = properties.multiProcessorCount > 0 ? properties.multiProcessorCount : 256;
     UA_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     UA_HIP(hipEventCreate(&event_begin_));
     UA_HIP(hipEventCreate(&event_end_));
@@ -263,12 +267,17 @@ const char* snapshot_t::ensure_workspace(std::size_t queries, std::size_t scratc
             (void)hipFree(d_status_);
         if (d_todo_)
             (void)hipFree(d_todo_);
+        if (d_peaks_)
+            (void)hipFree(d_peaks_);
         if (h_status_)
             (void)hipHostFree(h_status_);
-        d_status_ = d_todo_ = h_status_ = nullptr;
+        d_status_ = d_todo_ = d_peaks_ = h_status_ = nullptr;
         workspace_queries_ = 0;
         UA_HIP(hipMalloc((void**)&d_status_, queries * 4));
         UA_HIP(hipMalloc((void**)&d_todo_, queries * 4));
+        UA_HIP(hipMalloc((void**)&d_peaks_, queries * 8));
+        if (!d_queue_)
+            UA_HIP(hipMalloc((void**)&d_queue_, 256));
         UA_HIP(hipHostMalloc((void**)&h_status_, queries * 4, hipHostMallocDefault));
         workspace_queries_ = queries;
     }
@@ -350,23 +359,40 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
         expansion = default_expansion_search_k;
     const std::uint32_t ef = (std::uint32_t)std::max(expansion, wanted); // index.hpp:3052
 
-    // ---- scratch sizing. A hop marks at most m0 slots and pushes at most m0 candidates, so hops·m0 bounds both; hops ≈ ef
-    // in practice (73-84 pops, 1.2-2.1 k distances at ef = 64), hence the generous multiples below.
+    // ---- scratch sizing, from measurements with the reference's own traversal (DESIGN.md "scratch sizing"): the frontier
+    // peaks at 2.4-3.9 × ef and the visited set ends at 18-30 × ef entries; outliers go through the retry ladder below.
     const std::uint32_t query_lds = view_.chunks * (scalar_ == scalar_f16_k ? 32u : 16u);
     const std::uint32_t lds_budget = (std::uint32_t)env_size("USEARCH_AMD_LDS_BUDGET", 160 * 1024);
     std::uint32_t hash_cap = tuning.hash_cap ? tuning.hash_cap : (std::uint32_t)env_size("USEARCH_AMD_HASH_CAP", 0);
     if (!hash_cap)
-        hash_cap = std::max<std::uint32_t>(1024, ef * 64);
+        hash_cap = std::max<std::uint32_t>(1024, ef * 48);
     hash_cap = pow2_ceil(hash_cap);
     std::uint32_t next_cap = tuning.next_cap ? tuning.next_cap : (std::uint32_t)env_size("USEARCH_AMD_NEXT_CAP", 0);
     if (!next_cap)
-        next_cap = std::max<std::uint32_t>(256, ef * 8);
+        next_cap = std::max<std::uint32_t>(256, ef * 4);
     // never larger than the index could possibly need
     hash_cap = std::min<std::uint32_t>(hash_cap, pow2_ceil((std::uint32_t)std::min<std::uint64_t>(view_.size * 2 + 128, 1u << 30)));
     next_cap = (std::uint32_t)std::min<std::uint64_t>(next_cap, view_.size + 64);
-    const std::uint32_t unroll = tuning.unroll ? tuning.unroll : (std::uint32_t)env_size("USEARCH_AMD_UNROLL", view_.chunks / lanes_ >= 8 ? 8 : 4);
+    const std::uint32_t unroll = tuning.unroll ? tuning.unroll
+                                               : (std::uint32_t)env_size("USEARCH_AMD_UNROLL", view_.chunks / lanes_ >= 8 ? 8 : 4);
+    const std::uint32_t waves_cap = tuning.waves_per_cu ? tuning.waves_per_cu
+                                                        : (std::uint32_t)env_size("USEARCH_AMD_WAVES_PER_CU", 16);
+    std::uint32_t mode_request = tuning.mode ? tuning.mode : (std::uint32_t)env_size("USEARCH_AMD_MODE", 0);
 
-    const bool force_global = tuning.force_global_scratch || env_size("USEARCH_AMD_FORCE_GLOBAL", 0) != 0;
+    auto lds_bytes_for = [&](int mode, std::uint32_t cap_next, std::uint32_t cap_hash) -> std::uint64_t {
+        if (mode == scratch_global_k)
+            return query_lds;
+        const scratch_layout_t l = scratch_layout(ef, cap_next, mode == scratch_lds_k ? (std::uint64_t)cap_hash * 4 : 0);
+        return query_lds + l.total;
+    };
+    auto waves_for = [&](std::uint64_t lds_bytes) -> std::uint32_t {
+        const std::uint64_t granule = (lds_bytes + 1023) / 1024 * 1024; // LDS is allocated in coarse granules
+        return (std::uint32_t)std::max<std::uint64_t>(1, std::min<std::uint64_t>(waves_cap, lds_budget / std::max<std::uint64_t>(granule, 1)));
+    };
+    // auto: keep the visited set in LDS only while that still leaves 8 waves per CU; otherwise move it to the global hash
+    int mode = mode_request == 1 ? scratch_lds_k : mode_request == 2 ? scratch_hash_k : mode_request == 3 ? scratch_global_k
+               : (waves_for(lds_bytes_for(scratch_lds_k, next_cap, hash_cap)) >= 8 ? scratch_lds_k : scratch_hash_k);
+
     if (const char* e = ensure_workspace(count, 0))
         return e;
 
@@ -381,6 +407,8 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
     args.visited = visited;
     args.computed = computed;
     args.status = d_status_;
+    args.queue = d_queue_;
+    args.peaks = d_peaks_;
 
     launch_params_t params{};
     params.metric = metric_;
@@ -390,6 +418,7 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
 
     float total_ms = 0.f;
     auto timed_launch = [&](const launch_params_t& p, const search_args_t& a) -> const char* {
+        UA_HIP(hipMemsetAsync(d_queue_, 0, 4, stream));
         if (timed)
             UA_HIP(hipEventRecord(event_begin_, stream));
         UA_HIP(launch_search(scalar_, p, view_, a));
@@ -402,7 +431,7 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
         }
         return nullptr;
     };
-    /// Collects the indices of overflowed queries among `pending` into h_status_/d_todo_; returns how many.
+    /// Collects the indices of overflowed queries (among `previous`, or all) and uploads them as the next todo list.
     auto collect_overflow = [&](const std::vector<std::uint32_t>* previous, std::vector<std::uint32_t>& todo) -> const char* {
         UA_HIP(hipMemcpyAsync(h_status_, d_status_, count * 4, hipMemcpyDeviceToHost, stream));
         UA_HIP(hipStreamSynchronize(stream));
@@ -425,30 +454,35 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
     std::uint32_t passes = 0;
     bool have_todo = false;
 
-    // ---- pass 1 (+2): LDS scratch, second time with everything LDS can hold
-    if (!force_global) {
+    // ---- pass 1 (+2): persistent waves, heaps in LDS; the second attempt moves the visited set to the global hash and
+    //      gives both structures 4× the room
+    if (mode != scratch_global_k) {
         for (int attempt = 0; attempt < 2; ++attempt) {
-            scratch_layout_t layout = scratch_layout(ef, next_cap, hash_cap * 4);
-            if (query_lds + layout.total > lds_budget) {
-                if (attempt == 0) {
-                    // shrink to what fits; if even the minimum does not fit, go global
-                    while (hash_cap > 1024 && query_lds + scratch_layout(ef, next_cap, hash_cap * 4).total > lds_budget)
-                        hash_cap /= 2;
-                    while (next_cap > 128 && query_lds + scratch_layout(ef, next_cap, hash_cap * 4).total > lds_budget)
-                        next_cap /= 2;
-                    layout = scratch_layout(ef, next_cap, hash_cap * 4);
-                }
-                if (query_lds + layout.total > lds_budget)
-                    break;
+            if (lds_bytes_for(mode, next_cap, hash_cap) > lds_budget) {
+                if (mode == scratch_lds_k)
+                    mode = scratch_hash_k;
+                while (next_cap > 64 && lds_bytes_for(mode, next_cap, hash_cap) > lds_budget)
+                    next_cap /= 2;
+                if (lds_bytes_for(mode, next_cap, hash_cap) > lds_budget)
+                    break; // `top` alone does not fit LDS: straight to the global fallback
             }
+            const std::uint64_t lds_bytes = lds_bytes_for(mode, next_cap, hash_cap);
+            const std::uint32_t pending = have_todo ? (std::uint32_t)todo.size() : (std::uint32_t)count;
+            const std::uint32_t grid = (std::uint32_t)std::min<std::uint64_t>(pending, (std::uint64_t)waves_for(lds_bytes) * compute_units_);
+            const std::uint64_t slab = mode == scratch_hash_k ? (std::uint64_t)hash_cap * 4 : 0;
+            if (const char* e = ensure_workspace(count, slab * grid))
+                return e;
             args.hash_cap = hash_cap;
             args.next_cap = next_cap;
             args.todo = have_todo ? d_todo_ : nullptr;
-            args.count = have_todo ? (std::uint32_t)todo.size() : (std::uint32_t)count;
-            params.global_scratch = false;
-            params.lds_bytes = (std::uint32_t)(query_lds + layout.total);
+            args.count = pending;
+            args.scratch = d_scratch_;
+            args.scratch_stride = slab;
+            params.mode = mode;
+            params.grid = grid;
+            params.lds_bytes = (std::uint32_t)lds_bytes;
             if (stats && attempt == 1)
-                stats->retried_lds = args.count;
+                stats->retried_lds = pending;
             if (const char* e = timed_launch(params, args))
                 return e;
             ++passes;
@@ -456,25 +490,18 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
                 return e;
             todo.swap(todo_next);
             have_todo = true;
-            if (todo.empty())
+            if (todo.empty() || attempt == 1)
                 break;
-            // enlarge for the second attempt: ×8 cells, ×8 frontier, clipped to the LDS budget
-            std::uint32_t bigger_hash = hash_cap, bigger_next = next_cap;
-            for (int grow = 0; grow < 3; ++grow) {
-                if (query_lds + scratch_layout(ef, bigger_next * 2, bigger_hash * 4).total <= lds_budget)
-                    bigger_next *= 2;
-                if (query_lds + scratch_layout(ef, bigger_next, bigger_hash * 2 * 4).total <= lds_budget)
-                    bigger_hash *= 2;
-            }
-            if (bigger_hash == hash_cap && bigger_next == next_cap)
-                break;
-            hash_cap = bigger_hash;
-            next_cap = bigger_next;
+            mode = scratch_hash_k;
+            hash_cap = std::min<std::uint32_t>(hash_cap * 4, pow2_ceil((std::uint32_t)std::min<std::uint64_t>(view_.size * 2 + 128, 1u << 30)));
+            next_cap = (std::uint32_t)std::min<std::uint64_t>((std::uint64_t)next_cap * 4, view_.size + 64);
+            while (next_cap > 64 && lds_bytes_for(mode, next_cap, hash_cap) > lds_budget)
+                next_cap = next_cap * 3 / 4;
         }
     }
 
     // ---- pass 3: global-memory scratch — exact sizes (one bit per slot, one frontier cell per slot), cannot overflow
-    if (force_global || (have_todo && !todo.empty())) {
+    if (mode == scratch_global_k || (have_todo && !todo.empty())) {
         if (!have_todo) {
             todo.resize(count);
             for (std::uint32_t q = 0; q < count; ++q)
@@ -501,7 +528,8 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
             args.count = (std::uint32_t)chunk;
             args.scratch = d_scratch_;
             args.scratch_stride = slab;
-            params.global_scratch = true;
+            params.mode = scratch_global_k;
+            params.grid = (std::uint32_t)chunk;
             params.lds_bytes = query_lds;
             if (const char* e = timed_launch(params, args))
                 return e;
@@ -517,7 +545,20 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
     if (stats) {
         stats->passes = passes;
         stats->kernel_ms = total_ms;
+        stats->mode = (std::uint32_t)mode + 1;
+        stats->grid = params.grid;
+        stats->lds_bytes = params.lds_bytes;
     }
+    last_count_ = count;
+    return nullptr;
+}
+
+const char* snapshot_t::last_peaks(std::uint32_t* out, std::size_t queries) {
+    std::lock_guard<std::mutex> lock(mutex_);
+    if (!d_peaks_ || queries > last_count_)
+        return "No telemetry for that many queries";
+    UA_HIP(hipSetDevice(device_));
+    UA_HIP(hipMemcpy(out, d_peaks_, queries * 8, hipMemcpyDeviceToHost));
     return nullptr;
 }
 

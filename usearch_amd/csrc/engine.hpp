@@ -20,10 +20,11 @@ namespace usearch_amd {
 
 /// Tunables of one search launch; zeros mean "choose for me".
 struct search_tuning_t {
-    std::uint32_t hash_cap = 0; ///< LDS visited-set cells (power of two)
-    std::uint32_t next_cap = 0; ///< LDS frontier capacity
-    std::uint32_t unroll = 0;   ///< 16-byte loads in flight per lane inside one row (4 or 8)
-    bool force_global_scratch = false;
+    std::uint32_t hash_cap = 0;     ///< visited-set cells per query (power of two)
+    std::uint32_t next_cap = 0;     ///< frontier capacity per query
+    std::uint32_t unroll = 0;       ///< 16-byte loads in flight per lane inside one row (4 or 8)
+    std::uint32_t mode = 0;         ///< 0 = auto, 1 = visited set in LDS, 2 = visited set in a global hash, 3 = all-global fallback
+    std::uint32_t waves_per_cu = 0; ///< persistent waves per compute unit (0 = as many as LDS / registers admit)
 };
 
 struct search_stats_t {
@@ -31,6 +32,9 @@ struct search_stats_t {
     std::uint32_t retried_lds = 0;       ///< queries rerun with the enlarged LDS scratch
     std::uint32_t retried_global = 0;    ///< queries rerun with the global-memory scratch
     float kernel_ms = 0.f;               ///< HIP-event time of the search launches of this call (when `timed`)
+    std::uint32_t mode = 0;              ///< scratch mode of the last launch (1 = LDS, 2 = global hash, 3 = all global)
+    std::uint32_t grid = 0;              ///< persistent waves of the last launch
+    std::uint32_t lds_bytes = 0;         ///< LDS per wave of the last launch
 };
 
 class snapshot_t {
@@ -67,6 +71,9 @@ class snapshot_t {
                             std::uint64_t* counts, std::uint64_t* visited, std::uint64_t* computed,
                             const search_tuning_t& tuning, search_stats_t* stats);
 
+    /// Telemetry of the last search_device call: per query {peak frontier size, visited-set size}; host copy.
+    const char* last_peaks(std::uint32_t* out, std::size_t queries);
+
     /// out[q][j] = metric(query q, stored row slots[q][j]); host buffers, queries in storage kind.
     const char* distances_host(const void* queries, std::size_t count, std::size_t stride_bytes,
                                const std::uint32_t* slots, std::size_t slots_per_query, float* out);
@@ -94,8 +101,11 @@ class snapshot_t {
     std::mutex host_mutex_; ///< serialises `search_host` callers around the staging block
     std::uint32_t* d_status_ = nullptr;
     std::uint32_t* d_todo_ = nullptr;
+    std::uint32_t* d_queue_ = nullptr;
+    std::uint32_t* d_peaks_ = nullptr;
+    int compute_units_ = 256;
     std::uint32_t* h_status_ = nullptr; ///< pinned
-    std::size_t workspace_queries_ = 0;
+    std::size_t workspace_queries_ = 0, last_count_ = 0;
     std::uint8_t* d_scratch_ = nullptr;
     std::size_t scratch_bytes_ = 0;
     // staging for search_host
@@ -110,7 +120,8 @@ struct launch_params_t {
     metric_kind_t metric;
     std::uint32_t lanes;
     std::uint32_t unroll;
-    bool global_scratch;
+    int mode; ///< scratch_mode_t of kernels.hpp
+    std::uint32_t grid;
     std::uint32_t lds_bytes;
     hipStream_t stream;
 };

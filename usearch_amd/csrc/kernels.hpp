@@ -231,19 +231,26 @@ UA_DEVICE std::uint32_t hash_slot(std::uint32_t slot) {
     return h ^ (h >> 15);
 }
 
+/// Where the per-query scratch lives.
+enum scratch_mode_t : int {
+    scratch_lds_k = 0,    ///< top, next, visits (hash) all in LDS — small expansions
+    scratch_hash_k = 1,   ///< top, next in LDS; visits = open-addressing hash in a per-wave global slab (L2/MALL resident)
+    scratch_global_k = 2, ///< everything in a per-wave global slab, visits = one bit per slot: cannot overflow (fallback)
+};
+
 /// Returns true for lanes whose `slot` was NOT in the set before (and now is). Inactive lanes return false.
-template <bool global_ak>
-UA_DEVICE bool visits_set(std::uint32_t* cells, std::uint32_t mask_or_words, std::uint32_t slot, bool active) {
+template <int mode_ak>
+UA_DEVICE bool visits_set(std::uint32_t* cells, std::uint32_t mask, std::uint32_t slot, bool active) {
     bool fresh = false;
-    if constexpr (global_ak) {
+    if constexpr (mode_ak == scratch_global_k) {
         if (active) {
             const std::uint32_t bit = 1u << (slot & 31);
             const std::uint32_t old = atomicOr(cells + (slot >> 5), bit);
             fresh = (old & bit) == 0;
         }
-    } else {
+    } else { // LDS or global hash: the same CAS probing, ds_cmpst vs global_atomic_cmpswap
         if (active) {
-            std::uint32_t h = hash_slot(slot) & mask_or_words;
+            std::uint32_t h = hash_slot(slot) & mask;
             for (;;) {
                 const std::uint32_t old = atomicCAS(cells + h, none_slot_k, slot);
                 if (old == none_slot_k) {
@@ -252,7 +259,7 @@ UA_DEVICE bool visits_set(std::uint32_t* cells, std::uint32_t mask_or_words, std
                 }
                 if (old == slot)
                     break;
-                h = (h + 1) & mask_or_words;
+                h = (h + 1) & mask;
             }
         }
     }
@@ -481,21 +488,21 @@ UA_DEVICE query_norm_t stage_query(const snapshot_view_t& ix, const std::uint8_t
 
 /// Byte offsets of the per-wave scratch areas; the same arithmetic runs on the host to size LDS / the global slab.
 struct scratch_layout_t {
-    std::uint64_t top, next, visits, cand_slots, cand_distances, total;
+    std::uint64_t top, next, cand_slots, cand_distances, visits, total;
 };
 
 inline __host__ __device__ std::uint64_t align16(std::uint64_t v) { return (v + 15u) & ~(std::uint64_t)15u; }
 
-/// LDS variant: query | top | next | hash | candidates. Global variant: LDS holds only the query and the candidates.
+/// top | next | candidates | visits. In `scratch_hash_k` mode the first three sit in LDS and `visits` alone in the slab.
 inline __host__ __device__ scratch_layout_t scratch_layout(std::uint64_t ef, std::uint64_t next_cap,
                                                            std::uint64_t visits_bytes) {
     scratch_layout_t l;
     l.top = 0;
     l.next = l.top + align16(ef * 8);
-    l.visits = l.next + align16(next_cap * 8);
-    l.cand_slots = l.visits + align16(visits_bytes);
+    l.cand_slots = l.next + align16(next_cap * 8);
     l.cand_distances = l.cand_slots + 256;
-    l.total = l.cand_distances + 256;
+    l.visits = l.cand_distances + 256;
+    l.total = l.visits + align16(visits_bytes);
     return l;
 }
 
@@ -503,38 +510,37 @@ template <int scalar_ak> inline __host__ __device__ std::uint32_t query_lds_byte
     return chunks * (scalar_ak == scalar_f16_k ? 32u : 16u); // a multiple of 16
 }
 
-template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, bool global_ak>
-__global__ __launch_bounds__(64) void search_kernel(const snapshot_view_t ix, const search_args_t args) {
-    extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
+/**
+ *  One query, start to finish. `heaps` = top/next/candidate arrays (LDS, or the slab in `scratch_global_k`), `visits` = the
+ *  visited set (LDS hash, slab hash or slab bitmap). Returns false on scratch overflow (nothing written but `status`).
+ */
+template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, int mode_ak>
+UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, std::uint32_t q,
+                          std::uint8_t* query_lds, std::uint8_t* heaps, std::uint32_t* visits) {
+    constexpr bool global_ak = mode_ak == scratch_global_k;
     using mem = scratch_gt<global_ak>;
     const std::uint32_t lane = lane_id();
-    const std::uint32_t q = args.todo ? args.todo[blockIdx.x] : blockIdx.x;
     const std::uint32_t ef = args.ef, wanted = args.wanted;
-
-    // ---- carve the scratch
-    std::uint8_t* query_lds = lds;
-    const std::uint32_t query_bytes = query_lds_bytes<scalar_ak>(ix.chunks);
-    const std::uint64_t visits_bytes = global_ak ? ((ix.size + 31) / 32) * 4 : (std::uint64_t)args.hash_cap * 4;
-    const scratch_layout_t layout = scratch_layout(ef, args.next_cap, visits_bytes);
-    std::uint8_t* slab = global_ak ? args.scratch + (std::uint64_t)blockIdx.x * args.scratch_stride
-                                   : lds + query_bytes;
-    cand_t* top = reinterpret_cast<cand_t*>(slab + layout.top);
-    cand_t* next = reinterpret_cast<cand_t*>(slab + layout.next);
-    std::uint32_t* visits = reinterpret_cast<std::uint32_t*>(slab + layout.visits);
-    std::uint32_t* cand_slots = reinterpret_cast<std::uint32_t*>(slab + layout.cand_slots);
-    float* cand_distances = reinterpret_cast<float*>(slab + layout.cand_distances);
+    const scratch_layout_t layout = scratch_layout(ef, args.next_cap, 0);
+    cand_t* top = reinterpret_cast<cand_t*>(heaps + layout.top);
+    cand_t* next = reinterpret_cast<cand_t*>(heaps + layout.next);
+    std::uint32_t* cand_slots = reinterpret_cast<std::uint32_t*>(heaps + layout.cand_slots);
+    float* cand_distances = reinterpret_cast<float*>(heaps + layout.cand_distances);
     const std::uint32_t visits_mask = global_ak ? 0u : args.hash_cap - 1;
     const std::uint32_t visits_limit = global_ak ? 0xFFFFFFFFu : args.hash_cap - args.hash_cap / 4; // 75 % load
 
     const query_norm_t a2 = stage_query<metric_ak, scalar_ak, lanes_ak>(
         ix, args.queries + (std::uint64_t)q * args.query_stride, query_lds);
 
-    if constexpr (!global_ak) { // the global bitmap is zeroed by the host before the launch
+    if constexpr (!global_ak) { // the bitmap of `scratch_global_k` is zeroed by the host before the launch
         uint4* cells = reinterpret_cast<uint4*>(visits);
         const uint4 empty = {none_slot_k, none_slot_k, none_slot_k, none_slot_k};
         for (std::uint32_t i = lane; i < args.hash_cap / 4; i += 64)
             cells[i] = empty;
-        wave_sync<global_ak>();
+        if constexpr (mode_ak == scratch_hash_k) // the stores must have reached L2 before this wave's atomics probe the cells
+            wave_sync<true>();
+        else
+            wave_sync<false>();
     }
 
     std::uint32_t computed = 0, cycles = 0; // context_t counters, index.hpp:2208-2211
@@ -576,7 +582,8 @@ __global__ __launch_bounds__(64) void search_kernel(const snapshot_view_t ix, co
                 for (int offset = 32; offset >= 1; offset >>= 1)
                     best = fminf(best, __shfl_xor(best, offset, 64));
                 if (best < closest_distance) {
-                    const std::uint32_t winner = (std::uint32_t)__ffsll((long long)ballot(lane < count && mine == best)) - 1;
+                    const std::uint32_t winner =
+                        (std::uint32_t)__ffsll((long long)ballot(lane < count && mine == best)) - 1;
                     closest_distance = best;
                     closest = read_lane_u32(neighbor, winner);
                     changed = true;
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(64) void search_kernel(const snapshot_view_t ix, co
     }
 
     // ---- search_to_find_in_base_: best-first beam on level 0 (index.hpp:4176-4246)
-    std::uint32_t top_size = 0, next_size = 0, visits_count = 0;
+    std::uint32_t top_size = 0, next_size = 0, visits_count = 0, peak_next = 1;
     bool overflow = false;
     if (lane == 0)
         mem::store(cand_slots, closest);
@@ -596,9 +603,8 @@ __global__ __launch_bounds__(64) void search_kernel(const snapshot_view_t ix, co
     measure(1);
     float radius = uniform_f32(mem::load(cand_distances));
     heap_push<global_ak>(next, next_size, -radius, closest);
-    visits_set<global_ak>(visits, visits_mask, closest, lane == 0);
+    visits_set<mode_ak>(visits, visits_mask, closest, lane == 0);
     visits_count = 1;
-    wave_sync<global_ak>();
     if (allowed(closest))
         sorted_insert<global_ak>(top, top_size, ef, radius, closest);
 
@@ -623,7 +629,7 @@ __global__ __launch_bounds__(64) void search_kernel(const snapshot_view_t ix, co
                 break;
             }
             // visits.set(successor) for the whole tile at once; duplicates inside a list were removed on upload
-            const bool fresh = visits_set<global_ak>(visits, visits_mask, neighbor, present);
+            const bool fresh = visits_set<mode_ak>(visits, visits_mask, neighbor, present);
             const std::uint64_t fresh_mask = ballot(fresh);
             const std::uint32_t count = popcount64(fresh_mask);
             visits_count += count;
@@ -651,6 +657,7 @@ __global__ __launch_bounds__(64) void search_kernel(const snapshot_view_t ix, co
                     radius = uniform_f32(cand_distance(mem::load(top + (top_size - 1)))); // top.top() = worst kept
                 }
             }
+            peak_next = next_size > peak_next ? next_size : peak_next;
             wave_sync<global_ak>();
         }
         if (overflow)
@@ -661,7 +668,7 @@ __global__ __launch_bounds__(64) void search_kernel(const snapshot_view_t ix, co
     if (overflow) {
         if (lane == 0)
             args.status[q] = status_overflow_k;
-        return;
+        return false;
     }
     const std::uint32_t found = top_size < wanted ? top_size : wanted;
     for (std::uint32_t i = lane; i < wanted; i += 64) {
@@ -680,6 +687,46 @@ __global__ __launch_bounds__(64) void search_kernel(const snapshot_view_t ix, co
         args.visited[q] = cycles;
         args.computed[q] = computed;
         args.status[q] = status_done_k;
+        if (args.peaks) { // scratch-sizing telemetry: how big `next` and `visits` got
+            args.peaks[2 * (std::uint64_t)q] = peak_next;
+            args.peaks[2 * (std::uint64_t)q + 1] = visits_count;
+        }
+    }
+    return true;
+}
+
+/**
+ *  Persistent launch: every wave (= workgroup) pulls query indices from `args.queue` until the batch is drained, so a
+ *  grid of (CUs × resident waves) covers any batch size with perfect dynamic balance and one scratch slab per wave.
+ *  `scratch_global_k` is the exception: one wave per query, statically (its bitmaps are zeroed per launch by the host).
+ */
+template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, int mode_ak>
+__global__ __launch_bounds__(64) void search_kernel(const snapshot_view_t ix, const search_args_t args) {
+    extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
+    std::uint8_t* query_lds = lds;
+    const std::uint32_t query_bytes = query_lds_bytes<scalar_ak>(ix.chunks);
+    std::uint8_t* slab = args.scratch + (std::uint64_t)blockIdx.x * args.scratch_stride;
+    const scratch_layout_t layout = scratch_layout(args.ef, args.next_cap, 0);
+
+    if constexpr (mode_ak == scratch_global_k) {
+        const std::uint32_t q = args.todo ? args.todo[blockIdx.x] : blockIdx.x;
+        search_one<metric_ak, scalar_ak, lanes_ak, unroll_ak, mode_ak>(
+            ix, args, q, query_lds, slab, reinterpret_cast<std::uint32_t*>(slab + layout.visits));
+    } else {
+        std::uint8_t* heaps = lds + query_bytes;
+        std::uint32_t* visits = mode_ak == scratch_lds_k ? reinterpret_cast<std::uint32_t*>(heaps + layout.visits)
+                                                         : reinterpret_cast<std::uint32_t*>(slab);
+        for (;;) {
+            std::uint32_t ticket = 0;
+            if (lane_id() == 0)
+                ticket = atomicAdd(args.queue, 1u);
+            ticket = uniform_u32(ticket);
+            if (ticket >= args.count)
+                break;
+            const std::uint32_t q = args.todo ? args.todo[ticket] : ticket;
+            search_one<metric_ak, scalar_ak, lanes_ak, unroll_ak, mode_ak>(ix, args, q, query_lds, heaps, visits);
+            wave_sync<false>();
+        }
     }
 }
 

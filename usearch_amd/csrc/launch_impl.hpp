@@ -8,28 +8,37 @@
 
 namespace usearch_amd {
 
-template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, bool global_ak>
+template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, int mode_ak>
 hipError_t launch_search_one(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
-    auto kernel = search_kernel<metric_ak, scalar_ak, lanes_ak, unroll_ak, global_ak>;
+    auto kernel = search_kernel<metric_ak, scalar_ak, lanes_ak, unroll_ak, mode_ak>;
     if (p.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess)
             return e;
     }
-    hipLaunchKernelGGL(kernel, dim3(args.count), dim3(64), p.lds_bytes, p.stream, view, args);
+    hipLaunchKernelGGL(kernel, dim3(p.grid), dim3(64), p.lds_bytes, p.stream, view, args);
     return hipGetLastError();
+}
+
+template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak>
+hipError_t launch_search_mode(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
+    switch (p.mode) {
+    case scratch_lds_k: return launch_search_one<metric_ak, scalar_ak, lanes_ak, unroll_ak, scratch_lds_k>(p, view, args);
+    case scratch_hash_k: return launch_search_one<metric_ak, scalar_ak, lanes_ak, unroll_ak, scratch_hash_k>(p, view, args);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 template <int metric_ak, int scalar_ak, int lanes_ak>
 hipError_t launch_search_lanes(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
-    if (p.global_scratch)
-        return launch_search_one<metric_ak, scalar_ak, lanes_ak, 4, true>(p, view, args);
+    if (p.mode == scratch_global_k)
+        return launch_search_one<metric_ak, scalar_ak, lanes_ak, 4, scratch_global_k>(p, view, args);
     if constexpr (lanes_ak == 8) {
         if (p.unroll >= 8)
-            return launch_search_one<metric_ak, scalar_ak, lanes_ak, 8, false>(p, view, args);
+            return launch_search_mode<metric_ak, scalar_ak, lanes_ak, 8>(p, view, args);
     }
-    return launch_search_one<metric_ak, scalar_ak, lanes_ak, 4, false>(p, view, args);
+    return launch_search_mode<metric_ak, scalar_ak, lanes_ak, 4>(p, view, args);
 }
 
 template <int metric_ak, int scalar_ak>

@@ -30,14 +30,14 @@ NUMPY_DTYPES = {"f32": np.float32, "f64": np.float64, "f16": np.float16, "i8": n
 
 class Tuning(C.Structure):
     """`usearch_amd_tuning_t`."""
-    _fields_ = [("hash_cap", C.c_uint32), ("next_cap", C.c_uint32), ("unroll", C.c_uint32),
-                ("force_global_scratch", C.c_uint32)]
+    _fields_ = [("hash_cap", C.c_uint32), ("next_cap", C.c_uint32), ("unroll", C.c_uint32), ("mode", C.c_uint32),
+                ("waves_per_cu", C.c_uint32)]
 
 
 class Stats(C.Structure):
     """`usearch_amd_stats_t`."""
     _fields_ = [("passes", C.c_uint32), ("retried_lds", C.c_uint32), ("retried_global", C.c_uint32),
-                ("kernel_ms", C.c_float)]
+                ("kernel_ms", C.c_float), ("mode", C.c_uint32), ("grid", C.c_uint32), ("lds_bytes", C.c_uint32)]
 
 
 _library = None
@@ -48,7 +48,8 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_snapshot_connectivity", "usearch_amd_snapshot_max_level", "usearch_amd_snapshot_bytes_per_vector",
     "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_scalar_kind",
     "usearch_amd_snapshot_metric_kind", "usearch_amd_snapshot_lanes_per_row", "usearch_amd_search_many",
-    "usearch_amd_search_many_device", "usearch_amd_distances", "usearch_amd_test_containers", "usearch_amd_cast",
+    "usearch_amd_search_many_device", "usearch_amd_last_peaks", "usearch_amd_distances",
+    "usearch_amd_test_containers", "usearch_amd_cast",
 ]
 
 
@@ -85,6 +86,7 @@ def library() -> C.CDLL:
                                                  C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.POINTER(Tuning), C.c_int,
                                                  C.POINTER(Stats), err_p]
+    L.usearch_amd_last_peaks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, err_p]
     L.usearch_amd_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, err_p]
     L.usearch_amd_test_containers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
@@ -293,6 +295,14 @@ class Index:
                                                  C.byref(stats), C.byref(err))
         _raise(err, "usearch_amd_search_many_device")
         return stats
+
+    def last_peaks(self, queries_count: int) -> np.ndarray:
+        """[Q, 2] = {peak frontier size, visited-set size} of the most recent search (scratch-sizing telemetry)."""
+        out = np.zeros((queries_count, 2), dtype=np.uint32)
+        err = C.c_char_p()
+        library().usearch_amd_last_peaks(self._handle, _pointer(out), queries_count, C.byref(err))
+        _raise(err, "usearch_amd_last_peaks")
+        return out
 
     def distances(self, queries: np.ndarray, slots: np.ndarray) -> np.ndarray:
         """out[q, j] = metric(queries[q], stored vector of slot slots[q, j]); queries in the storage kind."""
