@@ -34,6 +34,19 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (â
 DTYPE_BYTES = {"f32": 4.0, "f16": 2.0, "i8": 1.0, "b1": 0.125}
 
 
+def host_cores() -> int:
+    """Cores this process may really use: the cgroup CPU quota when there is one (the GPU boxes advertise 256 logical
+    CPUs but grant a 16-CPU quota; oversubscribing the reference's OpenMP loops makes them slower), else all CPUs."""
+    cpus = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cpus = max(1, min(cpus, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return cpus
+
+
 def log(*args):
     print(*args, file=sys.stderr, flush=True)
 
@@ -80,11 +93,15 @@ def main() -> None:
     parser.add_argument("--cpu-seconds", type=float, default=12.0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--sharded", action="store_true")
-    parser.add_argument("--build-threads", type=int, default=int(os.environ.get("BENCH_BUILD_THREADS", 0)))
+    parser.add_argument("--build-threads", type=int, default=int(os.environ.get("BENCH_BUILD_THREADS", 0)),
+                        help="threads the reference uses to build the index (0 = 2 x the cgroup CPU quota)")
     parser.add_argument("--cache-dir", default=os.environ.get("BENCH_CACHE_DIR", ""),
                         help="keep the reference-built index image here between runs (e.g. /dev/shm)")
     args = parser.parse_args()
     metric = args.metric or ("hamming" if args.dtype == "b1" else "l2sq" if args.dtype == "i8" else "cos")
+    cores = host_cores()
+    if not args.build_threads:
+        args.build_threads = 2 * cores
 
     import torch
     import torch.distributed as dist
@@ -174,7 +191,7 @@ def main() -> None:
     recall, expansion = None, args.expansion
     sample = min(args.recall_queries, args.queries)
     if rank == 0 and not args.sharded and sample:
-        truth, *_ = ref_index.search(queries_host[:sample], args.k, dtype=args.dtype, exact=True)
+        truth, *_ = ref_index.search(queries_host[:sample], args.k, dtype=args.dtype, exact=True, threads=2 * cores)
         sweep = [args.expansion] if args.expansion else [64, 128, 256, 512]
         for ef in sweep:
             search_step(ef, False)
@@ -224,14 +241,14 @@ def main() -> None:
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ref_index.expansion_search = expansion
-        threads = refbind.max_threads()
+        threads = cores
         pilot = min(args.queries, 64 * threads)
         t1 = time.perf_counter()
-        ref_index.search(queries_host[:pilot], args.k, dtype=args.dtype, threads=0)
+        ref_index.search(queries_host[:pilot], args.k, dtype=args.dtype, threads=threads)
         rate = pilot / (time.perf_counter() - t1)
         sample_q = int(min(args.queries, max(pilot, rate * args.cpu_seconds)))
         t1 = time.perf_counter()
-        rkeys, *_ = ref_index.search(queries_host[:sample_q], args.k, dtype=args.dtype, threads=0)
+        rkeys, *_ = ref_index.search(queries_host[:sample_q], args.k, dtype=args.dtype, threads=threads)
         cpu_seconds = time.perf_counter() - t1
         agree = float(np.mean(keys_dev[:sample_q].cpu().numpy().astype(np.uint64) == rkeys))
         cpu = {"value": sample_q / cpu_seconds, "unit": "queries/s", "cores": threads, "kind": "reference",

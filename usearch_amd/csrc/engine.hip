@@ -369,7 +369,7 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
     hash_cap = pow2_ceil(hash_cap);
     std::uint32_t next_cap = tuning.next_cap ? tuning.next_cap : (std::uint32_t)env_size("USEARCH_AMD_NEXT_CAP", 0);
     if (!next_cap)
-        next_cap = std::max<std::uint32_t>(256, ef * 4);
+        next_cap = std::max<std::uint32_t>(512, ef * 4);
     // never larger than the index could possibly need
     hash_cap = std::min<std::uint32_t>(hash_cap, pow2_ceil((std::uint32_t)std::min<std::uint64_t>(view_.size * 2 + 128, 1u << 30)));
     next_cap = (std::uint32_t)std::min<std::uint64_t>(next_cap, view_.size + 64);
