@@ -48,7 +48,7 @@ enum {
 typedef struct usearch_amd_tuning_t {
     uint32_t hash_cap;     /**< visited-set cells per query (power of two); 0 = 48 × expansion */
     uint32_t next_cap;     /**< frontier capacity per query; 0 = 4 × expansion */
-    uint32_t unroll;       /**< 16-byte loads in flight per lane within one row: 4 or 8; 0 = auto */
+    uint32_t variant;      /**< kernel build: 0 = auto, 1 = 4 loads in flight/≤128 VGPRs, 2 = 8/≤128, 3 = 8/≤168, 4 = 12/≤256 */
     uint32_t mode;         /**< scratch placement: 0 = auto, 1 = visited set in LDS, 2 = visited set in a per-wave global
                                 hash (heaps stay in LDS), 3 = everything in global memory with exact sizes (slow) */
     uint32_t waves_per_cu; /**< persistent waves per compute unit; 0 = as many as LDS and registers admit (≤ 16) */
@@ -144,6 +144,10 @@ USEARCH_AMD_EXPORT void usearch_amd_distances(usearch_amd_snapshot_t snapshot, v
                                               size_t queries_count, size_t queries_stride, uint32_t const* slots,
                                               size_t slots_per_query, usearch_amd_distance_t* out,
                                               usearch_amd_error_t* error);
+
+/** HIP-event duration of the kernel of the most recent `usearch_amd_distances` call: the dependency-free row-gather rate,
+ *  i.e. the ceiling the search kernel's distance phase is measured against. */
+USEARCH_AMD_EXPORT float usearch_amd_last_distances_ms(usearch_amd_snapshot_t snapshot);
 
 /**
  *  Self-test hook: replays `count` scripted operations on the device-side containers (kind 0 = frontier push of

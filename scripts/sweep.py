@@ -3,7 +3,7 @@
 the batched search under different scratch placements / persistent-wave counts / unroll depths.
 
     python scripts/sweep.py --n 500000 --dim 768 --dtype f16 --cache-dir /dev/shm --ef 64 256 \
-        --modes 1 2 --waves 4 8 16 --unrolls 4 8
+        --modes 1 2 --waves 4 8 16 --variants 1 2 3 4
 
 Development tool (not part of the product or of the test-suite); prints one line per variant to stdout.
 """
@@ -30,8 +30,9 @@ def main():
     p.add_argument("--ef", type=int, nargs="+", default=[64, 256])
     p.add_argument("--modes", type=int, nargs="+", default=[1, 2])
     p.add_argument("--waves", type=int, nargs="+", default=[0])
-    p.add_argument("--unrolls", type=int, nargs="+", default=[0])
+    p.add_argument("--variants", type=int, nargs="+", default=[0])
     p.add_argument("--cache-dir", default="/dev/shm")
+    p.add_argument("--gather", action="store_true")
     p.add_argument("--build-threads", type=int, default=0)
     args = p.parse_args()
     metric = "hamming" if args.dtype == "b1" else "l2sq" if args.dtype == "i8" else "cos"
@@ -63,12 +64,23 @@ def main():
     visited = torch.zeros(args.queries, dtype=torch.int64, device=device)
     computed = torch.zeros(args.queries, dtype=torch.int64, device=device)
     bpv, m0 = index.bytes_per_vector, 2 * index.connectivity
+    if args.gather:
+        # ceiling: the same row-gather + distance loop with no graph dependencies (one wave per list of random slots)
+        rng = np.random.default_rng(7)
+        for per in (256, 2048):
+            nq = min(args.queries, 8192)
+            slots = rng.integers(0, len(index), size=(nq, per), dtype=np.uint32)
+            for _ in range(2):
+                index.distances(queries_host[:nq], slots)
+            ms = index.last_distances_ms
+            print(f"gather ceiling: {nq} waves x {per} random rows of {index.row_stride} B: {ms:.3f} ms = "
+                  f"{nq * per * index.row_stride / ms / 1e6:.1f} GB/s", flush=True)
     reference_keys = {}
     for ef in args.ef:
         for mode in args.modes:
             for waves in args.waves:
-                for unroll in args.unrolls:
-                    tuning = usearch_amd.Tuning(mode=mode, waves_per_cu=waves, unroll=unroll)
+                for variant in args.variants:
+                    tuning = usearch_amd.Tuning(mode=mode, waves_per_cu=waves, variant=variant)
                     ms = []
                     for step in range(args.steps + 1):
                         stats = index.search_device(queries.data_ptr(), args.queries, queries.stride(0), args.k, ef,
@@ -84,7 +96,7 @@ def main():
                     same = reference_keys.setdefault(ef, k_host)
                     peaks = index.last_peaks(args.queries)
                     print(f"ef={ef:4d} mode={stats.mode} waves/cu={waves:2d} grid={stats.grid:5d} lds={stats.lds_bytes:6d} "
-                          f"unroll={unroll} passes={stats.passes} ms={best:8.3f} (mean {np.mean(ms):8.3f}) "
+                          f"variant={variant} passes={stats.passes} ms={best:8.3f} (mean {np.mean(ms):8.3f}) "
                           f"qps={args.queries / best * 1e3:10.0f} GB/s={step_bytes / best / 1e6:8.1f} "
                           f"dist/q={c.mean():.0f} hops/q={v.mean():.0f} peak_next={peaks[:, 0].max()} "
                           f"visits_max={peaks[:, 1].max()} identical={np.array_equal(same, k_host)}", flush=True)

@@ -64,7 +64,7 @@ search_tuning_t tuning_from_c(usearch_amd_tuning_t const* t) {
     if (t) {
         out.hash_cap = t->hash_cap;
         out.next_cap = t->next_cap;
-        out.unroll = t->unroll;
+        out.variant = t->variant;
         out.mode = t->mode;
         out.waves_per_cu = t->waves_per_cu;
     }
@@ -242,6 +242,8 @@ void usearch_amd_distances(usearch_amd_snapshot_t snapshot, void const* queries,
                                                               slots_per_query, out))
         fail(error, e);
 }
+
+float usearch_amd_last_distances_ms(usearch_amd_snapshot_t snapshot) { return as_snapshot(snapshot)->last_distances_ms(); }
 
 void usearch_amd_test_containers(uint32_t const* kinds, float const* keys, uint32_t const* slots, size_t count,
                                  size_t limit, uint64_t* popped, size_t* popped_count, uint64_t* top, size_t* top_count,

@@ -307,15 +307,42 @@ const char* snapshot_t::ensure_staging(std::size_t query_bytes, std::size_t coun
     return nullptr;
 }
 
-static hipError_t launch_search(scalar_kind_t scalar, const launch_params_t& p, const snapshot_view_t& view,
-                                const search_args_t& args) {
-    switch (scalar) {
-    case scalar_f32_k: return launch_search_f32(p, view, args);
-    case scalar_f16_k: return launch_search_f16(p, view, args);
-    case scalar_i8_k: return launch_search_i8(p, view, args);
-    case scalar_b1x8_k: return launch_search_b1(p, view, args);
-    default: return hipErrorInvalidValue;
-    }
+static hipError_t launch_search(metric_kind_t metric, scalar_kind_t scalar, const launch_params_t& p,
+                                const snapshot_view_t& view, const search_args_t& args) {
+#define UA_PAIR(m, sc, name)                                                                                           \
+    if (metric == m && scalar == sc)                                                                                   \
+        return launch_search_##name(p, view, args);
+    UA_PAIR(metric_ip_k, scalar_f32_k, ip_f32)
+    UA_PAIR(metric_cos_k, scalar_f32_k, cos_f32)
+    UA_PAIR(metric_l2sq_k, scalar_f32_k, l2sq_f32)
+    UA_PAIR(metric_ip_k, scalar_f16_k, ip_f16)
+    UA_PAIR(metric_cos_k, scalar_f16_k, cos_f16)
+    UA_PAIR(metric_l2sq_k, scalar_f16_k, l2sq_f16)
+    UA_PAIR(metric_ip_k, scalar_i8_k, ip_i8)
+    UA_PAIR(metric_cos_k, scalar_i8_k, cos_i8)
+    UA_PAIR(metric_l2sq_k, scalar_i8_k, l2sq_i8)
+    UA_PAIR(metric_hamming_k, scalar_b1x8_k, hamming_b1)
+#undef UA_PAIR
+    return hipErrorInvalidValue;
+}
+
+static hipError_t launch_distances(metric_kind_t metric, scalar_kind_t scalar, const distances_params_t& p,
+                                   const snapshot_view_t& view) {
+#define UA_PAIR(m, sc, name)                                                                                           \
+    if (metric == m && scalar == sc)                                                                                   \
+        return launch_distances_##name(p, view);
+    UA_PAIR(metric_ip_k, scalar_f32_k, ip_f32)
+    UA_PAIR(metric_cos_k, scalar_f32_k, cos_f32)
+    UA_PAIR(metric_l2sq_k, scalar_f32_k, l2sq_f32)
+    UA_PAIR(metric_ip_k, scalar_f16_k, ip_f16)
+    UA_PAIR(metric_cos_k, scalar_f16_k, cos_f16)
+    UA_PAIR(metric_l2sq_k, scalar_f16_k, l2sq_f16)
+    UA_PAIR(metric_ip_k, scalar_i8_k, ip_i8)
+    UA_PAIR(metric_cos_k, scalar_i8_k, cos_i8)
+    UA_PAIR(metric_l2sq_k, scalar_i8_k, l2sq_i8)
+    UA_PAIR(metric_hamming_k, scalar_b1x8_k, hamming_b1)
+#undef UA_PAIR
+    return hipErrorInvalidValue;
 }
 
 /// Fills the outputs of queries that cannot produce anything (empty index): count 0, key 0 / signalling NaN padding.
@@ -369,25 +396,36 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
     hash_cap = pow2_ceil(hash_cap);
     std::uint32_t next_cap = tuning.next_cap ? tuning.next_cap : (std::uint32_t)env_size("USEARCH_AMD_NEXT_CAP", 0);
     if (!next_cap)
-        next_cap = std::max<std::uint32_t>(512, ef * 4);
+        next_cap = std::max<std::uint32_t>(512, ef * 3 + 256);
     // never larger than the index could possibly need
     hash_cap = std::min<std::uint32_t>(hash_cap, pow2_ceil((std::uint32_t)std::min<std::uint64_t>(view_.size * 2 + 128, 1u << 30)));
     next_cap = (std::uint32_t)std::min<std::uint64_t>(next_cap, view_.size + 64);
-    const std::uint32_t unroll = tuning.unroll ? tuning.unroll
-                                               : (std::uint32_t)env_size("USEARCH_AMD_UNROLL", view_.chunks / lanes_ >= 8 ? 8 : 4);
+    // register/latency trade-off of the kernel (kernels.hpp kernel_variant_t); rows shorter than 8 chunks per lane have
+    // nothing to unroll
+    const std::uint32_t chunks_per_lane = view_.chunks / lanes_;
+    std::uint32_t variant_request = tuning.variant ? tuning.variant : (std::uint32_t)env_size("USEARCH_AMD_VARIANT", 0);
+    int variant = variant_request ? (int)variant_request - 1 : chunks_per_lane >= 8 ? variant_u8_w3_k : variant_u4_w4_k;
+    if (lanes_ < 8 || variant < 0 || variant > variant_u12_w2_k)
+        variant = variant_u4_w4_k;
+    const std::uint32_t variant_waves_per_cu = 4u * (std::uint32_t)variant_waves(variant);
     const std::uint32_t waves_cap = tuning.waves_per_cu ? tuning.waves_per_cu
                                                         : (std::uint32_t)env_size("USEARCH_AMD_WAVES_PER_CU", 16);
     std::uint32_t mode_request = tuning.mode ? tuning.mode : (std::uint32_t)env_size("USEARCH_AMD_MODE", 0);
 
+    // `top` lives in registers (1 / 4 / 8 entries per lane) while the expansion allows it
+    const bool top_in_memory = tuning.top_in_memory || env_size("USEARCH_AMD_TOP_IN_MEMORY", 0) != 0;
+    const std::uint32_t entries_per_lane = top_in_memory ? 0u : ef <= 64 ? 1u : ef <= 256 ? 4u : ef <= 512 ? 8u : 0u;
     auto lds_bytes_for = [&](int mode, std::uint32_t cap_next, std::uint32_t cap_hash) -> std::uint64_t {
         if (mode == scratch_global_k)
             return query_lds;
-        const scratch_layout_t l = scratch_layout(ef, cap_next, mode == scratch_lds_k ? (std::uint64_t)cap_hash * 4 : 0);
+        const scratch_layout_t l = scratch_layout(entries_per_lane ? 0 : ef, cap_next,
+                                                  mode == scratch_lds_k ? (std::uint64_t)cap_hash * 4 : 0);
         return query_lds + l.total;
     };
     auto waves_for = [&](std::uint64_t lds_bytes) -> std::uint32_t {
         const std::uint64_t granule = (lds_bytes + 1023) / 1024 * 1024; // LDS is allocated in coarse granules
-        return (std::uint32_t)std::max<std::uint64_t>(1, std::min<std::uint64_t>(waves_cap, lds_budget / std::max<std::uint64_t>(granule, 1)));
+        return (std::uint32_t)std::max<std::uint64_t>(
+            1, std::min<std::uint64_t>(std::min(waves_cap, variant_waves_per_cu), lds_budget / std::max<std::uint64_t>(granule, 1)));
     };
     // auto: keep the visited set in LDS only while that still leaves 8 waves per CU; otherwise move it to the global hash
     int mode = mode_request == 1 ? scratch_lds_k : mode_request == 2 ? scratch_hash_k : mode_request == 3 ? scratch_global_k
@@ -413,7 +451,7 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
     launch_params_t params{};
     params.metric = metric_;
     params.lanes = lanes_;
-    params.unroll = unroll;
+    params.variant = variant;
     params.stream = stream;
 
     float total_ms = 0.f;
@@ -421,7 +459,7 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
         UA_HIP(hipMemsetAsync(d_queue_, 0, 4, stream));
         if (timed)
             UA_HIP(hipEventRecord(event_begin_, stream));
-        UA_HIP(launch_search(scalar_, p, view_, a));
+        UA_HIP(launch_search(metric_, scalar_, p, view_, a));
         if (timed) {
             UA_HIP(hipEventRecord(event_end_, stream));
             UA_HIP(hipEventSynchronize(event_end_));
@@ -479,6 +517,7 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
             args.scratch = d_scratch_;
             args.scratch_stride = slab;
             params.mode = mode;
+            params.entries_per_lane = entries_per_lane;
             params.grid = grid;
             params.lds_bytes = (std::uint32_t)lds_bytes;
             if (stats && attempt == 1)
@@ -529,6 +568,7 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
             args.scratch = d_scratch_;
             args.scratch_stride = slab;
             params.mode = scratch_global_k;
+            params.entries_per_lane = 0;
             params.grid = (std::uint32_t)chunk;
             params.lds_bytes = query_lds;
             if (const char* e = timed_launch(params, args))
@@ -665,13 +705,16 @@ const char* snapshot_t::distances_host(const void* queries, std::size_t count, s
         p.slots_per_query = (std::uint32_t)slots_per_query;
         p.count = (std::uint32_t)count;
         p.out = d_out;
-        switch (scalar_) {
-        case scalar_f32_k: e = launch_distances_f32(p, view_); break;
-        case scalar_f16_k: e = launch_distances_f16(p, view_); break;
-        case scalar_i8_k: e = launch_distances_i8(p, view_); break;
-        case scalar_b1x8_k: e = launch_distances_b1(p, view_); break;
-        default: e = hipErrorInvalidValue; break;
-        }
+        if (e == hipSuccess)
+            e = hipEventRecord(event_begin_, stream_);
+        if (e == hipSuccess)
+            e = launch_distances(metric_, scalar_, p, view_);
+        if (e == hipSuccess)
+            e = hipEventRecord(event_end_, stream_);
+        if (e == hipSuccess)
+            e = hipEventSynchronize(event_end_);
+        if (e == hipSuccess)
+            e = hipEventElapsedTime(&last_distances_ms_, event_begin_, event_end_);
         if (e == hipSuccess)
             e = hipStreamSynchronize(stream_);
         if (e == hipSuccess)

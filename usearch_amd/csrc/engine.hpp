@@ -22,9 +22,10 @@ namespace usearch_amd {
 struct search_tuning_t {
     std::uint32_t hash_cap = 0;     ///< visited-set cells per query (power of two)
     std::uint32_t next_cap = 0;     ///< frontier capacity per query
-    std::uint32_t unroll = 0;       ///< 16-byte loads in flight per lane inside one row (4 or 8)
+    std::uint32_t variant = 0;      ///< 0 = auto, else 1 + kernel_variant_t (loads in flight per lane vs waves per SIMD)
     std::uint32_t mode = 0;         ///< 0 = auto, 1 = visited set in LDS, 2 = visited set in a global hash, 3 = all-global fallback
     std::uint32_t waves_per_cu = 0; ///< persistent waves per compute unit (0 = as many as LDS / registers admit)
+    std::uint32_t top_in_memory = 0; ///< 1 = keep `top` in scratch memory even when it would fit registers
 };
 
 struct search_stats_t {
@@ -55,6 +56,7 @@ class snapshot_t {
     std::size_t device_bytes() const { return device_bytes_; }
     std::uint64_t count_present() const { return count_present_; }
     std::uint64_t upper_lists() const { return upper_lists_; }
+    float last_distances_ms() const { return last_distances_ms_; }
 
     /**
      *  Batched search, all pointers device-resident, queries already in the storage scalar kind.
@@ -104,6 +106,7 @@ class snapshot_t {
     std::uint32_t* d_queue_ = nullptr;
     std::uint32_t* d_peaks_ = nullptr;
     int compute_units_ = 256;
+    float last_distances_ms_ = 0.f;
     std::uint32_t* h_status_ = nullptr; ///< pinned
     std::size_t workspace_queries_ = 0, last_count_ = 0;
     std::uint8_t* d_scratch_ = nullptr;
@@ -119,16 +122,26 @@ class snapshot_t {
 struct launch_params_t {
     metric_kind_t metric;
     std::uint32_t lanes;
-    std::uint32_t unroll;
-    int mode; ///< scratch_mode_t of kernels.hpp
+    int variant; ///< kernel_variant_t of kernels.hpp
+    int mode;    ///< scratch_mode_t of kernels.hpp
+    std::uint32_t entries_per_lane; ///< `top` in registers: 1, 4 or 8 entries per lane; 0 = in scratch memory
     std::uint32_t grid;
     std::uint32_t lds_bytes;
     hipStream_t stream;
 };
-hipError_t launch_search_f32(const launch_params_t&, const snapshot_view_t&, const search_args_t&);
-hipError_t launch_search_f16(const launch_params_t&, const snapshot_view_t&, const search_args_t&);
-hipError_t launch_search_i8(const launch_params_t&, const snapshot_view_t&, const search_args_t&);
-hipError_t launch_search_b1(const launch_params_t&, const snapshot_view_t&, const search_args_t&);
+#define USEARCH_AMD_DECLARE_LAUNCHERS(name)                                                                            \
+    hipError_t launch_search_##name(const launch_params_t&, const snapshot_view_t&, const search_args_t&);            \
+    hipError_t launch_distances_##name(const struct distances_params_t&, const snapshot_view_t&);
+USEARCH_AMD_DECLARE_LAUNCHERS(ip_f32)
+USEARCH_AMD_DECLARE_LAUNCHERS(cos_f32)
+USEARCH_AMD_DECLARE_LAUNCHERS(l2sq_f32)
+USEARCH_AMD_DECLARE_LAUNCHERS(ip_f16)
+USEARCH_AMD_DECLARE_LAUNCHERS(cos_f16)
+USEARCH_AMD_DECLARE_LAUNCHERS(l2sq_f16)
+USEARCH_AMD_DECLARE_LAUNCHERS(ip_i8)
+USEARCH_AMD_DECLARE_LAUNCHERS(cos_i8)
+USEARCH_AMD_DECLARE_LAUNCHERS(l2sq_i8)
+USEARCH_AMD_DECLARE_LAUNCHERS(hamming_b1)
 
 struct distances_params_t {
     metric_kind_t metric;
@@ -142,11 +155,6 @@ struct distances_params_t {
     std::uint32_t count;
     float* out;
 };
-hipError_t launch_distances_f32(const distances_params_t&, const snapshot_view_t&);
-hipError_t launch_distances_f16(const distances_params_t&, const snapshot_view_t&);
-hipError_t launch_distances_i8(const distances_params_t&, const snapshot_view_t&);
-hipError_t launch_distances_b1(const distances_params_t&, const snapshot_view_t&);
-
 /// Is there a HIP kernel for this (metric, scalar) pair?
 bool kernel_available(metric_kind_t metric, scalar_kind_t scalar);
 

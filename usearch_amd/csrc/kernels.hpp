@@ -222,6 +222,112 @@ UA_DEVICE bool sorted_insert(cand_t* top, std::uint32_t& size, std::uint32_t lim
     return true;
 }
 
+/**
+ *  `top` as the search kernel holds it.
+ *    epl_ak > 0   in REGISTERS, blocked layout: lane L owns entries [L·epl, (L+1)·epl) of the ascending array, unused cells
+ *                 hold +inf. An insert is EPL ballots + one cross-lane carry — no LDS round trips, nothing to conflict.
+ *                 Capacity 64·epl ≥ expansion.
+ *    epl_ak == 0  in scratch memory (LDS, or the global slab of the fallback mode): any expansion.
+ *  Same observable behaviour as sorted_buffer_gt (index.hpp:845-956) either way.
+ */
+template <int epl_ak, bool global_ak> struct top_gt {
+    static constexpr int regs_k = epl_ak > 0 ? epl_ak : 1;
+    // SSA vectors, not arrays: an array would be an alloca that the optimiser demotes to scratch memory as soon as one
+    // of the unrolled select chains below is folded into an indexed load
+    typedef float distances_t __attribute__((ext_vector_type(regs_k)));
+    typedef std::uint32_t slots_t __attribute__((ext_vector_type(regs_k)));
+    distances_t d;
+    slots_t s;
+    cand_t* cells = nullptr;
+    std::uint32_t size = 0;
+
+    UA_DEVICE void reset(cand_t* memory) {
+        cells = memory;
+        size = 0;
+#pragma unroll
+        for (int i = 0; i < regs_k; ++i)
+            d[i] = __builtin_inff(), s[i] = none_slot_k;
+    }
+
+    /// insert(element, limit), index.hpp:928-939.
+    UA_DEVICE bool insert(float nd, std::uint32_t ns, std::uint32_t limit) {
+        if constexpr (epl_ak == 0) {
+            return sorted_insert<global_ak>(cells, size, limit, nd, ns);
+        } else {
+            const std::uint32_t lane = lane_id();
+            std::uint32_t position = 0; // lower_bound: entries strictly smaller (the +inf padding never is)
+#pragma unroll
+            for (int i = 0; i < epl_ak; ++i)
+                position += popcount64(ballot(d[i] < nd));
+            if (position == limit)
+                return false;
+            const float carry_d = __shfl_up(d[epl_ak - 1], 1, 64);
+            const std::uint32_t carry_s = __shfl_up(s[epl_ak - 1], 1, 64);
+            const std::uint32_t base = lane * epl_ak;
+#pragma unroll
+            for (int i = epl_ak - 1; i >= 0; --i) {
+                const std::uint32_t g = base + i;
+                const float below_d = i > 0 ? d[i > 0 ? i - 1 : 0] : carry_d;
+                const std::uint32_t below_s = i > 0 ? s[i > 0 ? i - 1 : 0] : carry_s;
+                if (g > position)
+                    d[i] = below_d, s[i] = below_s;
+                else if (g == position)
+                    d[i] = nd, s[i] = ns;
+                if (g >= limit) // what fell off the end of a full buffer
+                    d[i] = __builtin_inff(), s[i] = none_slot_k;
+            }
+            size += size == limit ? 0u : 1u;
+            return true;
+        }
+    }
+
+    /// top.top() — the worst kept distance (index.hpp:891). Requires size > 0.
+    UA_DEVICE float worst() const {
+        if constexpr (epl_ak == 0) {
+            return uniform_f32(cand_distance(scratch_gt<global_ak>::load(cells + (size - 1))));
+        } else {
+            const std::uint32_t index = size - 1;
+            const std::uint32_t base = lane_id() * epl_ak;
+            float mine = d[0]; // in the owning lane: the last entry whose global index does not exceed `index`
+#pragma unroll
+            for (int i = 1; i < epl_ak; ++i)
+                mine = base + i <= index ? d[i] : mine;
+            return read_lane_f32(mine, index / epl_ak);
+        }
+    }
+
+    /// dump_to(keys, distances, capacity = wanted) with the key 0 / signalling-NaN padding of index.hpp:2707-2722.
+    UA_DEVICE void dump(const snapshot_view_t& ix, const search_args_t& args, std::uint32_t q, std::uint32_t found,
+                        std::uint32_t wanted) const {
+        std::uint64_t* keys = args.keys + (std::uint64_t)q * wanted;
+        std::uint32_t* bits = reinterpret_cast<std::uint32_t*>(args.distances) + (std::uint64_t)q * wanted;
+        if constexpr (epl_ak == 0) {
+            for (std::uint32_t i = lane_id(); i < wanted; i += 64) {
+                std::uint64_t key = 0;
+                std::uint32_t distance_bits = signaling_nan_bits_k;
+                if (i < found) {
+                    const cand_t c = scratch_gt<global_ak>::load(cells + i);
+                    key = ix.keys[cand_slot(c)];
+                    distance_bits = (std::uint32_t)c;
+                }
+                keys[i] = key;
+                bits[i] = distance_bits;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < epl_ak; ++i) {
+                const std::uint32_t g = lane_id() * epl_ak + i;
+                if (g < wanted) {
+                    keys[g] = g < found ? ix.keys[s[i]] : 0;
+                    bits[g] = g < found ? __builtin_bit_cast(std::uint32_t, d[i]) : signaling_nan_bits_k;
+                }
+            }
+            for (std::uint32_t g = 64 * epl_ak + lane_id(); g < wanted; g += 64) // wanted beyond capacity: padding only
+                keys[g] = 0, bits[g] = signaling_nan_bits_k;
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------------
 //  `visits`: exact set of slots — index.hpp:1085-1211. LDS: open addressing (CAS); global slab: one bit per slot.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -493,12 +599,13 @@ struct scratch_layout_t {
 
 inline __host__ __device__ std::uint64_t align16(std::uint64_t v) { return (v + 15u) & ~(std::uint64_t)15u; }
 
-/// top | next | candidates | visits. In `scratch_hash_k` mode the first three sit in LDS and `visits` alone in the slab.
-inline __host__ __device__ scratch_layout_t scratch_layout(std::uint64_t ef, std::uint64_t next_cap,
+/// top | next | candidates | visits. In `scratch_hash_k` mode the first three sit in LDS and `visits` alone in the slab;
+/// `top_cells` is 0 when `top` lives in registers.
+inline __host__ __device__ scratch_layout_t scratch_layout(std::uint64_t top_cells, std::uint64_t next_cap,
                                                            std::uint64_t visits_bytes) {
     scratch_layout_t l;
     l.top = 0;
-    l.next = l.top + align16(ef * 8);
+    l.next = l.top + align16(top_cells * 8);
     l.cand_slots = l.next + align16(next_cap * 8);
     l.cand_distances = l.cand_slots + 256;
     l.visits = l.cand_distances + 256;
@@ -514,15 +621,16 @@ template <int scalar_ak> inline __host__ __device__ std::uint32_t query_lds_byte
  *  One query, start to finish. `heaps` = top/next/candidate arrays (LDS, or the slab in `scratch_global_k`), `visits` = the
  *  visited set (LDS hash, slab hash or slab bitmap). Returns false on scratch overflow (nothing written but `status`).
  */
-template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, int mode_ak>
+template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, int mode_ak, int epl_ak>
 UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, std::uint32_t q,
                           std::uint8_t* query_lds, std::uint8_t* heaps, std::uint32_t* visits) {
     constexpr bool global_ak = mode_ak == scratch_global_k;
     using mem = scratch_gt<global_ak>;
     const std::uint32_t lane = lane_id();
     const std::uint32_t ef = args.ef, wanted = args.wanted;
-    const scratch_layout_t layout = scratch_layout(ef, args.next_cap, 0);
-    cand_t* top = reinterpret_cast<cand_t*>(heaps + layout.top);
+    const scratch_layout_t layout = scratch_layout(epl_ak ? 0 : ef, args.next_cap, 0);
+    top_gt<epl_ak, global_ak> top;
+    top.reset(reinterpret_cast<cand_t*>(heaps + layout.top));
     cand_t* next = reinterpret_cast<cand_t*>(heaps + layout.next);
     std::uint32_t* cand_slots = reinterpret_cast<std::uint32_t*>(heaps + layout.cand_slots);
     float* cand_distances = reinterpret_cast<float*>(heaps + layout.cand_distances);
@@ -595,7 +703,7 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     }
 
     // ---- search_to_find_in_base_: best-first beam on level 0 (index.hpp:4176-4246)
-    std::uint32_t top_size = 0, next_size = 0, visits_count = 0, peak_next = 1;
+    std::uint32_t next_size = 0, visits_count = 0, peak_next = 1;
     bool overflow = false;
     if (lane == 0)
         mem::store(cand_slots, closest);
@@ -606,12 +714,12 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     visits_set<mode_ak>(visits, visits_mask, closest, lane == 0);
     visits_count = 1;
     if (allowed(closest))
-        sorted_insert<global_ak>(top, top_size, ef, radius, closest);
+        top.insert(radius, closest, ef);
 
     while (next_size) {
         const cand_t candidate = mem::load(next);
         const float candidate_distance = -uniform_f32(cand_distance(candidate));
-        if (candidate_distance > radius && top_size == ef) // index.hpp:4210, strict `>`
+        if (candidate_distance > radius && top.size == ef) // index.hpp:4210, strict `>`
             break;
         heap_pop<global_ak>(next, next_size);
         ++cycles;
@@ -643,18 +751,18 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
             // commit in list order with the reference's tests (index.hpp:4233-4240)
             const float mine = lane < count ? mem::load(cand_distances + lane) : 0.f;
             const std::uint32_t mine_slot = lane < count ? mem::load(cand_slots + lane) : 0u;
-            std::uint64_t pending = ballot(lane < count && (top_size < ef || mine < radius)); // radius only shrinks
+            std::uint64_t pending = ballot(lane < count && (top.size < ef || mine < radius)); // radius only shrinks
             while (pending) {
                 const std::uint32_t i = (std::uint32_t)__ffsll((long long)pending) - 1;
                 pending &= pending - 1;
                 const float d = read_lane_f32(mine, i);
-                if (!(top_size < ef || d < radius))
+                if (!(top.size < ef || d < radius))
                     continue;
                 const std::uint32_t successor = read_lane_u32(mine_slot, i);
                 heap_push<global_ak>(next, next_size, -d, successor);
                 if (allowed(successor)) {
-                    sorted_insert<global_ak>(top, top_size, ef, d, successor);
-                    radius = uniform_f32(cand_distance(mem::load(top + (top_size - 1)))); // top.top() = worst kept
+                    top.insert(d, successor, ef);
+                    radius = top.worst(); // top.top() = worst kept
                 }
             }
             peak_next = next_size > peak_next ? next_size : peak_next;
@@ -670,18 +778,8 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
             args.status[q] = status_overflow_k;
         return false;
     }
-    const std::uint32_t found = top_size < wanted ? top_size : wanted;
-    for (std::uint32_t i = lane; i < wanted; i += 64) {
-        std::uint64_t key = 0;
-        std::uint32_t distance_bits = signaling_nan_bits_k;
-        if (i < found) {
-            const cand_t c = mem::load(top + i);
-            key = ix.keys[cand_slot(c)];
-            distance_bits = (std::uint32_t)c;
-        }
-        args.keys[(std::uint64_t)q * wanted + i] = key;
-        reinterpret_cast<std::uint32_t*>(args.distances)[(std::uint64_t)q * wanted + i] = distance_bits;
-    }
+    const std::uint32_t found = top.size < wanted ? top.size : wanted;
+    top.dump(ix, args, q, found, wanted);
     if (lane == 0) {
         args.counts[q] = found;
         args.visited[q] = cycles;
@@ -700,17 +798,32 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
  *  grid of (CUs × resident waves) covers any batch size with perfect dynamic balance and one scratch slab per wave.
  *  `scratch_global_k` is the exception: one wave per query, statically (its bitmaps are zeroed per launch by the host).
  */
-template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, int mode_ak>
-__global__ __launch_bounds__(64) void search_kernel(const snapshot_view_t ix, const search_args_t args) {
+/**
+ *  Register/latency trade-off of one instantiation: how many 16-byte loads a lane keeps in flight inside a row
+ *  (`unroll`) against how many waves per SIMD the register allocator must leave room for (`waves`).
+ */
+enum kernel_variant_t : int {
+    variant_u4_w4_k = 0,  ///< 4 loads in flight, ≤ 128 VGPRs: 16 waves per CU
+    variant_u8_w4_k = 1,  ///< 8 loads in flight, ≤ 128 VGPRs
+    variant_u8_w3_k = 2,  ///< 8 loads in flight, ≤ 168 VGPRs: 12 waves per CU
+    variant_u12_w2_k = 3, ///< 12 loads in flight (a whole 768-d f16 row per lane group), ≤ 256 VGPRs: 8 waves per CU
+};
+constexpr int variant_unroll(int v) { return v == variant_u4_w4_k ? 4 : v == variant_u12_w2_k ? 12 : 8; }
+constexpr int variant_waves(int v) { return v == variant_u12_w2_k ? 2 : v == variant_u8_w3_k ? 3 : 4; }
+
+template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak>
+__global__ __launch_bounds__(64, variant_waves(variant_ak)) void search_kernel(const snapshot_view_t ix,
+                                                                               const search_args_t args) {
+    constexpr int unroll_ak = variant_unroll(variant_ak);
     extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
     std::uint8_t* query_lds = lds;
     const std::uint32_t query_bytes = query_lds_bytes<scalar_ak>(ix.chunks);
     std::uint8_t* slab = args.scratch + (std::uint64_t)blockIdx.x * args.scratch_stride;
-    const scratch_layout_t layout = scratch_layout(args.ef, args.next_cap, 0);
+    const scratch_layout_t layout = scratch_layout(epl_ak ? 0 : args.ef, args.next_cap, 0);
 
     if constexpr (mode_ak == scratch_global_k) {
         const std::uint32_t q = args.todo ? args.todo[blockIdx.x] : blockIdx.x;
-        search_one<metric_ak, scalar_ak, lanes_ak, unroll_ak, mode_ak>(
+        search_one<metric_ak, scalar_ak, lanes_ak, unroll_ak, mode_ak, epl_ak>(
             ix, args, q, query_lds, slab, reinterpret_cast<std::uint32_t*>(slab + layout.visits));
     } else {
         std::uint8_t* heaps = lds + query_bytes;
@@ -724,7 +837,7 @@ __global__ __launch_bounds__(64) void search_kernel(const snapshot_view_t ix, co
             if (ticket >= args.count)
                 break;
             const std::uint32_t q = args.todo ? args.todo[ticket] : ticket;
-            search_one<metric_ak, scalar_ak, lanes_ak, unroll_ak, mode_ak>(ix, args, q, query_lds, heaps, visits);
+            search_one<metric_ak, scalar_ak, lanes_ak, unroll_ak, mode_ak, epl_ak>(ix, args, q, query_lds, heaps, visits);
             wave_sync<false>();
         }
     }

@@ -8,9 +8,9 @@
 
 namespace usearch_amd {
 
-template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, int mode_ak>
+template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak>
 hipError_t launch_search_one(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
-    auto kernel = search_kernel<metric_ak, scalar_ak, lanes_ak, unroll_ak, mode_ak>;
+    auto kernel = search_kernel<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, epl_ak>;
     if (p.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
@@ -21,11 +21,23 @@ hipError_t launch_search_one(const launch_params_t& p, const snapshot_view_t& vi
     return hipGetLastError();
 }
 
-template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak>
+/// `top` in registers with 1 / 4 / 8 entries per lane (expansion ≤ 64 / 256 / 512), or in scratch memory (0).
+template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak>
+hipError_t launch_search_epl(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
+    switch (p.entries_per_lane) {
+    case 0: return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 0>(p, view, args);
+    case 1: return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 1>(p, view, args);
+    case 4: return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 4>(p, view, args);
+    case 8: return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 8>(p, view, args);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak>
 hipError_t launch_search_mode(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
     switch (p.mode) {
-    case scratch_lds_k: return launch_search_one<metric_ak, scalar_ak, lanes_ak, unroll_ak, scratch_lds_k>(p, view, args);
-    case scratch_hash_k: return launch_search_one<metric_ak, scalar_ak, lanes_ak, unroll_ak, scratch_hash_k>(p, view, args);
+    case scratch_lds_k: return launch_search_epl<metric_ak, scalar_ak, lanes_ak, variant_ak, scratch_lds_k>(p, view, args);
+    case scratch_hash_k: return launch_search_epl<metric_ak, scalar_ak, lanes_ak, variant_ak, scratch_hash_k>(p, view, args);
     default: return hipErrorInvalidValue;
     }
 }
@@ -33,12 +45,16 @@ hipError_t launch_search_mode(const launch_params_t& p, const snapshot_view_t& v
 template <int metric_ak, int scalar_ak, int lanes_ak>
 hipError_t launch_search_lanes(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
     if (p.mode == scratch_global_k)
-        return launch_search_one<metric_ak, scalar_ak, lanes_ak, 4, scratch_global_k>(p, view, args);
-    if constexpr (lanes_ak == 8) {
-        if (p.unroll >= 8)
-            return launch_search_mode<metric_ak, scalar_ak, lanes_ak, 8>(p, view, args);
+        return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_u4_w4_k, scratch_global_k, 0>(p, view, args);
+    if constexpr (lanes_ak == 8) { // rows of ≥ 128 bytes: the unroll depth matters
+        switch (p.variant) {
+        case variant_u8_w4_k: return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u8_w4_k>(p, view, args);
+        case variant_u8_w3_k: return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u8_w3_k>(p, view, args);
+        case variant_u12_w2_k: return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u12_w2_k>(p, view, args);
+        default: break;
+        }
     }
-    return launch_search_mode<metric_ak, scalar_ak, lanes_ak, 4>(p, view, args);
+    return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u4_w4_k>(p, view, args);
 }
 
 template <int metric_ak, int scalar_ak>
@@ -54,7 +70,7 @@ hipError_t launch_search_metric(const launch_params_t& p, const snapshot_view_t&
 
 template <int metric_ak, int scalar_ak, int lanes_ak>
 hipError_t launch_distances_one(const distances_params_t& p, const snapshot_view_t& view) {
-    auto kernel = distances_kernel<metric_ak, scalar_ak, lanes_ak, 4>;
+    auto kernel = distances_kernel<metric_ak, scalar_ak, lanes_ak, lanes_ak == 8 ? 8 : 4>;
     hipLaunchKernelGGL(kernel, dim3(p.count), dim3(64), p.lds_bytes, p.stream, view, p.queries, p.query_stride,
                        p.slots, p.slots_per_query, p.out);
     return hipGetLastError();
@@ -71,24 +87,14 @@ hipError_t launch_distances_metric(const distances_params_t& p, const snapshot_v
     }
 }
 
-/// ip / cos / l2sq over one numeric scalar kind.
-#define USEARCH_AMD_DEFINE_NUMERIC_LAUNCHERS(suffix, scalar_kind)                                                      \
-    hipError_t launch_search_##suffix(const launch_params_t& p, const snapshot_view_t& view,                           \
-                                      const search_args_t& args) {                                                     \
-        switch (p.metric) {                                                                                            \
-        case metric_ip_k: return launch_search_metric<metric_ip_k, scalar_kind>(p, view, args);                        \
-        case metric_cos_k: return launch_search_metric<metric_cos_k, scalar_kind>(p, view, args);                      \
-        case metric_l2sq_k: return launch_search_metric<metric_l2sq_k, scalar_kind>(p, view, args);                    \
-        default: return hipErrorInvalidValue;                                                                          \
-        }                                                                                                              \
+/// One (metric, scalar) pair per translation unit, so that the pairs compile in parallel.
+#define USEARCH_AMD_DEFINE_LAUNCHERS(name, metric_kind, scalar_kind)                                                   \
+    hipError_t launch_search_##name(const launch_params_t& p, const snapshot_view_t& view,                             \
+                                    const search_args_t& args) {                                                       \
+        return launch_search_metric<metric_kind, scalar_kind>(p, view, args);                                          \
     }                                                                                                                  \
-    hipError_t launch_distances_##suffix(const distances_params_t& p, const snapshot_view_t& view) {                   \
-        switch (p.metric) {                                                                                            \
-        case metric_ip_k: return launch_distances_metric<metric_ip_k, scalar_kind>(p, view);                           \
-        case metric_cos_k: return launch_distances_metric<metric_cos_k, scalar_kind>(p, view);                         \
-        case metric_l2sq_k: return launch_distances_metric<metric_l2sq_k, scalar_kind>(p, view);                       \
-        default: return hipErrorInvalidValue;                                                                          \
-        }                                                                                                              \
+    hipError_t launch_distances_##name(const distances_params_t& p, const snapshot_view_t& view) {                     \
+        return launch_distances_metric<metric_kind, scalar_kind>(p, view);                                             \
     }
 
 } // namespace usearch_amd

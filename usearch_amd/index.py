@@ -30,7 +30,7 @@ NUMPY_DTYPES = {"f32": np.float32, "f64": np.float64, "f16": np.float16, "i8": n
 
 class Tuning(C.Structure):
     """`usearch_amd_tuning_t`."""
-    _fields_ = [("hash_cap", C.c_uint32), ("next_cap", C.c_uint32), ("unroll", C.c_uint32), ("mode", C.c_uint32),
+    _fields_ = [("hash_cap", C.c_uint32), ("next_cap", C.c_uint32), ("variant", C.c_uint32), ("mode", C.c_uint32),
                 ("waves_per_cu", C.c_uint32)]
 
 
@@ -49,6 +49,7 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_scalar_kind",
     "usearch_amd_snapshot_metric_kind", "usearch_amd_snapshot_lanes_per_row", "usearch_amd_search_many",
     "usearch_amd_search_many_device", "usearch_amd_last_peaks", "usearch_amd_distances",
+    "usearch_amd_last_distances_ms",
     "usearch_amd_test_containers", "usearch_amd_cast",
 ]
 
@@ -89,6 +90,8 @@ def library() -> C.CDLL:
     L.usearch_amd_last_peaks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, err_p]
     L.usearch_amd_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, err_p]
+    L.usearch_amd_last_distances_ms.restype = C.c_float
+    L.usearch_amd_last_distances_ms.argtypes = [C.c_void_p]
     L.usearch_amd_test_containers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
                                               C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), err_p]
     L.usearch_amd_cast.restype = C.c_int
@@ -295,6 +298,10 @@ class Index:
                                                  C.byref(stats), C.byref(err))
         _raise(err, "usearch_amd_search_many_device")
         return stats
+
+    @property
+    def last_distances_ms(self) -> float:
+        return float(library().usearch_amd_last_distances_ms(self._handle))
 
     def last_peaks(self, queries_count: int) -> np.ndarray:
         """[Q, 2] = {peak frontier size, visited-set size} of the most recent search (scratch-sizing telemetry)."""
