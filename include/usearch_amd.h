@@ -48,7 +48,8 @@ enum {
 typedef struct usearch_amd_tuning_t {
     uint32_t hash_cap;     /**< visited-set cells per query (power of two); 0 = 48 × expansion */
     uint32_t next_cap;     /**< frontier capacity per query; 0 = 4 × expansion */
-    uint32_t variant;      /**< kernel build: 0 = auto, 1 = 4 loads in flight/≤128 VGPRs, 2 = 8/≤128, 3 = 8/≤168, 4 = 12/≤256 */
+    uint32_t variant;      /**< kernel build: 0 = auto, 1 = 4 row loads in flight per lane (≤128 VGPRs, 16 waves/CU), 2 = 8 loads
+                                (≤168 VGPRs, 12 waves/CU), 3 = 12 loads (≤256 VGPRs, 8 waves/CU) */
     uint32_t mode;         /**< scratch placement: 0 = auto, 1 = visited set in LDS, 2 = visited set in a per-wave global
                                 hash (heaps stay in LDS), 3 = everything in global memory with exact sizes (slow) */
     uint32_t waves_per_cu; /**< persistent waves per compute unit; 0 = as many as LDS and registers admit (≤ 16) */

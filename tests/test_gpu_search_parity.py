@@ -166,6 +166,19 @@ def test_persistent_waves_cover_large_batches(reference):
         assert peaks[:, 0].max() <= 4 * 64 and np.all(peaks[:, 1] >= 1)
 
 
+def test_every_kernel_build_agrees(reference):
+    """`top` in registers (1 / 4 / 8 entries per lane) or in LDS, times the three unroll/occupancy builds."""
+    from usearch_amd import Index, Tuning
+    image, _, _ = util.build_image(2500, 768, "cos", "f16", seed=71)
+    index = Index.restore(image)
+    assert index.lanes_per_row == 8
+    queries = util.make_vectors(48, 768, "f16", seed=72)
+    for expansion in (64, 128, 300, 600):
+        for variant in (1, 2, 3):
+            got = check_against_oracle(index, image, queries, 10, "f16", expansion, tuning=Tuning(variant=variant))
+            assert got.stats.passes == 1
+
+
 def test_large_expansion(reference):
     from usearch_amd import Index
     image, _, _ = util.build_image(4000, 48, "l2sq", "f32", seed=51)

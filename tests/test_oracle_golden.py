@@ -1,0 +1,88 @@
+"""CPU: the oracle (oracle/usearch_oracle.c) pinned against the committed golden fixtures — answers of the REAL reference
+(tests/golden/make_golden.py) — and against the literal known-answer vectors of the reference's own tests."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oraclebind
+from tests import util
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def load(path):
+    data = np.load(path)
+    return data, json.loads(str(data["meta"]))
+
+
+def test_fixtures_exist():
+    assert len(FIXTURES) >= 8 and os.path.exists(os.path.join(GOLDEN, "kat.json"))
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_oracle_reproduces_reference_answers(path):
+    data, meta = load(path)
+    index = oraclebind.OracleIndex(data["image"])
+    assert len(index) == meta["n"] and index.ndim == meta["ndim"] and index.dtype == meta["dtype"]
+    keys, distances, counts, visited, computed = index.search(data["queries"], meta["k"], dtype=meta["dtype"],
+                                                              expansion=meta["expansion"], lanes=0)
+    assert np.array_equal(counts, data["counts"])
+    found = np.arange(meta["k"])[None, :] < counts[:, None]
+    if meta["dtype"] in ("i8", "b1") and meta["metric"] != "cos":
+        # integer-valued distances: everything is exact, ties included (container semantics restated literally)
+        assert np.array_equal(keys, data["keys"])
+        assert util.same_float_bits(distances, data["distances"])
+        assert np.array_equal(visited, data["visited"]) and np.array_equal(computed, data["computed"])
+    else:
+        tolerance = 2e-3 if meta["dtype"] == "f16" else 1e-5
+        reference = np.where(found, data["distances"], 0)
+        assert np.all(np.abs(np.where(found, distances, 0) - reference) <= tolerance * np.maximum(1, np.abs(reference)))
+        assert ((keys == data["keys"]) | ~found).mean() > 0.99
+    assert np.all(keys[~found] == 0) and np.all(np.isnan(distances[~found]))  # padding of index.hpp:2707-2722
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_oracle_exact_search(path):
+    data, meta = load(path)
+    index = oraclebind.OracleIndex(data["image"])
+    keys, distances, counts, *_ = index.search(data["queries"], meta["k"], dtype=meta["dtype"], exact=True)
+    assert np.array_equal(counts, data["exact_counts"])
+    if meta["dtype"] in ("i8", "b1") and meta["metric"] != "cos":
+        assert np.array_equal(keys, data["exact_keys"]) and util.same_float_bits(distances, data["exact_distances"])
+    else:
+        assert (keys == data["exact_keys"]).mean() > 0.99
+
+
+def test_summation_layouts_agree_within_tolerance():
+    """`lanes = G` (the kernels' layout) only reorders float additions: same neighbours, tiny distance differences."""
+    data, meta = load(os.path.join(GOLDEN, "cos_f16_96.npz"))
+    index = oraclebind.OracleIndex(data["image"])
+    base = index.search(data["queries"], meta["k"], dtype="f16", expansion=64, lanes=0)
+    for lanes in (1, 2, 4, 8):
+        other = index.search(data["queries"], meta["k"], dtype="f16", expansion=64, lanes=lanes)
+        assert (other[0] == base[0]).mean() > 0.99
+        assert np.nanmax(np.abs(other[1] - base[1])) < 1e-3
+
+
+def test_known_answer_vectors():
+    kat = json.load(open(os.path.join(GOLDEN, "kat.json")))
+    for case in kat["distance"]:
+        dtype = util.NP_DTYPE[case["dtype"]]
+        a, b = np.array(case["a"], dtype=dtype), np.array(case["b"], dtype=dtype)
+        for lanes in (0, 1):
+            d = oraclebind.distance(a, b, case["metric"], case["dtype"], case["ndim"], lanes)
+            assert abs(d - case["expected"]) <= case["tolerance"], case["source"]
+
+
+def test_merge_into_places_later_equals_first():
+    """search_result_t::merge_into (index.hpp:2650-2670): lower_bound ⇒ a later-merged equal distance goes BEFORE."""
+    keys = np.zeros(4, dtype=np.uint64)
+    dists = np.zeros(4, dtype=np.float32)
+    count = oraclebind.merge_into(keys, dists, 0, np.array([1, 2, 3]), np.array([1.0, 2.0, 3.0]), 3)
+    count = oraclebind.merge_into(keys, dists, count, np.array([7, 8]), np.array([2.0, 2.0]), 2)
+    assert count == 4
+    assert keys.tolist() == [1, 8, 7, 2] and dists.tolist() == [1.0, 2.0, 2.0, 2.0]

@@ -404,9 +404,16 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
     // nothing to unroll
     const std::uint32_t chunks_per_lane = view_.chunks / lanes_;
     std::uint32_t variant_request = tuning.variant ? tuning.variant : (std::uint32_t)env_size("USEARCH_AMD_VARIANT", 0);
-    int variant = variant_request ? (int)variant_request - 1 : chunks_per_lane >= 8 ? variant_u8_w3_k : variant_u4_w4_k;
-    if (lanes_ < 8 || variant < 0 || variant > variant_u12_w2_k)
-        variant = variant_u4_w4_k;
+    int variant = variant_u4_w4_k;
+    if (lanes_ == 8 && chunks_per_lane >= 8) {
+        // measured on 1M x 768 f16 (profiles/): with room for ≥ 12 waves per CU the 8-deep build wins, once LDS caps the
+        // CU at ~8 waves the 12-deep build (a whole row per round trip) does
+        std::uint64_t heaps = scratch_layout(ef <= 512 ? 0 : ef, std::max<std::uint32_t>(512, ef * 3 + 256), 0).total;
+        const bool lds_bound = lds_budget / ((query_lds + heaps + 1023) / 1024 * 1024) < 12;
+        variant = chunks_per_lane >= 12 && lds_bound ? variant_u12_w2_k : variant_u8_w3_k;
+    }
+    if (variant_request && variant_request - 1 <= (std::uint32_t)variant_u12_w2_k && lanes_ == 8)
+        variant = (int)variant_request - 1;
     const std::uint32_t variant_waves_per_cu = 4u * (std::uint32_t)variant_waves(variant);
     const std::uint32_t waves_cap = tuning.waves_per_cu ? tuning.waves_per_cu
                                                         : (std::uint32_t)env_size("USEARCH_AMD_WAVES_PER_CU", 16);

@@ -317,9 +317,11 @@ template <int epl_ak, bool global_ak> struct top_gt {
 #pragma unroll
             for (int i = 0; i < epl_ak; ++i) {
                 const std::uint32_t g = lane_id() * epl_ak + i;
+                const float distance = d[i];       // copy the vector ELEMENTS out first: bit-casting `d[i]` itself
+                const std::uint32_t slot = s[i];   // reads element 0 of the vector
                 if (g < wanted) {
-                    keys[g] = g < found ? ix.keys[s[i]] : 0;
-                    bits[g] = g < found ? __builtin_bit_cast(std::uint32_t, d[i]) : signaling_nan_bits_k;
+                    keys[g] = g < found ? ix.keys[slot] : 0;
+                    bits[g] = g < found ? __builtin_bit_cast(std::uint32_t, distance) : signaling_nan_bits_k;
                 }
             }
             for (std::uint32_t g = 64 * epl_ak + lane_id(); g < wanted; g += 64) // wanted beyond capacity: padding only
@@ -804,9 +806,8 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
  */
 enum kernel_variant_t : int {
     variant_u4_w4_k = 0,  ///< 4 loads in flight, ≤ 128 VGPRs: 16 waves per CU
-    variant_u8_w4_k = 1,  ///< 8 loads in flight, ≤ 128 VGPRs
-    variant_u8_w3_k = 2,  ///< 8 loads in flight, ≤ 168 VGPRs: 12 waves per CU
-    variant_u12_w2_k = 3, ///< 12 loads in flight (a whole 768-d f16 row per lane group), ≤ 256 VGPRs: 8 waves per CU
+    variant_u8_w3_k = 1,  ///< 8 loads in flight, ≤ 168 VGPRs: 12 waves per CU (8 loads under 128 VGPRs spills: measured 2× slower)
+    variant_u12_w2_k = 2, ///< 12 loads in flight (a whole 768-d f16 row per lane group), ≤ 256 VGPRs: 8 waves per CU
 };
 constexpr int variant_unroll(int v) { return v == variant_u4_w4_k ? 4 : v == variant_u12_w2_k ? 12 : 8; }
 constexpr int variant_waves(int v) { return v == variant_u12_w2_k ? 2 : v == variant_u8_w3_k ? 3 : 4; }
