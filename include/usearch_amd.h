@@ -131,6 +131,26 @@ USEARCH_AMD_EXPORT void usearch_amd_search_many_device(usearch_amd_snapshot_t sn
                                                        usearch_amd_stats_t* stats, usearch_amd_error_t* error);
 
 /**
+ *  Exchange step of SHARDED search: merges per-shard results `distances/keys[shards][queries][wanted]`,
+ *  `counts[shards][queries]` (device pointers, e.g. the output of an RCCL all-gather of every rank's
+ *  `usearch_amd_search_many_device` results) into `[queries][wanted]`, reproducing `search_result_t::merge_into`
+ *  (index.hpp:2650-2670) applied to shards 0…P-1 in order — what `Indexes.search` does per query (python/lib.cpp:321-402).
+ *  `stream` is a `hipStream_t` (NULL = default); returns after it has drained.
+ */
+USEARCH_AMD_EXPORT void usearch_amd_merge_many_device(usearch_amd_distance_t const* distances,
+                                                      usearch_amd_key_t const* keys, uint64_t const* counts,
+                                                      size_t shards, size_t queries_count, size_t wanted,
+                                                      usearch_amd_distance_t* out_distances,
+                                                      usearch_amd_key_t* out_keys, uint64_t* out_counts, void* stream,
+                                                      usearch_amd_error_t* error);
+/** Same with host buffers (staged through the current device). */
+USEARCH_AMD_EXPORT void usearch_amd_merge_many(usearch_amd_distance_t const* distances, usearch_amd_key_t const* keys,
+                                               uint64_t const* counts, size_t shards, size_t queries_count,
+                                               size_t wanted, usearch_amd_distance_t* out_distances,
+                                               usearch_amd_key_t* out_keys, uint64_t* out_counts,
+                                               usearch_amd_error_t* error);
+
+/**
  *  Telemetry of the most recent search on this snapshot: out[q] = {peak frontier size, visited-set size} for the first
  *  `queries_count` queries — what DESIGN.md's scratch sizing is derived from.
  */

@@ -229,6 +229,56 @@ void usearch_amd_search_many_device(usearch_amd_snapshot_t snapshot, void const*
     stats_to_c(s, stats);
 }
 
+void usearch_amd_merge_many_device(usearch_amd_distance_t const* distances, usearch_amd_key_t const* keys,
+                                   uint64_t const* counts, size_t shards, size_t queries_count, size_t wanted,
+                                   usearch_amd_distance_t* out_distances, usearch_amd_key_t* out_keys,
+                                   uint64_t* out_counts, void* stream, usearch_amd_error_t* error) {
+    if (const char* e = merge_shards_device(distances, keys, counts, shards, queries_count, wanted, out_distances,
+                                            out_keys, out_counts, static_cast<hipStream_t>(stream)))
+        fail(error, e);
+}
+
+void usearch_amd_merge_many(usearch_amd_distance_t const* distances, usearch_amd_key_t const* keys,
+                            uint64_t const* counts, size_t shards, size_t queries_count, size_t wanted,
+                            usearch_amd_distance_t* out_distances, usearch_amd_key_t* out_keys, uint64_t* out_counts,
+                            usearch_amd_error_t* error) {
+    const size_t cells = shards * queries_count * wanted, rows = shards * queries_count;
+    if (!cells)
+        return;
+    float *d_distances = nullptr, *d_out_distances = nullptr;
+    uint64_t *d_keys = nullptr, *d_counts = nullptr, *d_out_keys = nullptr, *d_out_counts = nullptr;
+    hipError_t e = hipSuccess;
+    auto check = [&](hipError_t r) {
+        if (e == hipSuccess)
+            e = r;
+    };
+    check(hipMalloc((void**)&d_distances, cells * 4));
+    check(hipMalloc((void**)&d_keys, cells * 8));
+    check(hipMalloc((void**)&d_counts, rows * 8));
+    check(hipMalloc((void**)&d_out_distances, queries_count * wanted * 4));
+    check(hipMalloc((void**)&d_out_keys, queries_count * wanted * 8));
+    check(hipMalloc((void**)&d_out_counts, queries_count * 8));
+    if (e == hipSuccess) {
+        check(hipMemcpy(d_distances, distances, cells * 4, hipMemcpyHostToDevice));
+        check(hipMemcpy(d_keys, keys, cells * 8, hipMemcpyHostToDevice));
+        check(hipMemcpy(d_counts, counts, rows * 8, hipMemcpyHostToDevice));
+    }
+    if (e == hipSuccess) {
+        if (const char* message = merge_shards_device(d_distances, d_keys, d_counts, shards, queries_count, wanted,
+                                                      d_out_distances, d_out_keys, d_out_counts, nullptr))
+            fail(error, message);
+        check(hipMemcpy(out_distances, d_out_distances, queries_count * wanted * 4, hipMemcpyDeviceToHost));
+        check(hipMemcpy(out_keys, d_out_keys, queries_count * wanted * 8, hipMemcpyDeviceToHost));
+        check(hipMemcpy(out_counts, d_out_counts, queries_count * 8, hipMemcpyDeviceToHost));
+    }
+    for (void* p : {(void*)d_distances, (void*)d_keys, (void*)d_counts, (void*)d_out_distances, (void*)d_out_keys,
+                    (void*)d_out_counts})
+        if (p)
+            (void)hipFree(p);
+    if (e != hipSuccess)
+        fail(error, hipGetErrorString(e));
+}
+
 void usearch_amd_last_peaks(usearch_amd_snapshot_t snapshot, uint32_t* out, size_t queries_count,
                             usearch_amd_error_t* error) {
     if (const char* e = as_snapshot(snapshot)->last_peaks(out, queries_count))

@@ -155,6 +155,12 @@ struct distances_params_t {
     std::uint32_t count;
     float* out;
 };
+/// Exchange step of sharded search (merge.hip): [shards][queries][wanted] per-shard results → [queries][wanted], device
+/// pointers, `merge_into` tie rule with shards merged in index order. Returns after the stream has drained.
+const char* merge_shards_device(const float* distances, const std::uint64_t* keys, const std::uint64_t* counts,
+                                std::size_t shards, std::size_t queries, std::size_t wanted, float* out_distances,
+                                std::uint64_t* out_keys, std::uint64_t* out_counts, hipStream_t stream);
+
 /// Is there a HIP kernel for this (metric, scalar) pair?
 bool kernel_available(metric_kind_t metric, scalar_kind_t scalar);
 

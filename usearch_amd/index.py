@@ -49,7 +49,7 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_scalar_kind",
     "usearch_amd_snapshot_metric_kind", "usearch_amd_snapshot_lanes_per_row", "usearch_amd_search_many",
     "usearch_amd_search_many_device", "usearch_amd_last_peaks", "usearch_amd_distances",
-    "usearch_amd_last_distances_ms",
+    "usearch_amd_last_distances_ms", "usearch_amd_merge_many", "usearch_amd_merge_many_device",
     "usearch_amd_test_containers", "usearch_amd_cast",
 ]
 
@@ -87,6 +87,8 @@ def library() -> C.CDLL:
                                                  C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.POINTER(Tuning), C.c_int,
                                                  C.POINTER(Stats), err_p]
+    L.usearch_amd_merge_many_device.argtypes = [C.c_void_p] * 3 + [C.c_size_t] * 3 + [C.c_void_p] * 4 + [err_p]
+    L.usearch_amd_merge_many.argtypes = [C.c_void_p] * 3 + [C.c_size_t] * 3 + [C.c_void_p] * 3 + [err_p]
     L.usearch_amd_last_peaks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, err_p]
     L.usearch_amd_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, err_p]
@@ -322,6 +324,32 @@ class Index:
                                         _pointer(slots), slots.shape[1], _pointer(out), C.byref(err))
         _raise(err, "usearch_amd_distances")
         return out
+
+
+def merge_many(distances: np.ndarray, keys: np.ndarray, counts: np.ndarray):
+    """Host-buffer form of the shard merge: [P, Q, k] distances/keys + [P, Q] counts → ([Q, k] keys, distances, [Q] counts)."""
+    distances = np.ascontiguousarray(distances, dtype=np.float32)
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    counts = np.ascontiguousarray(counts, dtype=np.uint64)
+    shards, queries, wanted = distances.shape
+    out_d = np.zeros((queries, wanted), dtype=np.float32)
+    out_k = np.zeros((queries, wanted), dtype=np.uint64)
+    out_c = np.zeros(queries, dtype=np.uint64)
+    err = C.c_char_p()
+    library().usearch_amd_merge_many(_pointer(distances), _pointer(keys), _pointer(counts), shards, queries, wanted,
+                                     _pointer(out_d), _pointer(out_k), _pointer(out_c), C.byref(err))
+    _raise(err, "usearch_amd_merge_many")
+    return out_k, out_d, out_c
+
+
+def merge_many_device(distances_ptr: int, keys_ptr: int, counts_ptr: int, shards: int, queries: int, wanted: int,
+                      out_distances_ptr: int, out_keys_ptr: int, out_counts_ptr: int, stream: int = 0) -> None:
+    err = C.c_char_p()
+    library().usearch_amd_merge_many_device(C.c_void_p(distances_ptr), C.c_void_p(keys_ptr), C.c_void_p(counts_ptr),
+                                            shards, queries, wanted, C.c_void_p(out_distances_ptr),
+                                            C.c_void_p(out_keys_ptr), C.c_void_p(out_counts_ptr), C.c_void_p(stream),
+                                            C.byref(err))
+    _raise(err, "usearch_amd_merge_many_device")
 
 
 def device_count() -> int:
