@@ -13,7 +13,7 @@
  *  (c/usearch.h:371-374 → c/lib.cpp:398-411 → index_dense.hpp:2053-2085 → index.hpp:3016-3075) for a whole batch of
  *  queries per call — the loop the reference leaves to its callers (cpp/bench.cpp:352-377, python/lib.cpp:261-319).
  *
- *  The reference-compatible 38 `usearch_*` entry points are declared in `include/usearch.h`.
+ *  The reference-compatible 38 `usearch_*` entry points are declared in `include/usearch_c_dropin.h`.
  */
 #ifndef USEARCH_AMD_H
 #define USEARCH_AMD_H
@@ -129,6 +129,31 @@ USEARCH_AMD_EXPORT void usearch_amd_search_many_device(usearch_amd_snapshot_t sn
                                                        uint64_t* visited, uint64_t* computed, void* stream,
                                                        usearch_amd_tuning_t const* tuning, int timed,
                                                        usearch_amd_stats_t* stats, usearch_amd_error_t* error);
+
+/**
+ *  EXACT (brute-force) batched search over a snapshot — `usearch_search` on an index searched with `exact = true`
+ *  (index_dense.hpp:767-772, index.hpp:3046-3049, 4252-4268): every stored vector is measured, the `count` best under
+ *  (distance ascending, later slot first among equals) are returned, tombstones skipped. Host buffers; queries in any
+ *  scalar kind. `kernel_ms` (may be NULL) receives the HIP-event time of the scan kernel. Also the recall ground truth.
+ */
+USEARCH_AMD_EXPORT void usearch_amd_exact_search_many(usearch_amd_snapshot_t snapshot, void const* queries,
+                                                      int query_kind, size_t queries_count, size_t queries_stride,
+                                                      size_t wanted, usearch_amd_key_t* keys,
+                                                      usearch_amd_distance_t* distances, uint64_t* counts,
+                                                      float* kernel_ms, usearch_amd_error_t* error);
+
+/**
+ *  Exact search of a raw host dataset — `usearch_exact_search` (c/usearch.h:467-474, c/lib.cpp:468-501): keys are row
+ *  offsets of `dataset`. `metric_kind` / `scalar_kind` use the C enumerators of c/usearch.h:40-62. Ties between equal
+ *  distances (unspecified in the reference: `std::partial_sort` by distance) resolve to the later row first.
+ */
+USEARCH_AMD_EXPORT void usearch_amd_exact_search_dataset(void const* dataset, size_t dataset_count,
+                                                         size_t dataset_stride, void const* queries,
+                                                         size_t queries_count, size_t queries_stride, int scalar_kind,
+                                                         size_t dimensions, int metric_kind, size_t wanted,
+                                                         usearch_amd_key_t* keys, size_t keys_stride,
+                                                         usearch_amd_distance_t* distances, size_t distances_stride,
+                                                         usearch_amd_error_t* error);
 
 /**
  *  Exchange step of SHARDED search: merges per-shard results `distances/keys[shards][queries][wanted]`,

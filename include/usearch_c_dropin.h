@@ -1,0 +1,156 @@
+/**
+ *  include/usearch_c_dropin.h — the reference's C99 ABI as exported by THIS repository's drop-in `libusearch_c.so`.
+ *
+ *  Same 38 symbols, signatures, enum values and error convention as `/root/reference/c/usearch.h:116-481`
+ *  (implemented there by c/lib.cpp): a program or binding linked against the reference's `libusearch_c` (Go:
+ *  golang/lib.go:29-30, C#: csharp/src/Cloud.Unum.USearch/NativeMethods.cs:16, plain C: c/test.c) links against this
+ *  library unchanged. What differs is WHO does the work:
+ *
+ *    search path   `usearch_search`, `usearch_exact_search` and the additive batched `usearch_search_many` run on the
+ *                  MI355X through an HBM snapshot of the index (include/usearch_amd.h). The snapshot is taken lazily
+ *                  at the first search after a change and dropped by every mutating call.
+ *    the rest      index construction and mutation (`usearch_add`, `_remove`, `_rename`, `_reserve`, `_clear`,
+ *                  `_change_metric*`, `_filtered_search` with its host callback, `_distance`) are FORWARDED to the
+ *                  reference's own library, loaded at run time from `$USEARCH_AMD_REFERENCE_LIBRARY`. Without it the
+ *                  drop-in still opens, inspects, saves and searches existing `.usearch` files natively and the
+ *                  forwarded calls fail with an error string (never silently).
+ *
+ *  Errors: the callee stores a pointer to a static NUL-terminated string in `*error` on failure and leaves it untouched
+ *  on success (c/usearch.h:24-28).
+ */
+#ifndef USEARCH_AMD_DROPIN_USEARCH_H
+#define USEARCH_AMD_DROPIN_USEARCH_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef USEARCH_EXPORT
+#define USEARCH_EXPORT __attribute__((visibility("default")))
+#endif
+
+typedef void* usearch_index_t;       /* c/usearch.h:20 */
+typedef uint64_t usearch_key_t;      /* c/usearch.h:21 */
+typedef float usearch_distance_t;    /* c/usearch.h:22 */
+typedef char const* usearch_error_t; /* c/usearch.h:28 */
+typedef usearch_distance_t (*usearch_metric_t)(void const*, void const*); /* c/usearch.h:34 */
+
+typedef enum usearch_metric_kind_t { /* c/usearch.h:40-52 */
+    usearch_metric_unknown_k = 0,
+    usearch_metric_cos_k = 1,
+    usearch_metric_ip_k = 2,
+    usearch_metric_l2sq_k = 3,
+    usearch_metric_haversine_k = 4,
+    usearch_metric_divergence_k = 5,
+    usearch_metric_pearson_k = 6,
+    usearch_metric_jaccard_k = 7,
+    usearch_metric_hamming_k = 8,
+    usearch_metric_tanimoto_k = 9,
+    usearch_metric_sorensen_k = 10,
+} usearch_metric_kind_t;
+
+typedef enum usearch_scalar_kind_t { /* c/usearch.h:54-62 */
+    usearch_scalar_unknown_k = 0,
+    usearch_scalar_f32_k = 1,
+    usearch_scalar_f64_k = 2,
+    usearch_scalar_f16_k = 3,
+    usearch_scalar_i8_k = 4,
+    usearch_scalar_b1_k = 5,
+    usearch_scalar_bf16_k = 6,
+} usearch_scalar_kind_t;
+
+typedef struct usearch_init_options_t { /* c/usearch.h:64-110, same member order */
+    usearch_metric_kind_t metric_kind;
+    usearch_metric_t metric;
+    usearch_scalar_kind_t quantization;
+    size_t dimensions;
+    size_t connectivity;
+    size_t expansion_add;
+    size_t expansion_search;
+    bool multi;
+} usearch_init_options_t;
+
+/* ---- the 38 reference entry points (c/usearch.h line of each in the comment) ---- */
+USEARCH_EXPORT char const* usearch_version(void);                                                             /* 116 */
+USEARCH_EXPORT usearch_index_t usearch_init(usearch_init_options_t* options, usearch_error_t* error);         /* 124 */
+USEARCH_EXPORT void usearch_free(usearch_index_t index, usearch_error_t* error);                              /* 131 */
+USEARCH_EXPORT size_t usearch_memory_usage(usearch_index_t index, usearch_error_t* error);                    /* 139 */
+USEARCH_EXPORT char const* usearch_hardware_acceleration(usearch_index_t index, usearch_error_t* error);      /* 147 */
+USEARCH_EXPORT size_t usearch_serialized_length(usearch_index_t index, usearch_error_t* error);               /* 154 */
+USEARCH_EXPORT void usearch_save(usearch_index_t index, char const* path, usearch_error_t* error);            /* 162 */
+USEARCH_EXPORT void usearch_load(usearch_index_t index, char const* path, usearch_error_t* error);            /* 170 */
+USEARCH_EXPORT void usearch_view(usearch_index_t index, char const* path, usearch_error_t* error);            /* 178 */
+USEARCH_EXPORT void usearch_metadata(char const* path, usearch_init_options_t* options, usearch_error_t* error); /* 186 */
+USEARCH_EXPORT void usearch_save_buffer(usearch_index_t index, void* buffer, size_t length, usearch_error_t* error); /* 195 */
+USEARCH_EXPORT void usearch_load_buffer(usearch_index_t index, void const* buffer, size_t length, usearch_error_t* error); /* 204 */
+USEARCH_EXPORT void usearch_view_buffer(usearch_index_t index, void const* buffer, size_t length, usearch_error_t* error); /* 214 */
+USEARCH_EXPORT void usearch_metadata_buffer(void const* buffer, size_t length, usearch_init_options_t* options,
+                                            usearch_error_t* error);                                          /* 223 */
+USEARCH_EXPORT size_t usearch_size(usearch_index_t index, usearch_error_t* error);                            /* 231 */
+USEARCH_EXPORT size_t usearch_capacity(usearch_index_t index, usearch_error_t* error);                        /* 238 */
+USEARCH_EXPORT size_t usearch_dimensions(usearch_index_t index, usearch_error_t* error);                      /* 245 */
+USEARCH_EXPORT size_t usearch_connectivity(usearch_index_t index, usearch_error_t* error);                    /* 252 */
+USEARCH_EXPORT void usearch_reserve(usearch_index_t index, size_t capacity, usearch_error_t* error);          /* 260 */
+USEARCH_EXPORT size_t usearch_expansion_add(usearch_index_t index, usearch_error_t* error);                   /* 268 */
+USEARCH_EXPORT size_t usearch_expansion_search(usearch_index_t index, usearch_error_t* error);                /* 276 */
+USEARCH_EXPORT void usearch_change_expansion_add(usearch_index_t index, size_t expansion, usearch_error_t* error);    /* 284 */
+USEARCH_EXPORT void usearch_change_expansion_search(usearch_index_t index, size_t expansion, usearch_error_t* error); /* 292 */
+USEARCH_EXPORT void usearch_change_threads_add(usearch_index_t index, size_t threads, usearch_error_t* error);        /* 300 */
+USEARCH_EXPORT void usearch_change_threads_search(usearch_index_t index, size_t threads, usearch_error_t* error);     /* 308 */
+USEARCH_EXPORT void usearch_change_metric_kind(usearch_index_t index, usearch_metric_kind_t kind, usearch_error_t* error); /* 316 */
+USEARCH_EXPORT void usearch_change_metric(usearch_index_t index, usearch_metric_t metric, void* state,
+                                          usearch_metric_kind_t kind, usearch_error_t* error);                /* 327 */
+USEARCH_EXPORT void usearch_add(usearch_index_t index, usearch_key_t key, void const* vector,
+                                usearch_scalar_kind_t vector_kind, usearch_error_t* error);                   /* 338 */
+USEARCH_EXPORT bool usearch_contains(usearch_index_t index, usearch_key_t key, usearch_error_t* error);       /* 349 */
+USEARCH_EXPORT size_t usearch_count(usearch_index_t index, usearch_key_t key, usearch_error_t* error);        /* 358 */
+USEARCH_EXPORT size_t usearch_search(usearch_index_t index, void const* query, usearch_scalar_kind_t query_kind,
+                                     size_t count, usearch_key_t* keys, usearch_distance_t* distances,
+                                     usearch_error_t* error);                                                 /* 371 */
+USEARCH_EXPORT size_t usearch_filtered_search(usearch_index_t index, void const* query,
+                                              usearch_scalar_kind_t query_kind, size_t count,
+                                              int (*filter)(usearch_key_t key, void* filter_state), void* filter_state,
+                                              usearch_key_t* keys, usearch_distance_t* distances,
+                                              usearch_error_t* error);                                        /* 391 */
+USEARCH_EXPORT size_t usearch_get(usearch_index_t index, usearch_key_t key, size_t count, void* vector,
+                                  usearch_scalar_kind_t vector_kind, usearch_error_t* error);                 /* 407 */
+USEARCH_EXPORT size_t usearch_remove(usearch_index_t index, usearch_key_t key, usearch_error_t* error);       /* 418 */
+USEARCH_EXPORT size_t usearch_rename(usearch_index_t index, usearch_key_t from, usearch_key_t to,
+                                     usearch_error_t* error);                                                 /* 428 */
+USEARCH_EXPORT usearch_distance_t usearch_distance(void const* vector_first, void const* vector_second,
+                                                   usearch_scalar_kind_t scalar_kind, size_t dimensions,
+                                                   usearch_metric_kind_t metric_kind, usearch_error_t* error); /* 441 */
+USEARCH_EXPORT void usearch_exact_search(void const* dataset, size_t dataset_size, size_t dataset_stride,
+                                         void const* queries, size_t queries_size, size_t queries_stride,
+                                         usearch_scalar_kind_t scalar_kind, size_t dimensions,
+                                         usearch_metric_kind_t metric_kind, size_t count, size_t threads,
+                                         usearch_key_t* keys, size_t keys_stride, usearch_distance_t* distances,
+                                         size_t distances_stride, usearch_error_t* error);                    /* 467 */
+USEARCH_EXPORT void usearch_clear(usearch_index_t index, usearch_error_t* error);                             /* 481 */
+
+/* ---- additive, MI355X-specific ---- */
+
+/**
+ *  `usearch_search` for `queries_count` queries in one call — the batch the reference leaves to its callers
+ *  (cpp/bench.cpp:352-377, python/lib.cpp:261-319). Strides in bytes; `keys`/`distances` rows hold exactly `count`
+ *  cells (unused: key 0 / signalling NaN); `counts`, `visited_members`, `computed_distances` may be NULL, the last two
+ *  receive the batch totals of `search_result_t::{visited_members, computed_distances}` (index.hpp:3071-3072).
+ */
+USEARCH_EXPORT void usearch_search_many(usearch_index_t index, void const* queries, usearch_scalar_kind_t query_kind,
+                                        size_t queries_count, size_t queries_stride, size_t count,
+                                        usearch_key_t* keys, size_t keys_stride, usearch_distance_t* distances,
+                                        size_t distances_stride, size_t* counts, size_t* visited_members,
+                                        size_t* computed_distances, usearch_error_t* error);
+/** Takes (or refreshes) the HBM snapshot now instead of at the next search. */
+USEARCH_EXPORT void usearch_gpu_sync(usearch_index_t index, usearch_error_t* error);
+/** Drops the HBM snapshot (it is re-taken on demand). */
+USEARCH_EXPORT void usearch_gpu_release(usearch_index_t index, usearch_error_t* error);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

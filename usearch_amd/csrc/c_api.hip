@@ -43,6 +43,22 @@ int scalar_to_c(scalar_kind_t kind) {
     }
 }
 
+metric_kind_t metric_from_c(int kind) { // c/lib.cpp:26-42
+    switch (kind) {
+    case 1: return metric_cos_k;
+    case 2: return metric_ip_k;
+    case 3: return metric_l2sq_k;
+    case 4: return metric_haversine_k;
+    case 5: return metric_divergence_k;
+    case 6: return metric_pearson_k;
+    case 7: return metric_jaccard_k;
+    case 8: return metric_hamming_k;
+    case 9: return metric_tanimoto_k;
+    case 10: return metric_sorensen_k;
+    default: return metric_unknown_k;
+    }
+}
+
 int metric_to_c(metric_kind_t kind) { // c/usearch.h:40-52 ← c/lib.cpp:26-59
     switch (kind) {
     case metric_cos_k: return 1;
@@ -227,6 +243,30 @@ void usearch_amd_search_many_device(usearch_amd_snapshot_t snapshot, void const*
                                                              &s, timed != 0))
         return fail(error, e);
     stats_to_c(s, stats);
+}
+
+void usearch_amd_exact_search_many(usearch_amd_snapshot_t snapshot, void const* queries, int query_kind,
+                                   size_t queries_count, size_t queries_stride, size_t wanted, usearch_amd_key_t* keys,
+                                   usearch_amd_distance_t* distances, uint64_t* counts, float* kernel_ms,
+                                   usearch_amd_error_t* error) {
+    const scalar_kind_t kind = scalar_from_c(query_kind);
+    if (kind == scalar_unknown_k)
+        return fail(error, "Unknown scalar kind!");
+    if (const char* e = as_snapshot(snapshot)->exact_host(queries, kind, queries_count, queries_stride, wanted, keys,
+                                                          distances, counts, kernel_ms))
+        fail(error, e);
+}
+
+void usearch_amd_exact_search_dataset(void const* dataset, size_t dataset_count, size_t dataset_stride,
+                                      void const* queries, size_t queries_count, size_t queries_stride,
+                                      int scalar_kind, size_t dimensions, int metric_kind, size_t wanted,
+                                      usearch_amd_key_t* keys, size_t keys_stride, usearch_amd_distance_t* distances,
+                                      size_t distances_stride, usearch_amd_error_t* error) {
+    if (const char* e = exact_search_dataset_host(metric_from_c(metric_kind), scalar_from_c(scalar_kind), dimensions,
+                                                  dataset, dataset_count, dataset_stride, queries, queries_count,
+                                                  queries_stride, wanted, keys, keys_stride, distances,
+                                                  distances_stride))
+        fail(error, e);
 }
 
 void usearch_amd_merge_many_device(usearch_amd_distance_t const* distances, usearch_amd_key_t const* keys,

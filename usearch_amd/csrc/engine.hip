@@ -59,6 +59,36 @@ template <typename body_at> void parallel_ranges(std::uint64_t n, body_at&& body
 
 } // namespace
 
+void row_geometry(std::size_t bytes, std::uint32_t& lanes, std::uint32_t& row_stride) {
+    // lanes per row: the smallest power of two covering the row's 16-byte chunks, at most 8 (= one 128-byte line per load)
+    const std::uint32_t raw_chunks = std::max<std::uint32_t>(1, (std::uint32_t)((bytes + 15) / 16));
+    lanes = std::min<std::uint32_t>(8, pow2_ceil(raw_chunks));
+    row_stride = (std::uint32_t)((bytes + 16 * lanes - 1) / (16 * lanes) * (16 * lanes));
+}
+
+/// Re-pitches `rows` host rows of `bytes` bytes (source stride `source_stride`) into device rows of `row_stride` bytes.
+static const char* upload_rows(std::uint8_t* device, std::uint32_t row_stride, const std::uint8_t* source,
+                               std::size_t source_stride, std::size_t bytes, std::uint64_t rows) {
+    if (!rows)
+        return nullptr;
+    if (row_stride == bytes && source_stride == bytes) {
+        UA_HIP(hipMemcpy(device, source, (std::size_t)rows * bytes, hipMemcpyHostToDevice));
+        return nullptr;
+    }
+    const std::uint64_t block_rows = std::max<std::uint64_t>(1, ((std::uint64_t)256 << 20) / row_stride);
+    std::vector<std::uint8_t> block((std::size_t)std::min<std::uint64_t>(block_rows, rows) * row_stride);
+    for (std::uint64_t first = 0; first < rows; first += block_rows) {
+        const std::uint64_t count = std::min<std::uint64_t>(block_rows, rows - first);
+        std::memset(block.data(), 0, (std::size_t)count * row_stride);
+        parallel_ranges(count, [&](std::uint64_t begin, std::uint64_t end) {
+            for (std::uint64_t r = begin; r < end; ++r)
+                std::memcpy(block.data() + r * row_stride, source + (first + r) * source_stride, bytes);
+        });
+        UA_HIP(hipMemcpy(device + first * row_stride, block.data(), (std::size_t)count * row_stride, hipMemcpyHostToDevice));
+    }
+    return nullptr;
+}
+
 bool kernel_available(metric_kind_t metric, scalar_kind_t scalar) {
     const bool numeric_metric = metric == metric_ip_k || metric == metric_cos_k || metric == metric_l2sq_k;
     switch (scalar) {
@@ -109,10 +139,8 @@ const char* snapshot_t::build(const image_t& image, int device) {
     const std::uint32_t m = (std::uint32_t)image.connectivity, m0 = (std::uint32_t)image.connectivity_base;
     const std::uint32_t bpv = (std::uint32_t)image.cols;
 
-    // lanes per row: the smallest power of two covering the row's 16-byte chunks, at most 8 (= one 128-byte line per load)
-    const std::uint32_t raw_chunks = std::max<std::uint32_t>(1, (bpv + 15) / 16);
-    lanes_ = std::min<std::uint32_t>(8, pow2_ceil(raw_chunks));
-    const std::uint32_t row_stride = (bpv + 16 * lanes_ - 1) / (16 * lanes_) * (16 * lanes_);
+    std::uint32_t row_stride = 0;
+    row_geometry(bpv, lanes_, row_stride);
 
     // ---- host pass 1: tape offsets (sequential prefix) and the number of upper-level lists
     std::vector<std::uint64_t> offsets(n + 1);
@@ -213,23 +241,8 @@ const char* snapshot_t::build(const image_t& image, int device) {
     UA_HIP(allocate(&d_upper_, upper.size() * 4));
     UA_HIP(allocate(&d_keys_, keys.size() * 8));
     if (n) {
-        if (row_stride == bpv) {
-            UA_HIP(hipMemcpy(d_vectors_, image.vectors, vectors_bytes, hipMemcpyHostToDevice));
-        } else {
-            // re-pitch on the host in bounded blocks (rows zero padded to the stride), then plain copies
-            const std::uint64_t block_rows = std::max<std::uint64_t>(1, ((std::uint64_t)256 << 20) / row_stride);
-            std::vector<std::uint8_t> block((std::size_t)std::min<std::uint64_t>(block_rows, n) * row_stride);
-            for (std::uint64_t first = 0; first < n; first += block_rows) {
-                const std::uint64_t rows = std::min<std::uint64_t>(block_rows, n - first);
-                std::memset(block.data(), 0, (std::size_t)rows * row_stride);
-                parallel_ranges(rows, [&](std::uint64_t begin, std::uint64_t end) {
-                    for (std::uint64_t r = begin; r < end; ++r)
-                        std::memcpy(block.data() + r * row_stride, image.vectors + (first + r) * bpv, bpv);
-                });
-                UA_HIP(hipMemcpy(static_cast<std::uint8_t*>(d_vectors_) + first * row_stride, block.data(),
-                                 (std::size_t)rows * row_stride, hipMemcpyHostToDevice));
-            }
-        }
+        if (const char* e = upload_rows(static_cast<std::uint8_t*>(d_vectors_), row_stride, image.vectors, bpv, bpv, n))
+            return e;
         UA_HIP(hipMemcpy(d_nbr0_, nbr0.data(), nbr0.size() * 4, hipMemcpyHostToDevice));
         UA_HIP(hipMemcpy(d_upper_ref_, upper_ref.data(), upper_ref.size() * 4, hipMemcpyHostToDevice));
         UA_HIP(hipMemcpy(d_keys_, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
@@ -673,6 +686,216 @@ const char* snapshot_t::search_host(const void* queries, scalar_kind_t query_kin
         UA_HIP(hipMemcpy(visited, d_visited, count * 8, hipMemcpyDeviceToHost));
     if (computed)
         UA_HIP(hipMemcpy(computed, d_computed, count * 8, hipMemcpyDeviceToHost));
+    return nullptr;
+}
+
+static hipError_t launch_exact(metric_kind_t metric, scalar_kind_t scalar, const exact_params_t& p,
+                               const snapshot_view_t& view) {
+#define UA_PAIR(m, sc, name)                                                                                           \
+    if (metric == m && scalar == sc)                                                                                   \
+        return launch_exact_##name(p, view);
+    UA_PAIR(metric_ip_k, scalar_f32_k, ip_f32)
+    UA_PAIR(metric_cos_k, scalar_f32_k, cos_f32)
+    UA_PAIR(metric_l2sq_k, scalar_f32_k, l2sq_f32)
+    UA_PAIR(metric_ip_k, scalar_f16_k, ip_f16)
+    UA_PAIR(metric_cos_k, scalar_f16_k, cos_f16)
+    UA_PAIR(metric_l2sq_k, scalar_f16_k, l2sq_f16)
+    UA_PAIR(metric_ip_k, scalar_i8_k, ip_i8)
+    UA_PAIR(metric_cos_k, scalar_i8_k, cos_i8)
+    UA_PAIR(metric_l2sq_k, scalar_i8_k, l2sq_i8)
+    UA_PAIR(metric_hamming_k, scalar_b1x8_k, hamming_b1)
+#undef UA_PAIR
+    return hipErrorInvalidValue;
+}
+
+const char* exact_search_device(metric_kind_t metric, scalar_kind_t scalar, std::uint32_t lanes,
+                                const snapshot_view_t& view, const void* queries, std::size_t count,
+                                std::size_t stride_bytes, std::size_t wanted, bool map_keys, std::uint64_t* keys,
+                                float* distances, std::uint64_t* counts, hipStream_t stream, float* kernel_ms) {
+    if (kernel_ms)
+        *kernel_ms = 0.f;
+    if (!count || !wanted)
+        return nullptr;
+    if (count >= none_slot_k || wanted > 4096)
+        return "Batch is too large";
+    if (view.size == 0) {
+        const std::uint64_t cells = std::max<std::uint64_t>(count * wanted, count);
+        hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, keys,
+                           reinterpret_cast<std::uint32_t*>(distances), counts, counts, counts, (std::uint64_t)count,
+                           (std::uint64_t)wanted);
+        UA_HIP(hipGetLastError());
+        UA_HIP(hipStreamSynchronize(stream));
+        return nullptr;
+    }
+    // enough (query, partition) waves to fill the chip, few enough candidates for one merge wave per query
+    std::uint64_t partitions = std::max<std::uint64_t>(1, (8192 + count - 1) / count);
+    partitions = std::min<std::uint64_t>(partitions, std::max<std::uint64_t>(1, 8192 / wanted));
+    partitions = std::min<std::uint64_t>(partitions, std::max<std::uint64_t>(1, view.size / 256));
+    partitions = std::min<std::uint64_t>(partitions, 65535);
+    const std::uint64_t rows_per_partition = (view.size + partitions - 1) / partitions;
+    partitions = (view.size + rows_per_partition - 1) / rows_per_partition;
+
+    float* partial_distances = nullptr;
+    std::uint64_t *partial_keys = nullptr, *partial_counts = nullptr;
+    hipEvent_t begin = nullptr, end = nullptr;
+    const char* error = nullptr;
+    hipError_t e = hipMalloc((void**)&partial_distances, partitions * count * wanted * 4);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&partial_keys, partitions * count * wanted * 8);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&partial_counts, partitions * count * 8);
+    if (e == hipSuccess && kernel_ms) {
+        e = hipEventCreate(&begin);
+        if (e == hipSuccess)
+            e = hipEventCreate(&end);
+        if (e == hipSuccess)
+            e = hipEventRecord(begin, stream);
+    }
+    if (e == hipSuccess) {
+        exact_params_t p{};
+        p.lanes = lanes;
+        p.lds_bytes = view.chunks * (scalar == scalar_f16_k ? 32u : 16u) + 512 + (std::uint32_t)wanted * 8 + 16;
+        p.stream = stream;
+        p.queries = static_cast<const std::uint8_t*>(queries);
+        p.query_stride = stride_bytes;
+        p.query_count = (std::uint32_t)count;
+        p.wanted = (std::uint32_t)wanted;
+        p.partitions = (std::uint32_t)partitions;
+        p.rows_per_partition = rows_per_partition;
+        p.map_keys = map_keys ? 1u : 0u;
+        p.out_distances = partial_distances;
+        p.out_keys = partial_keys;
+        p.out_counts = partial_counts;
+        e = launch_exact(metric, scalar, p, view);
+    }
+    if (e == hipSuccess && kernel_ms)
+        e = hipEventRecord(end, stream);
+    if (e == hipSuccess)
+        error = merge_shards_device(partial_distances, partial_keys, partial_counts, partitions, count, wanted, distances,
+                                    keys, counts, stream, false);
+    if (e == hipSuccess && !error && kernel_ms)
+        e = hipEventElapsedTime(kernel_ms, begin, end);
+    if (e != hipSuccess)
+        error = hip_message(e);
+    for (void* p : {(void*)partial_distances, (void*)partial_keys, (void*)partial_counts})
+        if (p)
+            (void)hipFree(p);
+    if (begin)
+        (void)hipEventDestroy(begin);
+    if (end)
+        (void)hipEventDestroy(end);
+    return error;
+}
+
+const char* snapshot_t::exact_device(const void* queries, std::size_t count, std::size_t stride_bytes,
+                                     std::size_t wanted, std::uint64_t* keys, float* distances, std::uint64_t* counts,
+                                     hipStream_t stream, float* kernel_ms) {
+    std::lock_guard<std::mutex> lock(mutex_);
+    UA_HIP(hipSetDevice(device_));
+    return exact_search_device(metric_, scalar_, lanes_, view_, queries, count, stride_bytes, wanted, true, keys,
+                               distances, counts, stream ? stream : stream_, kernel_ms);
+}
+
+const char* snapshot_t::exact_host(const void* queries, scalar_kind_t query_kind, std::size_t count,
+                                   std::size_t stride_bytes, std::size_t wanted, std::uint64_t* keys, float* distances,
+                                   std::uint64_t* counts, float* kernel_ms) {
+    if (!count || !wanted)
+        return nullptr;
+    const std::size_t bpv = view_.bytes_per_vector, dims = view_.dimensions;
+    std::vector<std::uint8_t> dense(count * bpv, 0);
+    const std::uint8_t* source = static_cast<const std::uint8_t*>(queries);
+    if (query_kind != scalar_ && bytes_per_vector(query_kind, dims) == 0)
+        return "Unsupported query scalar kind";
+    parallel_ranges(count, [&](std::uint64_t begin, std::uint64_t end) {
+        for (std::uint64_t q = begin; q < end; ++q)
+            if (!cast_vector(query_kind, scalar_, source + q * stride_bytes, dims, dense.data() + q * bpv))
+                std::memcpy(dense.data() + q * bpv, source + q * stride_bytes, bpv);
+    });
+    std::lock_guard<std::mutex> host_lock(host_mutex_);
+    UA_HIP(hipSetDevice(device_));
+    if (const char* e = ensure_staging(bpv, count, wanted))
+        return e;
+    auto pad = [](std::size_t b) { return (b + 255) & ~(std::size_t)255; };
+    std::uint8_t* d_queries = d_stage_;
+    std::uint64_t* d_keys = reinterpret_cast<std::uint64_t*>(d_queries + pad(bpv * count));
+    float* d_distances = reinterpret_cast<float*>(reinterpret_cast<std::uint8_t*>(d_keys) + pad(count * wanted * 8));
+    std::uint64_t* d_counts = reinterpret_cast<std::uint64_t*>(reinterpret_cast<std::uint8_t*>(d_distances) + pad(count * wanted * 4));
+    UA_HIP(hipMemcpy(d_queries, dense.data(), bpv * count, hipMemcpyHostToDevice));
+    if (const char* e = exact_device(d_queries, count, bpv, wanted, d_keys, d_distances, d_counts, nullptr, kernel_ms))
+        return e;
+    if (keys)
+        UA_HIP(hipMemcpy(keys, d_keys, count * wanted * 8, hipMemcpyDeviceToHost));
+    if (distances)
+        UA_HIP(hipMemcpy(distances, d_distances, count * wanted * 4, hipMemcpyDeviceToHost));
+    if (counts)
+        UA_HIP(hipMemcpy(counts, d_counts, count * 8, hipMemcpyDeviceToHost));
+    return nullptr;
+}
+
+const char* exact_search_dataset_host(metric_kind_t metric, scalar_kind_t scalar, std::size_t dimensions,
+                                      const void* dataset, std::size_t dataset_count, std::size_t dataset_stride,
+                                      const void* queries, std::size_t queries_count, std::size_t queries_stride,
+                                      std::size_t wanted, std::uint64_t* keys, std::size_t keys_stride,
+                                      float* distances, std::size_t distances_stride) {
+    if (!kernel_available(metric, scalar))
+        return "No MI355X kernel for this metric / scalar kind combination";
+    if (!queries_count || !wanted)
+        return nullptr;
+    if (dataset_count >= none_slot_k)
+        return "Dataset is too large for 32-bit offsets";
+    const std::size_t bpv = bytes_per_vector(scalar, dimensions);
+    if (dataset_stride < bpv || queries_stride < bpv)
+        return "Stride is smaller than one vector";
+    std::uint32_t lanes = 1, row_stride = 16;
+    row_geometry(bpv, lanes, row_stride);
+    std::uint8_t *d_rows = nullptr, *d_queries = nullptr;
+    std::uint64_t *d_keys = nullptr, *d_counts = nullptr;
+    float* d_distances = nullptr;
+    const char* error = nullptr;
+    hipError_t e = hipMalloc((void**)&d_rows, std::max<std::size_t>(dataset_count * row_stride, 16));
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&d_queries, queries_count * bpv);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&d_keys, queries_count * wanted * 8);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&d_distances, queries_count * wanted * 4);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&d_counts, queries_count * 8);
+    if (e == hipSuccess)
+        error = upload_rows(d_rows, row_stride, static_cast<const std::uint8_t*>(dataset), dataset_stride, bpv, dataset_count);
+    if (e == hipSuccess && !error)
+        error = upload_rows(d_queries, (std::uint32_t)bpv, static_cast<const std::uint8_t*>(queries), queries_stride, bpv,
+                            queries_count);
+    std::vector<std::uint64_t> host_keys(queries_count * wanted);
+    std::vector<float> host_distances(queries_count * wanted);
+    if (e == hipSuccess && !error) {
+        snapshot_view_t view{};
+        view.vectors = d_rows;
+        view.size = dataset_count;
+        view.row_stride = row_stride;
+        view.chunks = row_stride / 16;
+        view.bytes_per_vector = (std::uint32_t)bpv;
+        view.dimensions = (std::uint32_t)dimensions;
+        error = exact_search_device(metric, scalar, lanes, view, d_queries, queries_count, bpv, wanted, false, d_keys,
+                                    d_distances, d_counts, nullptr, nullptr);
+    }
+    if (e == hipSuccess && !error) {
+        e = hipMemcpy(host_keys.data(), d_keys, host_keys.size() * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            e = hipMemcpy(host_distances.data(), d_distances, host_distances.size() * 4, hipMemcpyDeviceToHost);
+    }
+    for (void* p : {(void*)d_rows, (void*)d_queries, (void*)d_keys, (void*)d_distances, (void*)d_counts})
+        if (p)
+            (void)hipFree(p);
+    if (e != hipSuccess)
+        return hip_message(e);
+    if (error)
+        return error;
+    for (std::size_t q = 0; q < queries_count; ++q) {
+        std::memcpy(reinterpret_cast<std::uint8_t*>(keys) + q * keys_stride, host_keys.data() + q * wanted, wanted * 8);
+        std::memcpy(reinterpret_cast<std::uint8_t*>(distances) + q * distances_stride, host_distances.data() + q * wanted,
+                    wanted * 4);
+    }
     return nullptr;
 }
 

@@ -76,6 +76,16 @@ class snapshot_t {
     /// Telemetry of the last search_device call: per query {peak frontier size, visited-set size}; host copy.
     const char* last_peaks(std::uint32_t* out, std::size_t queries);
 
+    /// `search(…, exact = true)` for a batch (index_dense.hpp:767-772 with exact, index.hpp:3046-3049): device buffers,
+    /// queries in the storage kind.
+    const char* exact_device(const void* queries, std::size_t count, std::size_t stride_bytes, std::size_t wanted,
+                             std::uint64_t* keys, float* distances, std::uint64_t* counts, hipStream_t stream,
+                             float* kernel_ms);
+    /// Same with host buffers and any query scalar kind.
+    const char* exact_host(const void* queries, scalar_kind_t query_kind, std::size_t count, std::size_t stride_bytes,
+                           std::size_t wanted, std::uint64_t* keys, float* distances, std::uint64_t* counts,
+                           float* kernel_ms);
+
     /// out[q][j] = metric(query q, stored row slots[q][j]); host buffers, queries in storage kind.
     const char* distances_host(const void* queries, std::size_t count, std::size_t stride_bytes,
                                const std::uint32_t* slots, std::size_t slots_per_query, float* out);
@@ -131,7 +141,8 @@ struct launch_params_t {
 };
 #define USEARCH_AMD_DECLARE_LAUNCHERS(name)                                                                            \
     hipError_t launch_search_##name(const launch_params_t&, const snapshot_view_t&, const search_args_t&);            \
-    hipError_t launch_distances_##name(const struct distances_params_t&, const snapshot_view_t&);
+    hipError_t launch_distances_##name(const struct distances_params_t&, const snapshot_view_t&);                     \
+    hipError_t launch_exact_##name(const struct exact_params_t&, const snapshot_view_t&);
 USEARCH_AMD_DECLARE_LAUNCHERS(ip_f32)
 USEARCH_AMD_DECLARE_LAUNCHERS(cos_f32)
 USEARCH_AMD_DECLARE_LAUNCHERS(l2sq_f32)
@@ -155,11 +166,48 @@ struct distances_params_t {
     std::uint32_t count;
     float* out;
 };
+struct exact_params_t {
+    std::uint32_t lanes;
+    std::uint32_t lds_bytes;
+    hipStream_t stream;
+    const std::uint8_t* queries;
+    std::uint64_t query_stride;
+    std::uint32_t query_count;
+    std::uint32_t wanted;
+    std::uint32_t partitions;
+    std::uint64_t rows_per_partition;
+    std::uint32_t map_keys;
+    float* out_distances;      ///< [partitions][queries][wanted]
+    std::uint64_t* out_keys;
+    std::uint64_t* out_counts; ///< [partitions][queries]
+};
+
+/**
+ *  Exact search over the rows of `view` (device pointers everywhere; `view` needs `vectors`, sizes and — when
+ *  `map_keys` — `keys`): partition scan + fold. Results as `index_gt::search_exact_` gives them: top-`wanted` under
+ *  (distance ↑, slot ↓), padded with key 0 / signalling NaN.
+ */
+const char* exact_search_device(metric_kind_t metric, scalar_kind_t scalar, std::uint32_t lanes,
+                                const snapshot_view_t& view, const void* queries, std::size_t count,
+                                std::size_t stride_bytes, std::size_t wanted, bool map_keys, std::uint64_t* keys,
+                                float* distances, std::uint64_t* counts, hipStream_t stream, float* kernel_ms);
+
+/// Host-buffer exact search of a raw dataset — `usearch_exact_search` (c/usearch.h:467-474): keys are dataset offsets.
+const char* exact_search_dataset_host(metric_kind_t metric, scalar_kind_t scalar, std::size_t dimensions,
+                                      const void* dataset, std::size_t dataset_count, std::size_t dataset_stride,
+                                      const void* queries, std::size_t queries_count, std::size_t queries_stride,
+                                      std::size_t wanted, std::uint64_t* keys, std::size_t keys_stride,
+                                      float* distances, std::size_t distances_stride);
+
+/// Lanes per stored row and padded row stride for rows of `bytes` bytes (the summation layout of DESIGN.md §3.3).
+void row_geometry(std::size_t bytes, std::uint32_t& lanes, std::uint32_t& row_stride);
+
 /// Exchange step of sharded search (merge.hip): [shards][queries][wanted] per-shard results → [queries][wanted], device
 /// pointers, `merge_into` tie rule with shards merged in index order. Returns after the stream has drained.
 const char* merge_shards_device(const float* distances, const std::uint64_t* keys, const std::uint64_t* counts,
                                 std::size_t shards, std::size_t queries, std::size_t wanted, float* out_distances,
-                                std::uint64_t* out_keys, std::uint64_t* out_counts, hipStream_t stream);
+                                std::uint64_t* out_keys, std::uint64_t* out_counts, hipStream_t stream,
+                                bool later_position_first = true);
 
 /// Is there a HIP kernel for this (metric, scalar) pair?
 bool kernel_available(metric_kind_t metric, scalar_kind_t scalar);

@@ -871,4 +871,74 @@ __global__ __launch_bounds__(64) void distances_kernel(const snapshot_view_t ix,
     }
 }
 
+/**
+ *  Exact (brute-force) search — `index_gt::search_exact_` (index.hpp:4252-4268): every allowed slot in slot order goes
+ *  through `top.insert(candidate, wanted)`. One wave owns one (query, row-partition) pair and streams its rows with the
+ *  same `measure_rows` loop as the graph search (so distances are bit-identical to it); partitions are folded afterwards
+ *  by `merge_kernel`. Because inserts use lower_bound, the result is the top-`wanted` under (distance ↑, slot ↓).
+ *  out_* are laid out [partition][query][wanted]; `map_keys` = 0 returns slots (dataset offsets) instead of keys.
+ */
+template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak>
+__global__ __launch_bounds__(64) void exact_kernel(const snapshot_view_t ix, const std::uint8_t* queries,
+                                                   std::uint64_t query_stride, std::uint32_t query_count,
+                                                   std::uint32_t wanted, std::uint64_t rows_per_partition,
+                                                   std::uint32_t map_keys, float* out_distances,
+                                                   std::uint64_t* out_keys, std::uint64_t* out_counts) {
+    extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
+    const std::uint32_t lane = lane_id();
+    const std::uint32_t q = blockIdx.x, partition = blockIdx.y;
+    std::uint8_t* query_lds = lds;
+    std::uint32_t* cand_slots = reinterpret_cast<std::uint32_t*>(lds + query_lds_bytes<scalar_ak>(ix.chunks));
+    float* cand_distances = reinterpret_cast<float*>(cand_slots + 64);
+    top_gt<0, false> top;
+    top.reset(reinterpret_cast<cand_t*>(cand_distances + 64));
+    const query_norm_t a2 = stage_query<metric_ak, scalar_ak, lanes_ak>(ix, queries + (std::uint64_t)q * query_stride, query_lds);
+
+    const std::uint64_t first = (std::uint64_t)partition * rows_per_partition;
+    const std::uint64_t last = first + rows_per_partition < ix.size ? first + rows_per_partition : ix.size;
+    float worst = 0.f;
+    for (std::uint64_t base = first; base < last; base += 64) {
+        const std::uint32_t span = last - base < 64 ? (std::uint32_t)(last - base) : 64u;
+        // the `allow` predicate of index_dense.hpp:2071-2081 (tombstones), then compaction in slot order
+        const std::uint32_t slot = (std::uint32_t)base + lane;
+        const bool allowed = lane < span && (!ix.has_tombstones || ix.keys[slot] != free_key_k);
+        const std::uint64_t allowed_mask = ballot(allowed);
+        const std::uint32_t count = popcount64(allowed_mask);
+        if (!count)
+            continue;
+        if (allowed)
+            cand_slots[rank_below(allowed_mask, lane)] = slot;
+        wave_sync<false>();
+        measure_rows<metric_ak, scalar_ak, lanes_ak, unroll_ak, false>(ix, query_lds, a2, cand_slots, cand_distances, count);
+        const float mine = lane < count ? cand_distances[lane] : 0.f;
+        const std::uint32_t mine_slot = lane < count ? cand_slots[lane] : 0u;
+        // an element equal to a full buffer's worst still gets in (lower_bound lands before it): only `>` is hopeless
+        std::uint64_t pending = ballot(lane < count && (top.size < wanted || !(mine > worst)));
+        while (pending) {
+            const std::uint32_t i = (std::uint32_t)__ffsll((long long)pending) - 1;
+            pending &= pending - 1;
+            const float d = read_lane_f32(mine, i);
+            if (top.size == wanted && d > worst)
+                continue;
+            if (top.insert(d, read_lane_u32(mine_slot, i), wanted))
+                worst = top.worst();
+        }
+        wave_sync<false>();
+    }
+    const std::uint64_t row = ((std::uint64_t)partition * query_count + q) * wanted;
+    for (std::uint32_t i = lane; i < wanted; i += 64) {
+        std::uint64_t key = 0;
+        std::uint32_t bits = signaling_nan_bits_k;
+        if (i < top.size) {
+            const cand_t c = top.cells[i];
+            key = map_keys ? ix.keys[cand_slot(c)] : (std::uint64_t)cand_slot(c);
+            bits = (std::uint32_t)c;
+        }
+        out_keys[row + i] = key;
+        reinterpret_cast<std::uint32_t*>(out_distances)[row + i] = bits;
+    }
+    if (lane == 0)
+        out_counts[(std::uint64_t)partition * query_count + q] = top.size;
+}
+
 } // namespace usearch_amd

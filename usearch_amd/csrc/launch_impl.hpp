@@ -86,6 +86,26 @@ hipError_t launch_distances_metric(const distances_params_t& p, const snapshot_v
     }
 }
 
+template <int metric_ak, int scalar_ak, int lanes_ak>
+hipError_t launch_exact_one(const exact_params_t& p, const snapshot_view_t& view) {
+    auto kernel = exact_kernel<metric_ak, scalar_ak, lanes_ak, lanes_ak == 8 ? 8 : 4>;
+    hipLaunchKernelGGL(kernel, dim3(p.query_count, p.partitions), dim3(64), p.lds_bytes, p.stream, view, p.queries,
+                       p.query_stride, p.query_count, p.wanted, p.rows_per_partition, p.map_keys, p.out_distances,
+                       p.out_keys, p.out_counts);
+    return hipGetLastError();
+}
+
+template <int metric_ak, int scalar_ak>
+hipError_t launch_exact_metric(const exact_params_t& p, const snapshot_view_t& view) {
+    switch (p.lanes) {
+    case 1: return launch_exact_one<metric_ak, scalar_ak, 1>(p, view);
+    case 2: return launch_exact_one<metric_ak, scalar_ak, 2>(p, view);
+    case 4: return launch_exact_one<metric_ak, scalar_ak, 4>(p, view);
+    case 8: return launch_exact_one<metric_ak, scalar_ak, 8>(p, view);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 /// One (metric, scalar) pair per translation unit, so that the pairs compile in parallel.
 #define USEARCH_AMD_DEFINE_LAUNCHERS(name, metric_kind, scalar_kind)                                                   \
     hipError_t launch_search_##name(const launch_params_t& p, const snapshot_view_t& view,                             \
@@ -94,6 +114,9 @@ hipError_t launch_distances_metric(const distances_params_t& p, const snapshot_v
     }                                                                                                                  \
     hipError_t launch_distances_##name(const distances_params_t& p, const snapshot_view_t& view) {                     \
         return launch_distances_metric<metric_kind, scalar_kind>(p, view);                                             \
+    }                                                                                                                  \
+    hipError_t launch_exact_##name(const exact_params_t& p, const snapshot_view_t& view) {                             \
+        return launch_exact_metric<metric_kind, scalar_kind>(p, view);                                                 \
     }
 
 } // namespace usearch_amd

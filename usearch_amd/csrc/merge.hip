@@ -17,7 +17,8 @@ namespace usearch_amd {
 
 __global__ __launch_bounds__(64) void merge_kernel(const float* distances, const std::uint64_t* keys,
                                                    const std::uint64_t* counts, std::uint32_t shards,
-                                                   std::uint32_t queries, std::uint32_t wanted, float* out_distances,
+                                                   std::uint32_t queries, std::uint32_t wanted,
+                                                   std::uint32_t later_position_first, float* out_distances,
                                                    std::uint64_t* out_keys, std::uint64_t* out_counts) {
     extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
     const std::uint32_t q = blockIdx.x, lane = threadIdx.x;
@@ -45,7 +46,11 @@ __global__ __launch_bounds__(64) void merge_kernel(const float* distances, const
         std::uint32_t rank = 0; // how many candidates precede this one
         for (std::uint32_t j = 0; j < total; ++j) {
             const float other = pool_d[j];
-            rank += pool_valid[j] && (other < mine || (other == mine && j > i)); // j > i ⇔ later shard, or later position
+            // ties: a later shard always goes first; inside one shard the later position does under `merge_into`, the
+            // earlier one when folding the slot-ordered partitions of an exact search
+            const bool same_shard = j / wanted == i / wanted;
+            const bool tie_wins = same_shard && !later_position_first ? j < i : j > i;
+            rank += pool_valid[j] && (other < mine || (other == mine && tie_wins));
         }
         if (rank < wanted) {
             const std::uint32_t shard = i / wanted, position = i % wanted;
@@ -63,15 +68,16 @@ __global__ __launch_bounds__(64) void merge_kernel(const float* distances, const
 
 const char* merge_shards_device(const float* distances, const std::uint64_t* keys, const std::uint64_t* counts,
                                 std::size_t shards, std::size_t queries, std::size_t wanted, float* out_distances,
-                                std::uint64_t* out_keys, std::uint64_t* out_counts, hipStream_t stream) {
+                                std::uint64_t* out_keys, std::uint64_t* out_counts, hipStream_t stream,
+                                bool later_position_first) {
     if (!queries || !wanted || !shards)
         return nullptr;
     const std::size_t lds = shards * wanted * 8;
     if (lds > 64 * 1024)
         return "Too many candidates per query for the merge kernel";
     hipLaunchKernelGGL(merge_kernel, dim3((unsigned)queries), dim3(64), lds, stream, distances, keys, counts,
-                       (std::uint32_t)shards, (std::uint32_t)queries, (std::uint32_t)wanted, out_distances, out_keys,
-                       out_counts);
+                       (std::uint32_t)shards, (std::uint32_t)queries, (std::uint32_t)wanted,
+                       later_position_first ? 1u : 0u, out_distances, out_keys, out_counts);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipStreamSynchronize(stream);

@@ -50,6 +50,7 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_snapshot_metric_kind", "usearch_amd_snapshot_lanes_per_row", "usearch_amd_search_many",
     "usearch_amd_search_many_device", "usearch_amd_last_peaks", "usearch_amd_distances",
     "usearch_amd_last_distances_ms", "usearch_amd_merge_many", "usearch_amd_merge_many_device",
+    "usearch_amd_exact_search_many", "usearch_amd_exact_search_dataset",
     "usearch_amd_test_containers", "usearch_amd_cast",
 ]
 
@@ -89,6 +90,11 @@ def library() -> C.CDLL:
                                                  C.POINTER(Stats), err_p]
     L.usearch_amd_merge_many_device.argtypes = [C.c_void_p] * 3 + [C.c_size_t] * 3 + [C.c_void_p] * 4 + [err_p]
     L.usearch_amd_merge_many.argtypes = [C.c_void_p] * 3 + [C.c_size_t] * 3 + [C.c_void_p] * 3 + [err_p]
+    L.usearch_amd_exact_search_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), err_p]
+    L.usearch_amd_exact_search_dataset.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                   C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p,
+                                                   C.c_size_t, C.c_void_p, C.c_size_t, err_p]
     L.usearch_amd_last_peaks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, err_p]
     L.usearch_amd_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, err_p]
@@ -245,7 +251,8 @@ class Index:
 
     # ---- search
     def search(self, vectors: np.ndarray, count: int = 10, *, expansion: Optional[int] = None,
-               dtype: Optional[str] = None, tuning: Optional[Tuning] = None) -> Union[Matches, BatchMatches]:
+               dtype: Optional[str] = None, tuning: Optional[Tuning] = None,
+               exact: bool = False) -> Union[Matches, BatchMatches]:
         """`Index.search` (index.py:700-748): one vector → `Matches`, a 2-D batch → `BatchMatches`.
 
         `dtype` names the scalar kind of `vectors` when numpy cannot tell (bit-packed `b1` rows are `uint8`);
@@ -274,6 +281,17 @@ class Index:
         computed = np.zeros(q, dtype=np.uint64)
         stats = Stats()
         err = C.c_char_p()
+        if exact:  # brute force over every stored vector (Index.search(..., exact=True), index.py:700-748)
+            kernel_ms = C.c_float()
+            library().usearch_amd_exact_search_many(self._handle, _pointer(vectors), SCALAR_KINDS[dtype], q,
+                                                    vectors.shape[1] * vectors.itemsize if q <= 1 else vectors.strides[0],
+                                                    count, _pointer(keys), _pointer(distances), _pointer(counts),
+                                                    C.byref(kernel_ms), C.byref(err))
+            _raise(err, "usearch_amd_exact_search_many")
+            stats.kernel_ms = kernel_ms.value
+            computed[:] = len(self)
+            batch = BatchMatches(keys, distances, counts, 0, int(computed.sum()), visited, computed, stats)
+            return batch[0] if single else batch
         ef = self.expansion_search if expansion is None else expansion
         library().usearch_amd_search_many(self._handle, _pointer(vectors), SCALAR_KINDS[dtype], q,
                                           vectors.shape[1] * vectors.itemsize if q <= 1 else vectors.strides[0],
@@ -324,6 +342,27 @@ class Index:
                                         _pointer(slots), slots.shape[1], _pointer(out), C.byref(err))
         _raise(err, "usearch_amd_distances")
         return out
+
+
+def exact_search(dataset: np.ndarray, queries: np.ndarray, count: int, metric: str = "cos",
+                 dtype: Optional[str] = None):
+    """`usearch.index.search(dataset, queries, count, exact=True)` (index.py:1608-1700) → (keys = row offsets [Q, k],
+    distances [Q, k]); both matrices in the same scalar kind, rows may be strided."""
+    dataset, queries = np.asarray(dataset), np.asarray(queries)
+    if dtype is None:
+        dtype = {np.dtype(np.float32): "f32", np.dtype(np.float16): "f16", np.dtype(np.int8): "i8",
+                 np.dtype(np.uint8): "b1"}[dataset.dtype]
+    ndim = dataset.shape[1] * 8 if dtype == "b1" else dataset.shape[1]
+    metric_kind = {name: kind for kind, name in METRIC_NAMES.items()}[metric]
+    keys = np.zeros((len(queries), count), dtype=np.uint64)
+    distances = np.zeros((len(queries), count), dtype=np.float32)
+    err = C.c_char_p()
+    library().usearch_amd_exact_search_dataset(_pointer(dataset), len(dataset), dataset.strides[0], _pointer(queries),
+                                               len(queries), queries.strides[0], SCALAR_KINDS[dtype], ndim,
+                                               metric_kind, count, _pointer(keys), keys.strides[0],
+                                               _pointer(distances), distances.strides[0], C.byref(err))
+    _raise(err, "usearch_amd_exact_search_dataset")
+    return keys, distances
 
 
 def merge_many(distances: np.ndarray, keys: np.ndarray, counts: np.ndarray):
