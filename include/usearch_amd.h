@@ -175,6 +175,50 @@ USEARCH_AMD_EXPORT void usearch_amd_merge_many(usearch_amd_distance_t const* dis
                                                usearch_amd_key_t* out_keys, uint64_t* out_counts,
                                                usearch_amd_error_t* error);
 
+/* ---- index construction on the device ------------------------------------------------------------------------------ */
+
+typedef void* usearch_amd_builder_t;
+
+/** Knobs of a build; zero-initialise for the reference's defaults (M = 16, M0 = 2·M, ef_construction = 128). */
+typedef struct usearch_amd_build_config_t {
+    uint32_t connectivity;      /**< M  (`usearch_init_options_t::connectivity`, c/usearch.h:90-95); 0 = 16 */
+    uint32_t connectivity_base; /**< M0; 0 = 2·M */
+    uint32_t expansion_add;     /**< ef_construction (`expansion_add`, c/usearch.h:97-101); 0 = 128 */
+    uint32_t batch_divisor;     /**< a batch holds at most (nodes linked so far) / divisor new nodes; 0 = 16 */
+    uint32_t max_batch;         /**< … and at most this many; 0 = 65536 */
+    uint32_t reserved;
+    uint64_t seed;              /**< level draw; 0 = a fixed default */
+} usearch_amd_build_config_t;
+
+typedef struct usearch_amd_build_stats_t {
+    uint64_t batches, passes;
+    uint64_t search_distances, search_hops;   /**< counters of the insertion searches (index.hpp:4011-4079) */
+    uint64_t select_distances, reverse_distances, repruned_lists, dropped_requests;
+    double seconds_total, seconds_search, seconds_link, seconds_upload;
+    uint32_t max_level, reserved;
+} usearch_amd_build_stats_t;
+
+/**
+ *  Builds an HNSW index over `count` vectors on `device` — the whole `usearch_add` loop (c/usearch.h:338-339;
+ *  cpp/bench.cpp:296-327) in one call: insertion search, `form_links_to_closest_` and `form_reverse_links_`
+ *  (index.hpp:2855-2863) run as batched gfx950 kernels. `vectors` holds rows of the storage `scalar_kind`, `stride`
+ *  bytes apart, in host memory or (`vectors_on_device != 0`) in HBM. `keys` (host) may be NULL: key = row number.
+ *  The result owns a searchable snapshot and can be serialized in the reference's format.
+ */
+USEARCH_AMD_EXPORT usearch_amd_builder_t usearch_amd_build(void const* vectors, size_t count, size_t stride,
+                                                           int scalar_kind, size_t dimensions, int metric_kind,
+                                                           usearch_amd_key_t const* keys,
+                                                           usearch_amd_build_config_t const* config, int device,
+                                                           int vectors_on_device, usearch_amd_error_t* error);
+USEARCH_AMD_EXPORT void usearch_amd_build_free(usearch_amd_builder_t builder, usearch_amd_error_t* error);
+/** The snapshot the build produced; owned by the builder, valid until `usearch_amd_build_free`. */
+USEARCH_AMD_EXPORT usearch_amd_snapshot_t usearch_amd_build_snapshot(usearch_amd_builder_t builder);
+/** `usearch_serialized_length` / `usearch_save_buffer` (c/usearch.h:154, 195): a v2 image the reference loads. */
+USEARCH_AMD_EXPORT size_t usearch_amd_build_serialized_length(usearch_amd_builder_t builder);
+USEARCH_AMD_EXPORT void usearch_amd_build_save_buffer(usearch_amd_builder_t builder, void* buffer, size_t length,
+                                                      usearch_amd_error_t* error);
+USEARCH_AMD_EXPORT void usearch_amd_build_stats(usearch_amd_builder_t builder, usearch_amd_build_stats_t* stats);
+
 /**
  *  Telemetry of the most recent search on this snapshot: out[q] = {peak frontier size, visited-set size} for the first
  *  `queries_count` queries — what DESIGN.md's scratch sizing is derived from.

@@ -11,6 +11,7 @@
 
 #include <new>
 
+#include "build.hpp"
 #include "casts.hpp"
 #include "engine.hpp"
 #include "kernels.hpp"
@@ -377,6 +378,66 @@ void usearch_amd_test_containers(uint32_t const* kinds, float const* keys, uint3
             (void)hipFree(p);
     if (e != hipSuccess)
         fail(error, hipGetErrorString(e));
+}
+
+usearch_amd_builder_t usearch_amd_build(void const* vectors, size_t count, size_t stride, int scalar_kind,
+                                        size_t dimensions, int metric_kind, usearch_amd_key_t const* keys,
+                                        usearch_amd_build_config_t const* config, int device, int vectors_on_device,
+                                        usearch_amd_error_t* error) {
+    build_config_t c;
+    if (config) {
+        if (config->connectivity)
+            c.connectivity = config->connectivity;
+        c.connectivity_base = config->connectivity_base;
+        if (config->expansion_add)
+            c.expansion_add = config->expansion_add;
+        if (config->batch_divisor)
+            c.batch_divisor = config->batch_divisor;
+        if (config->max_batch)
+            c.max_batch = config->max_batch;
+        if (config->seed)
+            c.seed = config->seed;
+    }
+    builder_t* builder = new (std::nothrow) builder_t();
+    if (!builder) {
+        fail(error, "Out of memory!");
+        return nullptr;
+    }
+    if (const char* e = builder->build(metric_from_c(metric_kind), scalar_from_c(scalar_kind), dimensions, vectors, count,
+                                       stride, vectors_on_device != 0, keys, c, device)) {
+        fail(error, e);
+        delete builder;
+        return nullptr;
+    }
+    return builder;
+}
+
+void usearch_amd_build_free(usearch_amd_builder_t builder, usearch_amd_error_t*) { delete static_cast<builder_t*>(builder); }
+
+usearch_amd_snapshot_t usearch_amd_build_snapshot(usearch_amd_builder_t builder) {
+    return &static_cast<builder_t*>(builder)->snapshot();
+}
+
+size_t usearch_amd_build_serialized_length(usearch_amd_builder_t builder) {
+    return static_cast<builder_t*>(builder)->serialized_length();
+}
+
+void usearch_amd_build_save_buffer(usearch_amd_builder_t builder, void* buffer, size_t length,
+                                   usearch_amd_error_t* error) {
+    if (const char* e = static_cast<builder_t*>(builder)->save_buffer(buffer, length))
+        fail(error, e);
+}
+
+void usearch_amd_build_stats(usearch_amd_builder_t builder, usearch_amd_build_stats_t* out) {
+    const build_stats_t& s = static_cast<builder_t*>(builder)->stats();
+    *out = usearch_amd_build_stats_t{};
+    out->batches = s.batches, out->passes = s.passes;
+    out->search_distances = s.search_distances, out->search_hops = s.search_hops;
+    out->select_distances = s.select_distances, out->reverse_distances = s.reverse_distances;
+    out->repruned_lists = s.repruned_lists, out->dropped_requests = s.dropped_requests;
+    out->seconds_total = s.seconds_total, out->seconds_search = s.seconds_search;
+    out->seconds_link = s.seconds_link, out->seconds_upload = s.seconds_upload;
+    out->max_level = s.max_level;
 }
 
 int usearch_amd_cast(int from_kind, int to_kind, void const* input, size_t dimensions, void* output) {

@@ -105,6 +105,10 @@ struct search_args_t {
     std::uint32_t next_cap;    ///< frontier heap capacity
     std::uint8_t* scratch;        ///< per-wave global slabs (visited hash, or everything in the fallback mode)
     std::uint64_t scratch_stride; ///< bytes per launched wave
+    // index construction reuses the search (search_to_insert_, index.hpp:4011-4079, is the same beam on any level):
+    const std::uint32_t* query_ids; ///< optional: query `q` is row query_ids[q] of `queries` (a stored vector); outputs stay at row q
+    std::uint32_t beam_level;       ///< level the beam runs on (0 for `search`); the greedy descent stops above it
+    std::uint32_t emit_slots;       ///< 1 = write slots instead of keys into `keys`
 };
 
 enum : std::uint32_t { status_done_k = 0, status_overflow_k = 1 };

@@ -11,53 +11,11 @@
 #include <thread>
 
 #include "casts.hpp"
+#include "host_util.hpp"
 #include "kernels.hpp"
 
 namespace usearch_amd {
 
-namespace {
-
-const char* hip_message(hipError_t e) { return hipGetErrorString(e); } // static strings owned by the runtime
-
-#define UA_HIP(call)                                                                                                   \
-    do {                                                                                                               \
-        hipError_t ua_error_ = (call);                                                                                 \
-        if (ua_error_ != hipSuccess)                                                                                   \
-            return hip_message(ua_error_);                                                                             \
-    } while (0)
-
-std::uint32_t pow2_ceil(std::uint32_t v) {
-    std::uint32_t p = 1;
-    while (p < v)
-        p <<= 1;
-    return p;
-}
-
-std::size_t env_size(const char* name, std::size_t fallback) {
-    const char* v = std::getenv(name);
-    return v && *v ? (std::size_t)std::strtoull(v, nullptr, 10) : fallback;
-}
-
-/// Runs `body(begin, end)` over [0, n) on the host's cores.
-template <typename body_at> void parallel_ranges(std::uint64_t n, body_at&& body) {
-    unsigned workers = std::thread::hardware_concurrency();
-    workers = std::max(1u, std::min(workers, 64u));
-    if (n < 4096 || workers == 1) {
-        body(0, n);
-        return;
-    }
-    std::vector<std::thread> pool;
-    const std::uint64_t step = (n + workers - 1) / workers;
-    for (unsigned w = 0; w < workers; ++w) {
-        const std::uint64_t begin = std::min<std::uint64_t>(n, w * step), end = std::min<std::uint64_t>(n, begin + step);
-        if (begin < end)
-            pool.emplace_back([=, &body] { body(begin, end); });
-    }
-    for (auto& t : pool)
-        t.join();
-}
-
-} // namespace
 
 void row_geometry(std::size_t bytes, std::uint32_t& lanes, std::uint32_t& row_stride) {
     // lanes per row: the smallest power of two covering the row's 16-byte chunks, at most 8 (= one 128-byte line per load)
@@ -67,7 +25,7 @@ void row_geometry(std::size_t bytes, std::uint32_t& lanes, std::uint32_t& row_st
 }
 
 /// Re-pitches `rows` host rows of `bytes` bytes (source stride `source_stride`) into device rows of `row_stride` bytes.
-static const char* upload_rows(std::uint8_t* device, std::uint32_t row_stride, const std::uint8_t* source,
+const char* upload_rows(std::uint8_t* device, std::uint32_t row_stride, const std::uint8_t* source,
                                std::size_t source_stride, std::size_t bytes, std::uint64_t rows) {
     if (!rows)
         return nullptr;
@@ -373,7 +331,7 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
                                       std::size_t wanted, std::size_t expansion, std::uint64_t* keys,
                                       float* distances, std::uint64_t* counts, std::uint64_t* visited,
                                       std::uint64_t* computed, hipStream_t stream, const search_tuning_t& tuning,
-                                      search_stats_t* stats, bool timed) {
+                                      search_stats_t* stats, bool timed, const search_extras_t* extras) {
     if (stats)
         *stats = search_stats_t{};
     if (!count || !wanted) // index.hpp:3025-3027: nothing wanted, nothing found
@@ -467,6 +425,11 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
     args.status = d_status_;
     args.queue = d_queue_;
     args.peaks = d_peaks_;
+    if (extras) {
+        args.query_ids = extras->query_ids;
+        args.beam_level = extras->beam_level;
+        args.emit_slots = extras->emit_slots ? 1u : 0u;
+    }
 
     launch_params_t params{};
     params.metric = metric_;

@@ -38,6 +38,13 @@ struct search_stats_t {
     std::uint32_t lds_bytes = 0;         ///< LDS per wave of the last launch
 };
 
+/// What index construction asks of the search on top of a plain query batch (see search_args_t).
+struct search_extras_t {
+    const std::uint32_t* query_ids = nullptr; ///< device: query q is row query_ids[q] of `queries`
+    std::uint32_t beam_level = 0;             ///< level the beam runs on
+    bool emit_slots = false;                  ///< slots instead of keys in the `keys` output
+};
+
 class snapshot_t {
   public:
     snapshot_t() = default;
@@ -65,7 +72,26 @@ class snapshot_t {
     const char* search_device(const void* queries, std::size_t count, std::size_t stride_bytes, std::size_t wanted,
                               std::size_t expansion, std::uint64_t* keys, float* distances, std::uint64_t* counts,
                               std::uint64_t* visited, std::uint64_t* computed, hipStream_t stream,
-                              const search_tuning_t& tuning, search_stats_t* stats, bool timed);
+                              const search_tuning_t& tuning, search_stats_t* stats, bool timed,
+                              const search_extras_t* extras = nullptr);
+
+    /**
+     *  Construction support (build.hip): allocates the HBM arrays of an index of `capacity` nodes whose levels are
+     *  already drawn, every list empty. `vectors` (host or device memory, `stride` bytes between rows) are re-pitched to
+     *  the row stride; `keys` may be null (key = slot). The graph arrays are then filled in place by the link kernels
+     *  while `set_frontier` tells the search how much of the graph exists.
+     */
+    const char* allocate_for_build(metric_kind_t metric, scalar_kind_t scalar, std::size_t dimensions,
+                                   std::uint64_t capacity, std::uint32_t m, std::uint32_t m0,
+                                   const std::int16_t* levels, const void* vectors, std::size_t stride,
+                                   bool vectors_on_device, const std::uint64_t* keys, int device);
+    void set_frontier(std::uint64_t size, std::uint32_t entry_slot, std::uint32_t max_level) {
+        view_.size = size, view_.entry_slot = entry_slot, view_.max_level = max_level;
+    }
+    std::uint32_t* mutable_nbr0() { return static_cast<std::uint32_t*>(d_nbr0_); }
+    std::uint32_t* mutable_upper() { return static_cast<std::uint32_t*>(d_upper_); }
+    hipStream_t stream() const { return stream_; }
+    int compute_units() const { return compute_units_; }
 
     /// Same with host buffers and a query scalar kind that may differ from the storage kind (cast first).
     const char* search_host(const void* queries, scalar_kind_t query_kind, std::size_t count, std::size_t stride_bytes,
@@ -142,7 +168,8 @@ struct launch_params_t {
 #define USEARCH_AMD_DECLARE_LAUNCHERS(name)                                                                            \
     hipError_t launch_search_##name(const launch_params_t&, const snapshot_view_t&, const search_args_t&);            \
     hipError_t launch_distances_##name(const struct distances_params_t&, const snapshot_view_t&);                     \
-    hipError_t launch_exact_##name(const struct exact_params_t&, const snapshot_view_t&);
+    hipError_t launch_exact_##name(const struct exact_params_t&, const snapshot_view_t&);                             \
+    hipError_t launch_build_##name(const struct build_params_t&, const snapshot_view_t&, const struct build_args_t&);
 USEARCH_AMD_DECLARE_LAUNCHERS(ip_f32)
 USEARCH_AMD_DECLARE_LAUNCHERS(cos_f32)
 USEARCH_AMD_DECLARE_LAUNCHERS(l2sq_f32)
@@ -153,6 +180,14 @@ USEARCH_AMD_DECLARE_LAUNCHERS(ip_i8)
 USEARCH_AMD_DECLARE_LAUNCHERS(cos_i8)
 USEARCH_AMD_DECLARE_LAUNCHERS(l2sq_i8)
 USEARCH_AMD_DECLARE_LAUNCHERS(hamming_b1)
+
+/// Launch shape of one construction linking kernel (build_kernels.hpp): `reverse` = 0 select, 1 reverse links.
+struct build_params_t {
+    std::uint32_t lanes;
+    std::uint32_t grid;
+    int reverse;
+    hipStream_t stream;
+};
 
 struct distances_params_t {
     metric_kind_t metric;

@@ -307,7 +307,7 @@ template <int epl_ak, bool global_ak> struct top_gt {
                 std::uint32_t distance_bits = signaling_nan_bits_k;
                 if (i < found) {
                     const cand_t c = scratch_gt<global_ak>::load(cells + i);
-                    key = ix.keys[cand_slot(c)];
+                    key = args.emit_slots ? (std::uint64_t)cand_slot(c) : ix.keys[cand_slot(c)];
                     distance_bits = (std::uint32_t)c;
                 }
                 keys[i] = key;
@@ -320,7 +320,7 @@ template <int epl_ak, bool global_ak> struct top_gt {
                 const float distance = d[i];       // copy the vector ELEMENTS out first: bit-casting `d[i]` itself
                 const std::uint32_t slot = s[i];   // reads element 0 of the vector
                 if (g < wanted) {
-                    keys[g] = g < found ? ix.keys[slot] : 0;
+                    keys[g] = g < found ? (args.emit_slots ? (std::uint64_t)slot : ix.keys[slot]) : 0;
                     bits[g] = g < found ? __builtin_bit_cast(std::uint32_t, distance) : signaling_nan_bits_k;
                 }
             }
@@ -537,26 +537,10 @@ UA_DEVICE void measure_rows(const snapshot_view_t& ix, const std::uint8_t* query
     wave_sync<global_ak>();
 }
 
-/// Copies query `q` into LDS (zero padded to the row stride; f16 widened to f32) and derives its norm.
+/// Query-side constant of the distance for the query already staged in LDS: Σa² in the row summation layout.
 template <int metric_ak, int scalar_ak, int lanes_ak>
-UA_DEVICE query_norm_t stage_query(const snapshot_view_t& ix, const std::uint8_t* query, std::uint8_t* query_lds) {
+UA_DEVICE query_norm_t staged_norm(const snapshot_view_t& ix, const std::uint8_t* query_lds) {
     const std::uint32_t lane = lane_id();
-    if constexpr (scalar_ak == scalar_f16_k) {
-        float* dst = reinterpret_cast<float*>(query_lds);
-        const std::uint32_t scalars = ix.chunks * 8;
-        for (std::uint32_t e = lane; e < scalars; e += 64) {
-            float value = 0.f;
-            if (e < ix.dimensions)
-                value = half_bits_to_float((std::uint32_t)query[2 * e] | ((std::uint32_t)query[2 * e + 1] << 8));
-            dst[e] = value;
-        }
-    } else {
-        const std::uint32_t bytes = ix.chunks * 16;
-        for (std::uint32_t b = lane; b < bytes; b += 64)
-            query_lds[b] = b < ix.bytes_per_vector ? query[b] : (std::uint8_t)0;
-    }
-    wave_sync<false>();
-
     query_norm_t a2;
     if constexpr ((scalar_ak == scalar_f32_k || scalar_ak == scalar_f16_k) && metric_ak == metric_cos_k) {
         // Σa² with the row layout: lane `sub` owns chunks sub, sub+G, …; every group computes the same value
@@ -588,6 +572,49 @@ UA_DEVICE query_norm_t stage_query(const snapshot_view_t& ix, const std::uint8_t
         a2.i = sum;
     }
     return a2;
+}
+
+/// Copies query `q` into LDS (zero padded to the row stride; f16 widened to f32) and derives its norm.
+template <int metric_ak, int scalar_ak, int lanes_ak>
+UA_DEVICE query_norm_t stage_query(const snapshot_view_t& ix, const std::uint8_t* query, std::uint8_t* query_lds) {
+    const std::uint32_t lane = lane_id();
+    if constexpr (scalar_ak == scalar_f16_k) {
+        float* dst = reinterpret_cast<float*>(query_lds);
+        const std::uint32_t scalars = ix.chunks * 8;
+        for (std::uint32_t e = lane; e < scalars; e += 64) {
+            float value = 0.f;
+            if (e < ix.dimensions)
+                value = half_bits_to_float((std::uint32_t)query[2 * e] | ((std::uint32_t)query[2 * e + 1] << 8));
+            dst[e] = value;
+        }
+    } else {
+        const std::uint32_t bytes = ix.chunks * 16;
+        for (std::uint32_t b = lane; b < bytes; b += 64)
+            query_lds[b] = b < ix.bytes_per_vector ? query[b] : (std::uint8_t)0;
+    }
+    wave_sync<false>();
+    return staged_norm<metric_ak, scalar_ak, lanes_ak>(ix, query_lds);
+}
+
+/// Same for a STORED row (16-byte aligned, already zero padded to the row stride) playing the query: 16-byte loads.
+/// Produces the same LDS image as `stage_query` of that vector, so distances agree bit for bit.
+template <int metric_ak, int scalar_ak, int lanes_ak>
+UA_DEVICE query_norm_t stage_row(const snapshot_view_t& ix, std::uint32_t slot, std::uint8_t* query_lds) {
+    const uint4* row = reinterpret_cast<const uint4*>(ix.vectors + (std::uint64_t)slot * ix.row_stride);
+    for (std::uint32_t c = lane_id(); c < ix.chunks; c += 64) {
+        const uint4 v = row[c];
+        if constexpr (scalar_ak == scalar_f16_k) {
+            float4* dst = reinterpret_cast<float4*>(query_lds + (std::size_t)c * 32);
+            dst[0] = float4{half_bits_to_float(v.x & 0xFFFFu), half_bits_to_float(v.x >> 16),
+                            half_bits_to_float(v.y & 0xFFFFu), half_bits_to_float(v.y >> 16)};
+            dst[1] = float4{half_bits_to_float(v.z & 0xFFFFu), half_bits_to_float(v.z >> 16),
+                            half_bits_to_float(v.w & 0xFFFFu), half_bits_to_float(v.w >> 16)};
+        } else {
+            *reinterpret_cast<uint4*>(query_lds + (std::size_t)c * 16) = v;
+        }
+    }
+    wave_sync<false>();
+    return staged_norm<metric_ak, scalar_ak, lanes_ak>(ix, query_lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -639,8 +666,9 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     const std::uint32_t visits_mask = global_ak ? 0u : args.hash_cap - 1;
     const std::uint32_t visits_limit = global_ak ? 0xFFFFFFFFu : args.hash_cap - args.hash_cap / 4; // 75 % load
 
+    const std::uint64_t query_row = args.query_ids ? args.query_ids[q] : q;
     const query_norm_t a2 = stage_query<metric_ak, scalar_ak, lanes_ak>(
-        ix, args.queries + (std::uint64_t)q * args.query_stride, query_lds);
+        ix, args.queries + query_row * args.query_stride, query_lds);
 
     if constexpr (!global_ak) { // the bitmap of `scratch_global_k` is zeroed by the host before the launch
         uint4* cells = reinterpret_cast<uint4*>(visits);
@@ -670,7 +698,8 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     wave_sync<global_ak>();
     measure(1);
     float closest_distance = uniform_f32(mem::load(cand_distances));
-    for (std::uint32_t level = ix.max_level; level > 0; --level) {
+    const std::uint32_t beam_level = args.beam_level; // 0 for search; the level being linked during construction
+    for (std::uint32_t level = ix.max_level; level > beam_level; --level) {
         bool changed;
         do {
             changed = false;
@@ -726,10 +755,13 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
         heap_pop<global_ak>(next, next_size);
         ++cycles;
         const std::uint32_t expanded = uniform_u32(cand_slot(candidate));
-        const std::uint32_t* list = ix.nbr0 + (std::uint64_t)expanded * ix.m0;
-        for (std::uint32_t tile = 0; tile < ix.m0; tile += 64) {
+        const std::uint32_t* list = beam_level
+                                        ? ix.upper + (std::uint64_t)(ix.upper_ref[expanded] + (beam_level - 1)) * ix.m
+                                        : ix.nbr0 + (std::uint64_t)expanded * ix.m0;
+        const std::uint32_t cells = beam_level ? ix.m : ix.m0;
+        for (std::uint32_t tile = 0; tile < cells; tile += 64) {
             const std::uint32_t cell = tile + lane;
-            const std::uint32_t neighbor = cell < ix.m0 ? list[cell] : none_slot_k;
+            const std::uint32_t neighbor = cell < cells ? list[cell] : none_slot_k;
             const bool present = neighbor != none_slot_k;
             const std::uint32_t present_count = popcount64(ballot(present));
             if (!present_count)

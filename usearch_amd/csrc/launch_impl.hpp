@@ -3,6 +3,7 @@
  *  storage scalar kind. Each `search_<kind>.hip` includes this once, so the kinds compile in parallel.
  */
 #pragma once
+#include "build_kernels.hpp"
 #include "engine.hpp"
 #include "kernels.hpp"
 
@@ -106,6 +107,30 @@ hipError_t launch_exact_metric(const exact_params_t& p, const snapshot_view_t& v
     }
 }
 
+template <int metric_ak, int scalar_ak, int lanes_ak>
+hipError_t launch_build_one(const build_params_t& p, const snapshot_view_t& view, const build_args_t& args) {
+    constexpr int unroll_ak = lanes_ak == 8 ? 8 : 4;
+    const std::uint32_t lds_bytes = query_lds_bytes<scalar_ak>(view.chunks) + build_lds_bytes_k;
+    if (p.reverse)
+        hipLaunchKernelGGL((build_reverse_kernel<metric_ak, scalar_ak, lanes_ak, unroll_ak>), dim3(p.grid), dim3(64),
+                           lds_bytes, p.stream, view, args);
+    else
+        hipLaunchKernelGGL((build_select_kernel<metric_ak, scalar_ak, lanes_ak, unroll_ak>), dim3(p.grid), dim3(64),
+                           lds_bytes, p.stream, view, args);
+    return hipGetLastError();
+}
+
+template <int metric_ak, int scalar_ak>
+hipError_t launch_build_metric(const build_params_t& p, const snapshot_view_t& view, const build_args_t& args) {
+    switch (p.lanes) {
+    case 1: return launch_build_one<metric_ak, scalar_ak, 1>(p, view, args);
+    case 2: return launch_build_one<metric_ak, scalar_ak, 2>(p, view, args);
+    case 4: return launch_build_one<metric_ak, scalar_ak, 4>(p, view, args);
+    case 8: return launch_build_one<metric_ak, scalar_ak, 8>(p, view, args);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 /// One (metric, scalar) pair per translation unit, so that the pairs compile in parallel.
 #define USEARCH_AMD_DEFINE_LAUNCHERS(name, metric_kind, scalar_kind)                                                   \
     hipError_t launch_search_##name(const launch_params_t& p, const snapshot_view_t& view,                             \
@@ -117,6 +142,9 @@ hipError_t launch_exact_metric(const exact_params_t& p, const snapshot_view_t& v
     }                                                                                                                  \
     hipError_t launch_exact_##name(const exact_params_t& p, const snapshot_view_t& view) {                             \
         return launch_exact_metric<metric_kind, scalar_kind>(p, view);                                                 \
+    }                                                                                                                  \
+    hipError_t launch_build_##name(const build_params_t& p, const snapshot_view_t& view, const build_args_t& args) {   \
+        return launch_build_metric<metric_kind, scalar_kind>(p, view, args);                                           \
     }
 
 } // namespace usearch_amd

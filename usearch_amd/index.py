@@ -40,6 +40,25 @@ class Stats(C.Structure):
                 ("kernel_ms", C.c_float), ("mode", C.c_uint32), ("grid", C.c_uint32), ("lds_bytes", C.c_uint32)]
 
 
+class BuildConfig(C.Structure):
+    """`usearch_amd_build_config_t`; zeros = the reference's defaults."""
+    _fields_ = [("connectivity", C.c_uint32), ("connectivity_base", C.c_uint32), ("expansion_add", C.c_uint32),
+                ("batch_divisor", C.c_uint32), ("max_batch", C.c_uint32), ("reserved", C.c_uint32),
+                ("seed", C.c_uint64)]
+
+
+class BuildStats(C.Structure):
+    """`usearch_amd_build_stats_t`."""
+    _fields_ = [("batches", C.c_uint64), ("passes", C.c_uint64), ("search_distances", C.c_uint64),
+                ("search_hops", C.c_uint64), ("select_distances", C.c_uint64), ("reverse_distances", C.c_uint64),
+                ("repruned_lists", C.c_uint64), ("dropped_requests", C.c_uint64), ("seconds_total", C.c_double),
+                ("seconds_search", C.c_double), ("seconds_link", C.c_double), ("seconds_upload", C.c_double),
+                ("max_level", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+
+
 _library = None
 
 EXPORTED_SYMBOLS = [
@@ -52,6 +71,8 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_last_distances_ms", "usearch_amd_merge_many", "usearch_amd_merge_many_device",
     "usearch_amd_exact_search_many", "usearch_amd_exact_search_dataset",
     "usearch_amd_test_containers", "usearch_amd_cast",
+    "usearch_amd_build", "usearch_amd_build_free", "usearch_amd_build_snapshot",
+    "usearch_amd_build_serialized_length", "usearch_amd_build_save_buffer", "usearch_amd_build_stats",
 ]
 
 
@@ -104,6 +125,16 @@ def library() -> C.CDLL:
                                               C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), err_p]
     L.usearch_amd_cast.restype = C.c_int
     L.usearch_amd_cast.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.usearch_amd_build.restype = C.c_void_p
+    L.usearch_amd_build.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_void_p,
+                                    C.POINTER(BuildConfig), C.c_int, C.c_int, err_p]
+    L.usearch_amd_build_free.argtypes = [C.c_void_p, err_p]
+    L.usearch_amd_build_snapshot.restype = C.c_void_p
+    L.usearch_amd_build_snapshot.argtypes = [C.c_void_p]
+    L.usearch_amd_build_serialized_length.restype = C.c_size_t
+    L.usearch_amd_build_serialized_length.argtypes = [C.c_void_p]
+    L.usearch_amd_build_save_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, err_p]
+    L.usearch_amd_build_stats.argtypes = [C.c_void_p, C.POINTER(BuildStats)]
     _library = L
     return L
 
@@ -168,8 +199,9 @@ class BatchMatches:
 class Index:
     """An immutable HBM-resident snapshot of a serialized USearch index, searchable in batches on one MI355X."""
 
-    def __init__(self, handle: int, expansion_search: int = 0):
+    def __init__(self, handle: int, expansion_search: int = 0, owner=None):
         self._handle = handle
+        self._owner = owner  # a `BuiltIndex` whose builder owns the snapshot: keeps it alive, frees it
         self.expansion_search = expansion_search  # 0 = the reference's default of 64 (index.hpp:3029-3030)
 
     @classmethod
@@ -191,9 +223,11 @@ class Index:
 
     def close(self) -> None:
         if getattr(self, "_handle", None):
-            err = C.c_char_p()
-            library().usearch_amd_snapshot_free(self._handle, C.byref(err))
+            if getattr(self, "_owner", None) is None:
+                err = C.c_char_p()
+                library().usearch_amd_snapshot_free(self._handle, C.byref(err))
             self._handle = None
+            self._owner = None
 
     def __del__(self):
         try:
@@ -342,6 +376,84 @@ class Index:
                                         _pointer(slots), slots.shape[1], _pointer(out), C.byref(err))
         _raise(err, "usearch_amd_distances")
         return out
+
+
+class BuiltIndex:
+    """An index constructed on the MI355X (`usearch_amd_build`): a searchable `Index` (`.index`) plus the reference's
+    serialized form (`.save_buffer()` / `.save(path)`), so the reference — or anything else that reads `.usearch` files —
+    can load what was built. Mirrors the `Index(...)` + `add(keys, vectors)` + `save` sequence of python/usearch/index.py
+    (index.py:400-520, 640-700, 1060-1100) collapsed into one call."""
+
+    def __init__(self, handle: int):
+        self._builder = handle
+        self.index = Index(library().usearch_amd_build_snapshot(handle), owner=self)
+
+    @property
+    def stats(self) -> BuildStats:
+        out = BuildStats()
+        library().usearch_amd_build_stats(self._builder, C.byref(out))
+        return out
+
+    @property
+    def serialized_length(self) -> int:
+        return library().usearch_amd_build_serialized_length(self._builder)
+
+    def save_buffer(self) -> np.ndarray:
+        image = np.empty(self.serialized_length, dtype=np.uint8)
+        err = C.c_char_p()
+        library().usearch_amd_build_save_buffer(self._builder, _pointer(image), image.size, C.byref(err))
+        _raise(err, "usearch_amd_build_save_buffer")
+        return image
+
+    def save(self, path) -> None:
+        self.save_buffer().tofile(os.fspath(path))
+
+    def close(self) -> None:
+        if getattr(self, "_builder", None):
+            self.index._handle = None
+            self.index._owner = None
+            err = C.c_char_p()
+            library().usearch_amd_build_free(self._builder, C.byref(err))
+            self._builder = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def build(vectors, metric: str = "cos", dtype: Optional[str] = None, *, keys: Optional[np.ndarray] = None,
+          connectivity: int = 16, expansion_add: int = 128, connectivity_base: int = 0, device: int = 0,
+          max_batch: int = 0, batch_divisor: int = 0, seed: int = 0, ndim: Optional[int] = None,
+          device_pointer: Optional[int] = None, count: Optional[int] = None, stride: Optional[int] = None) -> BuiltIndex:
+    """Builds an HNSW index on the device. `vectors` is a [N, d] numpy matrix in the storage scalar kind (bit-packed
+    `uint8` rows for `b1`); or pass `device_pointer` / `count` / `stride` / `ndim` / `dtype` for rows already in HBM."""
+    err = C.c_char_p()
+    config = BuildConfig(connectivity, connectivity_base, expansion_add, batch_divisor, max_batch, 0, seed)
+    metric_kind = {name: kind for kind, name in METRIC_NAMES.items()}[metric]
+    if keys is not None:
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    if device_pointer is not None:
+        assert dtype and ndim and count and stride
+        handle = library().usearch_amd_build(C.c_void_p(device_pointer), count, stride, SCALAR_KINDS[dtype], ndim,
+                                             metric_kind, _pointer(keys), C.byref(config), device, 1, C.byref(err))
+    else:
+        vectors = np.asarray(vectors)
+        if dtype is None:
+            dtype = {np.dtype(np.float32): "f32", np.dtype(np.float16): "f16", np.dtype(np.int8): "i8",
+                     np.dtype(np.uint8): "b1"}[vectors.dtype]
+        if vectors.ndim != 2 or vectors.strides[1] != vectors.itemsize:
+            vectors = np.ascontiguousarray(vectors)
+        if ndim is None:
+            ndim = vectors.shape[1] * 8 if dtype == "b1" else vectors.shape[1]
+        handle = library().usearch_amd_build(_pointer(vectors), len(vectors), vectors.strides[0], SCALAR_KINDS[dtype],
+                                             ndim, metric_kind, _pointer(keys), C.byref(config), device, 0,
+                                             C.byref(err))
+    _raise(err, "usearch_amd_build")
+    if not handle:
+        raise RuntimeError("usearch_amd_build: failed without a message")
+    return BuiltIndex(handle)
 
 
 def exact_search(dataset: np.ndarray, queries: np.ndarray, count: int, metric: str = "cos",
