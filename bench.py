@@ -11,11 +11,13 @@ with two extra objects:
   "cpu_baseline": the REAL reference (`oracle/_ref`, compiled from /root/reference's own headers) searching the same
                   index with the loop of cpp/bench.cpp:352-377 on all host cores, on a bounded sample (rank 0, N = 1).
 
-The index is BUILT by the reference (index construction is outside the GPU path): the reference library adds
-the seeded synthetic vectors on the host cores, serialises the index (`usearch_save_buffer`) and that image is what the
-engine uploads. With N > 1 every rank holds a replica and searches its own batch (weak scaling, no collective on the data
-path). `--sharded` is the capacity mode: every rank builds and holds its own shard of `--n` vectors
-EACH (per-GPU work fixed as N grows = weak scaling of the index size), the batch is broadcast, every rank
+Default workload = the configuration BASELINE.json's metric is quoted on: 10M x 768 f16 cosine, batch 10 000, k = 10.
+The seeded synthetic vectors are generated in HBM and the index is built ON THE GPU (`usearch_amd.build`, ≈20 s for 10M;
+`--builder reference` lets the reference build it on the host cores instead — minutes per million vectors, so only for
+small `--n`). The reference is handed the very same index (`save_buffer` → `usearch_view_buffer`) for the CPU baseline.
+With N > 1 every rank builds (deterministically, so identically) and holds a replica and searches its own batch (weak
+scaling, no collective on the data path). `--sharded` is the capacity mode: every rank builds and holds its own shard of
+`--n` vectors EACH (per-GPU work fixed as N grows = weak scaling of the index size), the batch is broadcast, every rank
 searches its shard, per-shard top-k are all-gathered over RCCL and merged (usearch_amd/sharded.py).
 """
 from __future__ import annotations
@@ -34,6 +36,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (≈6.3 TB/s achievable on streaming copies)
 DTYPE_BYTES = {"f32": 4.0, "f16": 2.0, "i8": 1.0, "b1": 0.125}
+NUMPY_STORAGE = {"f32": np.float32, "f16": np.float16, "i8": np.int8, "b1": np.uint8}
 
 
 def host_cores() -> int:
@@ -112,24 +115,27 @@ def main() -> None:
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=5)
     parser.add_argument("--warmup", type=int, default=1)
-    parser.add_argument("--n", type=int, default=int(os.environ.get("BENCH_N", 200_000)), help="vectors in the index")
+    parser.add_argument("--n", type=int, default=int(os.environ.get("BENCH_N", 10_000_000)), help="vectors in the index")
     parser.add_argument("--dim", type=int, default=768)
     parser.add_argument("--dtype", default="f16", choices=list(DTYPE_BYTES))
     parser.add_argument("--metric", default=None)
     parser.add_argument("--queries", type=int, default=10_000)
     parser.add_argument("--k", type=int, default=10)
     parser.add_argument("--expansion", type=int, default=0,
-                        help="0 = smallest of 64/96/128/192/256/320/384/512/768/1024 with recall@k >= 0.95")
+                        help="0 = smallest of the sweep (64 ... 1024) with recall@k >= 0.95")
     parser.add_argument("--connectivity", type=int, default=16)
     parser.add_argument("--expansion-add", type=int, default=128)
     parser.add_argument("--recall-queries", type=int, default=1000)
     parser.add_argument("--cpu-seconds", type=float, default=12.0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--sharded", action="store_true")
+    parser.add_argument("--builder", default=os.environ.get("BENCH_BUILDER", "gpu"), choices=["gpu", "reference"],
+                        help="who links the index: the device builder (default) or the reference on the host cores")
     parser.add_argument("--build-threads", type=int, default=int(os.environ.get("BENCH_BUILD_THREADS", 0)),
                         help="threads the reference uses to build the index (0 = 2 x the cgroup CPU quota)")
-    parser.add_argument("--cache-dir", default=os.environ.get("BENCH_CACHE_DIR", ""),
-                        help="keep the reference-built index image here between runs (e.g. /dev/shm)")
+    parser.add_argument("--traffic-json", default=os.environ.get("BENCH_TRAFFIC_JSON", ""),
+                        help="PMC-derived HBM bytes per launch of this workload (scripts/pmc_traffic.py), copied into "
+                             "roofline.traffic")
     args = parser.parse_args()
     metric = args.metric or ("hamming" if args.dtype == "b1" else "l2sq" if args.dtype == "i8" else "cos")
     cores = host_cores()
@@ -149,64 +155,53 @@ def main() -> None:
     device = torch.device("cuda", local_rank)
 
     import usearch_amd
-    from oracle import refbind  # the reference builds the index and is the cpu_baseline; never on the timed GPU path
 
-    cache_path = None
-    if args.cache_dir:
-        cache_path = os.path.join(args.cache_dir, f"usearch_amd_{args.n}x{args.dim}{args.dtype}_{metric}_m{args.connectivity}"
-                                                  f"_efa{args.expansion_add}.usearch")
-    # ---- the index: built once by the reference on the host cores (rank 0), shared with the other ranks through /dev/shm
-    image_path = f"/dev/shm/usearch_amd_bench_{os.environ.get('MASTER_PORT', '0')}_{args.n}x{args.dim}{args.dtype}.usearch"
-    build_seconds = 0.0
-    ref_index = None
-    shard_base = 0
-    if args.sharded and world > 1:
-        per_shard = args.n  # per-GPU shard size is fixed; the total index grows with the number of GPUs
-        shard_base = rank * per_shard
-        vectors = synthetic_vectors(per_shard, args.dim, args.dtype, seed=42 + rank)
+    # ---- the index. Replicas: every rank builds the same seeded data (the device build is deterministic). Shards: rank r
+    #      builds its own `--n` vectors with keys offset by r * n.
+    sharded = args.sharded and world > 1
+    data_seed = 42 + (rank if sharded else 0)
+    key_base = rank * args.n if sharded else 0
+    build_seconds, build_stats, ref_index, image, built = 0.0, None, None, None, None
+    t_generate = time.time()
+    if args.builder == "gpu":
+        data = synthetic_vectors_device(args.n, args.dim, args.dtype, data_seed, device)
+        torch.cuda.synchronize()
+        generate_seconds = time.time() - t_generate
+        keys = np.arange(args.n, dtype=np.uint64) + key_base if key_base else None
+        t0 = time.time()
+        built = usearch_amd.build(None, metric, args.dtype, keys=keys, connectivity=args.connectivity,
+                                  expansion_add=args.expansion_add, device=local_rank, device_pointer=data.data_ptr(),
+                                  count=args.n, stride=data.stride(0), ndim=args.dim)
+        build_seconds = time.time() - t0
+        del data
+        torch.cuda.empty_cache()
+        index = built.index
+        build_stats = built.stats.as_dict()
+        if rank == 0:
+            log(f"[bench] generated {args.n}x{args.dim} {args.dtype} in HBM in {generate_seconds:.1f}s; GPU build "
+                f"{build_seconds:.1f}s ({args.n / build_seconds:,.0f} vectors/s; search {build_stats['seconds_search']:.1f}s, "
+                f"link {build_stats['seconds_link']:.1f}s, {build_stats['batches']} batches, max level {build_stats['max_level']})")
+    else:
+        from oracle import refbind  # the reference builds the index on the host; never on the timed GPU path
+        vectors = synthetic_vectors(args.n, args.dim, args.dtype, seed=data_seed)
         ref_index = refbind.RefIndex(args.dim, metric, args.dtype, args.connectivity, args.expansion_add, 64)
         t0 = time.time()
-        ref_index.add(np.arange(per_shard, dtype=np.uint64) + shard_base, vectors,
-                      threads=max(1, 2 * cores // world))
+        ref_index.add(np.arange(args.n, dtype=np.uint64) + key_base, vectors,
+                      threads=max(1, args.build_threads // (world if world > 1 else 1)))
         build_seconds = time.time() - t0
-        image = ref_index.save_buffer()
-    else:
-        if rank == 0 and cache_path and os.path.exists(cache_path):
-            image = np.fromfile(cache_path, dtype=np.uint8)
-            ref_index = refbind.RefIndex.from_buffer(image, view=False, dtype=args.dtype)
-            log(f"[bench] reusing the reference-built index {cache_path}")
-        elif rank == 0:
-            vectors = synthetic_vectors(args.n, args.dim, args.dtype, seed=42)
-            ref_index = refbind.RefIndex(args.dim, metric, args.dtype, args.connectivity, args.expansion_add, 64)
-            t0 = time.time()
-            ref_index.add(np.arange(args.n, dtype=np.uint64), vectors, threads=args.build_threads)
-            build_seconds = time.time() - t0
-            log(f"[bench] reference built {args.n}x{args.dim} {args.dtype} in {build_seconds:.1f}s "
-                f"on {args.build_threads or refbind.max_threads()} threads")
-            image = ref_index.save_buffer()
-            if cache_path:
-                image.tofile(cache_path)
         if rank == 0:
-            if world > 1:
-                image.tofile(image_path)
-        if world > 1:
-            dist.barrier()
-            if rank != 0:
-                image = np.fromfile(image_path, dtype=np.uint8)
-            dist.barrier()
-            if rank == 0:
-                os.unlink(image_path)
-    t0 = time.time()
-    index = usearch_amd.Index.restore(image, device=local_rank)
-    upload_seconds = time.time() - t0
+            log(f"[bench] reference built {args.n}x{args.dim} {args.dtype} in {build_seconds:.1f}s")
+        image = ref_index.save_buffer()
+        del vectors
+        index = usearch_amd.Index.restore(image, device=local_rank)
     bpv = index.bytes_per_vector
     if rank == 0:
-        log(f"[bench] snapshot: {len(index)} vectors, {index.memory_usage / 1e9:.2f} GB HBM, upload {upload_seconds:.1f}s, "
-            f"lanes/row {index.lanes_per_row}, row stride {index.row_stride}")
+        log(f"[bench] snapshot: {len(index)} vectors, {index.memory_usage / 1e9:.2f} GB HBM, lanes/row {index.lanes_per_row}, "
+            f"row stride {index.row_stride}, max level {index.max_level}")
 
     # ---- queries: out-of-sample, seeded per rank; resident in HBM before the timed region
-    queries_host = synthetic_vectors(args.queries, args.dim, args.dtype, seed=43 if args.sharded else 43 + 1000 * rank)
-    queries_dev = torch.from_numpy(queries_host.view(np.uint8).reshape(args.queries, -1)).to(device)
+    queries_dev = synthetic_vectors_device(args.queries, args.dim, args.dtype, 43 if sharded else 43 + 1000 * rank, device)
+    queries_host = queries_dev.cpu().numpy().view(NUMPY_STORAGE[args.dtype])
     keys_dev = torch.zeros((args.queries, args.k), dtype=torch.int64, device=device)
     dist_dev = torch.zeros((args.queries, args.k), dtype=torch.float32, device=device)
     counts_dev = torch.zeros(args.queries, dtype=torch.int64, device=device)
@@ -215,7 +210,7 @@ def main() -> None:
     stream = torch.cuda.Stream(device)
 
     sharded_searcher = None
-    if args.sharded and world > 1:
+    if sharded:
         from usearch_amd.sharded import gpu_searcher
         sharded_searcher = gpu_searcher(index, stream=stream.cuda_stream)
         merged = {}
@@ -232,12 +227,15 @@ def main() -> None:
                                    visited_dev.data_ptr(), computed_dev.data_ptr(), stream=stream.cuda_stream,
                                    timed=timed)
 
-    # ---- recall@k against the reference's own exact search (index.hpp:4252-4268) on a sample; pick ef
+    # ---- recall@k against EXACT search (the brute-force kernel, bit-checked against the reference's `exact = true` in
+    #      tests/test_gpu_exact.py) on a sample; pick the smallest ef of the sweep that reaches 0.95
     recall, expansion = None, args.expansion
     sample = min(args.recall_queries, args.queries)
-    if rank == 0 and not args.sharded and sample:
-        truth, *_ = ref_index.search(queries_host[:sample], args.k, dtype=args.dtype, exact=True, threads=2 * cores)
-        sweep = [args.expansion] if args.expansion else [64, 96, 128, 192, 256, 320, 384, 512, 768, 1024]
+    if rank == 0 and not sharded and sample:
+        t0 = time.time()
+        truth = index.search(queries_host[:sample], args.k, dtype=args.dtype, exact=True).keys
+        log(f"[bench] exact ground truth for {sample} queries in {time.time() - t0:.1f}s")
+        sweep = [args.expansion] if args.expansion else [64, 96, 128, 192, 256, 320, 384, 448, 512, 576, 640, 704, 768, 896, 1024]
         for ef in sweep:
             search_step(ef, False)
             found = keys_dev[:sample].cpu().numpy().astype(np.uint64)
@@ -250,7 +248,7 @@ def main() -> None:
         chosen = torch.tensor([expansion or 64], device=device)
         dist.broadcast(chosen, 0)
         expansion = int(chosen.item())
-    expansion = expansion or (256 if args.sharded else 64)
+    expansion = expansion or (256 if sharded else 64)
 
     # ---- warmup, then EXACTLY `steps` timed steps between barriers
     for _ in range(args.warmup):
@@ -295,9 +293,15 @@ def main() -> None:
     # ---- the reference on the host cores, same index, same queries, same ef (rank 0, N = 1 only)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import refbind
+        if ref_index is None:  # hand the GPU-built index to the reference: serialize, then `usearch_view_buffer`
+            t1 = time.time()
+            image = built.save_buffer()
+            ref_index = refbind.RefIndex.from_buffer(image, view=True, dtype=args.dtype)
+            log(f"[bench] serialized {image.nbytes / 1e9:.1f} GB for the reference in {time.time() - t1:.1f}s")
         ref_index.expansion_search = expansion
         threads = cores
-        pilot = min(args.queries, 64 * threads)
+        pilot = min(args.queries, 16 * threads)
         t1 = time.perf_counter()
         ref_index.search(queries_host[:pilot], args.k, dtype=args.dtype, threads=threads)
         rate = pilot / (time.perf_counter() - t1)
@@ -312,10 +316,13 @@ def main() -> None:
                          f"unavailable offline; {cpu_seconds:.1f}s; label agreement with the GPU {agree:.4f}"}
 
     if rank == 0:
-        total_queries = args.queries * args.steps * (1 if args.sharded else world)
-        total_vectors = args.n * (world if args.sharded else 1)
+        traffic = None
+        if args.traffic_json and os.path.exists(args.traffic_json):
+            traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+        total_queries = args.queries * args.steps * (1 if sharded else world)
+        total_vectors = args.n * (world if sharded else 1)
         line = {
-            "metric": f"QPS at recall@{args.k}>=0.95, {args.metric or metric} {args.dtype}, batch={args.queries}",
+            "metric": f"QPS at recall@{args.k}>=0.95, {args.n}x{args.dim} {args.dtype} {metric}, batch={args.queries}",
             "value": total_queries / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
@@ -330,13 +337,14 @@ def main() -> None:
             "config": {"workload": f"{args.n}x{args.dim} {args.dtype} {metric}, batch {args.queries}, k={args.k}, "
                                    f"M={args.connectivity}, ef_construction={args.expansion_add}, ef={expansion}",
                        "vectors": total_vectors, "dimensions": args.dim, "expansion_search": expansion,
-                       "recall_at_k": recall, "parallelism": ("shards" if args.sharded else "replicas") + str(world),
-                       "index_build_seconds": round(build_seconds, 1), "kernel_passes": passes,
+                       "recall_at_k": recall, "parallelism": ("shards" if sharded else "replicas") + str(world),
+                       "index_builder": args.builder, "index_build_seconds": round(build_seconds, 1),
+                       "index_build": build_stats, "kernel_passes": passes,
                        "scratch_mode": {1: "lds", 2: "global-hash", 3: "global"}.get(stats.mode, "?"),
                        "persistent_waves": stats.grid, "lds_bytes_per_wave": stats.lds_bytes,
                        "host_buffer_api_qps_pcie_inclusive": host_api_qps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "search_kernel", "kernel_ms": kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": step_bytes,
                          "distances_per_query": float(np.mean(computed)), "hops_per_query": float(np.mean(visited))},

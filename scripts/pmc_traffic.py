@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""scripts/pmc_traffic.py <FETCH_SIZE csv> <WRITE_SIZE csv> [kernel substring] → JSON with the HBM bytes per launch of the
+search kernel, from rocprofv3 PMC passes collected SEPARATELY (TCC slots: FETCH_SIZE and WRITE_SIZE do not fit one pass),
+corrected as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes: counters are in KiB; on gfx950 FETCH_SIZE tallies
+128-byte requests at 64 bytes, so wide (16 B/lane) reads are doubled; WRITE_SIZE is taken as is (uncalibrated)."""
+import csv
+import json
+import sys
+
+
+def mean_counter(path, name, kernel):
+    """Mean per launch over the instantiation of `kernel` with the largest launches: the index build of the same process
+    runs (smaller-expansion) instantiations of the search kernel as well, and warm-up / sweep launches of the timed
+    instantiation have the same size as the timed ones."""
+    groups = {}
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] == name and kernel in row["Kernel_Name"]:
+                groups.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+    if not groups:
+        return None, 0, None
+    best = max(groups, key=lambda k: sum(groups[k]) / len(groups[k]))
+    values = groups[best]
+    return sum(values) / len(values), len(values), best.split("(")[0]
+
+
+def main():
+    fetch_csv, write_csv = sys.argv[1], sys.argv[2]
+    kernel = sys.argv[3] if len(sys.argv) > 3 else "search_kernel"
+    fetch_kib, fetch_n, kernel_name = mean_counter(fetch_csv, "FETCH_SIZE", kernel)
+    write_kib, write_n, _ = mean_counter(write_csv, "WRITE_SIZE", kernel)
+    fetch_bytes = fetch_kib * 1024 * 2 if fetch_kib is not None else None
+    write_bytes = write_kib * 1024 if write_kib is not None else None
+    total = (fetch_bytes or 0) + (write_bytes or 0) if fetch_bytes is not None else None
+    print(json.dumps({"hbm_bytes_per_launch": total, "fetch_bytes_per_launch": fetch_bytes,
+                      "write_bytes_per_launch": write_bytes, "launches_averaged": [fetch_n, write_n], "kernel": kernel_name,
+                      "correction": "FETCH_SIZE[KiB] x 1024 x 2 (gfx950: 128-B requests tallied at 64 B) + "
+                                    "WRITE_SIZE[KiB] x 1024 (uncalibrated)"}))
+
+
+if __name__ == "__main__":
+    main()

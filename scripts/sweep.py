@@ -39,25 +39,19 @@ def main():
 
     import torch
     import usearch_amd
-    from oracle import refbind
 
-    path = os.path.join(args.cache_dir, f"usearch_amd_{args.n}x{args.dim}{args.dtype}_{metric}_m16_efa128.usearch")
-    if os.path.exists(path):
-        image = np.fromfile(path, dtype=np.uint8)
-    else:
-        vectors = bench.synthetic_vectors(args.n, args.dim, args.dtype, seed=42)
-        ref = refbind.RefIndex(args.dim, metric, args.dtype, 16, 128, 64)
-        t0 = time.time()
-        ref.add(np.arange(args.n, dtype=np.uint64), vectors, threads=args.build_threads)
-        print(f"built {args.n} in {time.time() - t0:.1f}s ({args.build_threads or refbind.max_threads()} threads)", flush=True)
-        image = ref.save_buffer()
-        image.tofile(path)
-        del ref, vectors
-    index = usearch_amd.Index.restore(image)
-    del image
     device = torch.device("cuda", 0)
-    queries_host = bench.synthetic_vectors(args.queries, args.dim, args.dtype, seed=43)
-    queries = torch.from_numpy(queries_host.view(np.uint8).reshape(args.queries, -1)).to(device)
+    data = bench.synthetic_vectors_device(args.n, args.dim, args.dtype, 42, device)
+    t0 = time.time()
+    built = usearch_amd.build(None, metric, args.dtype, device_pointer=data.data_ptr(), count=args.n,
+                              stride=data.stride(0), ndim=args.dim)
+    print(f"GPU-built {args.n} in {time.time() - t0:.1f}s", flush=True)
+    del data
+    torch.cuda.empty_cache()
+    index = built.index
+    device = torch.device("cuda", 0)
+    queries = bench.synthetic_vectors_device(args.queries, args.dim, args.dtype, 43, device)
+    queries_host = queries.cpu().numpy().view(bench.NUMPY_STORAGE[args.dtype])
     keys = torch.zeros((args.queries, args.k), dtype=torch.int64, device=device)
     dists = torch.zeros((args.queries, args.k), dtype=torch.float32, device=device)
     counts = torch.zeros(args.queries, dtype=torch.int64, device=device)

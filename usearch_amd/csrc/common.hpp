@@ -109,6 +109,7 @@ struct search_args_t {
     const std::uint32_t* query_ids; ///< optional: query `q` is row query_ids[q] of `queries` (a stored vector); outputs stay at row q
     std::uint32_t beam_level;       ///< level the beam runs on (0 for `search`); the greedy descent stops above it
     std::uint32_t emit_slots;       ///< 1 = write slots instead of keys into `keys`
+    unsigned long long* phases;     ///< optional [8] diagnostic: shader-clock ticks per phase summed over all waves
 };
 
 enum : std::uint32_t { status_done_k = 0, status_overflow_k = 1 };

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -377,22 +378,21 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
     std::uint32_t variant_request = tuning.variant ? tuning.variant : (std::uint32_t)env_size("USEARCH_AMD_VARIANT", 0);
     int variant = variant_u4_w4_k;
     if (lanes_ == 8 && chunks_per_lane >= 8) {
-        // measured on 1M x 768 f16 (profiles/): with room for ≥ 12 waves per CU the 8-deep build wins, once LDS caps the
-        // CU at ~8 waves the 12-deep build (a whole row per round trip) does
-        std::uint64_t heaps = scratch_layout(ef <= 512 ? 0 : ef, std::max<std::uint32_t>(512, ef * 3 + 256), 0).total;
-        const bool lds_bound = lds_budget / ((query_lds + heaps + 1023) / 1024 * 1024) < 12;
-        variant = chunks_per_lane >= 12 && lds_bound ? variant_u12_w2_k : variant_u8_w3_k;
+        // measured on 10M x 768 f16 (profiles/): a whole row per round trip (12 loads per lane, 8 waves per CU) beats 8 loads
+        // at 12 waves per CU at every expansion — the traversal is latency-bound, fewer round trips per hop win
+        variant = chunks_per_lane >= 12 ? variant_u12_w2_k : variant_u8_w3_k;
     }
     if (variant_request && variant_request - 1 <= (std::uint32_t)variant_u12_w2_k && lanes_ == 8)
         variant = (int)variant_request - 1;
-    const std::uint32_t variant_waves_per_cu = 4u * (std::uint32_t)variant_waves(variant);
+    const std::uint32_t top_entries_hint = ef <= 64 ? 1u : ef <= 256 ? 4u : ef <= 512 ? 8u : ef <= 1024 ? 16u : 0u;
+    const std::uint32_t variant_waves_per_cu = 4u * (std::uint32_t)kernel_waves(variant, (int)top_entries_hint);
     const std::uint32_t waves_cap = tuning.waves_per_cu ? tuning.waves_per_cu
                                                         : (std::uint32_t)env_size("USEARCH_AMD_WAVES_PER_CU", 16);
     std::uint32_t mode_request = tuning.mode ? tuning.mode : (std::uint32_t)env_size("USEARCH_AMD_MODE", 0);
 
-    // `top` lives in registers (1 / 4 / 8 entries per lane) while the expansion allows it
+    // `top` lives in registers (1 / 4 / 8 / 16 entries per lane) while the expansion allows it
     const bool top_in_memory = tuning.top_in_memory || env_size("USEARCH_AMD_TOP_IN_MEMORY", 0) != 0;
-    const std::uint32_t entries_per_lane = top_in_memory ? 0u : ef <= 64 ? 1u : ef <= 256 ? 4u : ef <= 512 ? 8u : 0u;
+    const std::uint32_t entries_per_lane = top_in_memory ? 0u : ef <= 64 ? 1u : ef <= 256 ? 4u : ef <= 512 ? 8u : ef <= 1024 ? 16u : 0u;
     auto lds_bytes_for = [&](int mode, std::uint32_t cap_next, std::uint32_t cap_hash) -> std::uint64_t {
         if (mode == scratch_global_k)
             return query_lds;
@@ -405,6 +405,21 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
         return (std::uint32_t)std::max<std::uint64_t>(
             1, std::min<std::uint64_t>(std::min(waves_cap, variant_waves_per_cu), lds_budget / std::max<std::uint64_t>(granule, 1)));
     };
+    // the frontier's default room has 256 cells of slack; when giving up to half of it back lets one more wave share the
+    // compute unit's LDS, do (the retry ladder still catches a query that would have needed them)
+    const bool default_next_cap = !tuning.next_cap && !env_size("USEARCH_AMD_NEXT_CAP", 0);
+    if (default_next_cap && mode_request != 1 && mode_request != 3) {
+        const std::uint32_t now = waves_for(lds_bytes_for(scratch_hash_k, next_cap, hash_cap));
+        if (now < std::min(waves_cap, variant_waves_per_cu)) {
+            const std::uint64_t room = lds_budget / (now + 1) / 1024 * 1024;
+            const std::uint64_t fixed = lds_bytes_for(scratch_hash_k, 0, hash_cap);
+            if (room > fixed) {
+                const std::uint32_t trimmed = (std::uint32_t)((room - fixed) / 8 / 2 * 2);
+                if (trimmed < next_cap && trimmed + 128 >= next_cap)
+                    next_cap = trimmed;
+            }
+        }
+    }
     // auto: keep the visited set in LDS only while that still leaves 8 waves per CU; otherwise move it to the global hash
     int mode = mode_request == 1 ? scratch_lds_k : mode_request == 2 ? scratch_hash_k : mode_request == 3 ? scratch_global_k
                : (waves_for(lds_bytes_for(scratch_lds_k, next_cap, hash_cap)) >= 8 ? scratch_lds_k : scratch_hash_k);
@@ -436,6 +451,13 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
     params.lanes = lanes_;
     params.variant = variant;
     params.stream = stream;
+
+    // diagnostic: per-phase shader-clock ticks of the search kernel, printed to stderr (USEARCH_AMD_PHASES=1)
+    const bool want_phases = env_size("USEARCH_AMD_PHASES", 0) != 0;
+    if (want_phases) {
+        args.phases = reinterpret_cast<unsigned long long*>(d_queue_) + 8; // d_queue_ is a 256-byte block
+        UA_HIP(hipMemsetAsync(args.phases, 0, 128, stream));
+    }
 
     float total_ms = 0.f;
     auto timed_launch = [&](const launch_params_t& p, const search_args_t& a) -> const char* {
@@ -564,6 +586,19 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
         for (std::uint32_t q : todo)
             if (h_status_[q] != status_done_k)
                 return "Search scratch overflow in the global-memory pass";
+    }
+    if (want_phases) {
+        unsigned long long ticks[16] = {0};
+        UA_HIP(hipMemcpy(ticks, args.phases, 128, hipMemcpyDeviceToHost));
+        double total = 0;
+        for (int i = 0; i < 6; ++i)
+            total += (double)ticks[i];
+        std::fprintf(stderr, "[usearch_amd] phases ef=%u grid=%u: setup %.1f%% pop+list %.1f%% visited %.1f%% distances %.1f%% "
+                             "commit %.1f%% [heap push %.1f%% top insert %.1f%%, %llu candidates rechecked] dump %.1f%% (%.3g ticks); "
+                             "frontier pushes %llu, lists ready ahead %llu\n",
+                     ef, params.grid, 100 * ticks[0] / total, 100 * ticks[1] / total, 100 * ticks[2] / total,
+                     100 * ticks[3] / total, 100 * ticks[4] / total, 100 * ticks[8] / total, 100 * ticks[9] / total, ticks[10],
+                     100 * ticks[5] / total, total, ticks[6], ticks[7]);
     }
     if (stats) {
         stats->passes = passes;

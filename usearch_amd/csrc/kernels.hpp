@@ -222,22 +222,30 @@ UA_DEVICE bool sorted_insert(cand_t* top, std::uint32_t& size, std::uint32_t lim
     return true;
 }
 
+/// Every lane receives the value of the lane below it (lane 0 keeps its own): one DPP `wave_shr:1` move, no LDS crossbar.
+UA_DEVICE std::uint32_t lane_below_u32(std::uint32_t v) {
+    return (std::uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+UA_DEVICE float lane_below_f32(float v) {
+    return __builtin_bit_cast(float, lane_below_u32(__builtin_bit_cast(std::uint32_t, v)));
+}
+
 /**
  *  `top` as the search kernel holds it.
- *    epl_ak > 0   in REGISTERS, blocked layout: lane L owns entries [L·epl, (L+1)·epl) of the ascending array, unused cells
- *                 hold +inf. An insert is EPL ballots + one cross-lane carry — no LDS round trips, nothing to conflict.
- *                 Capacity 64·epl ≥ expansion.
+ *    epl_ak > 0   in REGISTERS, striped layout: entry `g` of the ascending array lives in lane g % 64 of register row
+ *                 g / 64 (epl_ak rows, capacity 64·epl_ak ≥ expansion), unused cells hold +inf. An insert costs one ballot per
+ *                 row up to the landing row plus one DPP lane shift per row from the landing row on — rows below the
+ *                 landing position are skipped by wave-uniform branches, nothing touches LDS.
  *    epl_ak == 0  in scratch memory (LDS, or the global slab of the fallback mode): any expansion.
  *  Same observable behaviour as sorted_buffer_gt (index.hpp:845-956) either way.
  */
 template <int epl_ak, bool global_ak> struct top_gt {
     static constexpr int regs_k = epl_ak > 0 ? epl_ak : 1;
-    // SSA vectors, not arrays: an array would be an alloca that the optimiser demotes to scratch memory as soon as one
-    // of the unrolled select chains below is folded into an indexed load
-    typedef float distances_t __attribute__((ext_vector_type(regs_k)));
-    typedef std::uint32_t slots_t __attribute__((ext_vector_type(regs_k)));
-    distances_t d;
-    slots_t s;
+    // plain arrays that are only ever indexed by compile-time constants (every loop over them is fully unrolled, the row
+    // chain of `insert` is a template per row): SROA turns each cell into its own SSA value, so the control flow between
+    // rows merges single registers. (An ext_vector is merged as a whole: 2·epl register copies at every row boundary.)
+    float d[regs_k];
+    std::uint32_t s[regs_k];
     cand_t* cells = nullptr;
     std::uint32_t size = 0;
 
@@ -249,36 +257,102 @@ template <int epl_ak, bool global_ak> struct top_gt {
             d[i] = __builtin_inff(), s[i] = none_slot_k;
     }
 
-    /// insert(element, limit), index.hpp:928-939.
-    UA_DEVICE bool insert(float nd, std::uint32_t ns, std::uint32_t limit) {
+    /// insert(element, limit), index.hpp:928-939. When the buffer is full afterwards, `radius` receives top().distance
+    /// (index.hpp:891); before that the traversal never reads it (every use is guarded by `size == limit`).
+    UA_DEVICE bool insert(float nd, std::uint32_t ns, std::uint32_t limit, float& radius) {
         if constexpr (epl_ak == 0) {
-            return sorted_insert<global_ak>(cells, size, limit, nd, ns);
+            const bool inserted = sorted_insert<global_ak>(cells, size, limit, nd, ns);
+            if (inserted && size == limit)
+                radius = worst();
+            return inserted;
         } else {
-            const std::uint32_t lane = lane_id();
-            std::uint32_t position = 0; // lower_bound: entries strictly smaller (the +inf padding never is)
+            // lower_bound: entries strictly smaller (the +inf padding never is). Straight-line on purpose: in this
+            // scalar-heavy code a taken branch costs more than the ballot it would skip.
+            std::uint32_t position = 0;
 #pragma unroll
-            for (int i = 0; i < epl_ak; ++i)
-                position += popcount64(ballot(d[i] < nd));
+            for (int r = 0; r < epl_ak; ++r)
+                position += popcount64(ballot(d[r] < nd));
             if (position == limit)
                 return false;
-            const float carry_d = __shfl_up(d[epl_ak - 1], 1, 64);
-            const std::uint32_t carry_s = __shfl_up(s[epl_ak - 1], 1, 64);
-            const std::uint32_t base = lane * epl_ak;
-#pragma unroll
-            for (int i = epl_ak - 1; i >= 0; --i) {
-                const std::uint32_t g = base + i;
-                const float below_d = i > 0 ? d[i > 0 ? i - 1 : 0] : carry_d;
-                const std::uint32_t below_s = i > 0 ? s[i > 0 ? i - 1 : 0] : carry_s;
-                if (g > position)
-                    d[i] = below_d, s[i] = below_s;
-                else if (g == position)
-                    d[i] = nd, s[i] = ns;
-                if (g >= limit) // what fell off the end of a full buffer
-                    d[i] = __builtin_inff(), s[i] = none_slot_k;
+            // entries [position, last] move one cell up: inside a row to the next lane, from lane 63 to lane 0 of the next
+            // row; what leaves cell `limit - 1` of a full buffer is dropped. Rows above the last element hold padding only
+            // and rows below the landing row do not move: enter the (descending) row chain at the last row, leave it after
+            // the landing row — every row still sees the old content of the row below it.
+            // (`size` is wave-uniform by construction; saying so keeps the row chain on the scalar branch unit)
+            const std::uint32_t last = uniform_u32(size < limit ? size : limit - 1); // last element after this insert
+            shift_t shift;
+            shift.landing_row = position / 64, shift.landing_lane = position % 64;
+            shift.last_row = last / 64, shift.last_lane = last % 64;
+            shift.full = last + 1 == uniform_u32(limit);
+            shift.nd = nd, shift.ns = ns;
+#define UA_TOP_ROW(r)                                                                                                  \
+    case r:                                                                                                            \
+        if constexpr (r < epl_ak) {                                                                                    \
+            shift_row<r>(shift, radius);                                                                               \
+            if (shift.landing_row == r)                                                                                \
+                break;                                                                                                 \
+        }                                                                                                              \
+        [[fallthrough]];
+            switch (shift.last_row) {
+                UA_TOP_ROW(15)
+                UA_TOP_ROW(14)
+                UA_TOP_ROW(13)
+                UA_TOP_ROW(12)
+                UA_TOP_ROW(11)
+                UA_TOP_ROW(10)
+                UA_TOP_ROW(9)
+                UA_TOP_ROW(8)
+                UA_TOP_ROW(7)
+                UA_TOP_ROW(6)
+                UA_TOP_ROW(5)
+                UA_TOP_ROW(4)
+                UA_TOP_ROW(3)
+                UA_TOP_ROW(2)
+                UA_TOP_ROW(1)
+                UA_TOP_ROW(0)
+            default: break;
             }
-            size += size == limit ? 0u : 1u;
+#undef UA_TOP_ROW
+            size = last + 1;
             return true;
         }
+    }
+
+    struct shift_t {
+        std::uint32_t landing_row, landing_lane, last_row, last_lane, ns;
+        float nd;
+        bool full;
+    };
+
+    /// One row of an insert, branch-free: element X enters at lane L and the lanes above L take their lower neighbour's
+    /// value — in the landing row X is the new element, in the rows above it X is what left lane 63 of the row below
+    /// and L = 0. The last row also restores the +inf padding behind the last element and reports the new radius.
+    template <int r> UA_DEVICE void shift_row(const shift_t& shift, float& radius) {
+        const std::uint32_t lane = lane_id();
+        const bool landing = shift.landing_row == (std::uint32_t)r;
+        float enter_d = shift.nd;
+        std::uint32_t enter_s = shift.ns, enter_lane = shift.landing_lane;
+        if constexpr (r > 0) {
+            const float carry_d = read_lane_f32(d[r - 1], 63);
+            const std::uint32_t carry_s = read_lane_u32(s[r - 1], 63);
+            enter_d = landing ? shift.nd : carry_d;
+            enter_s = landing ? shift.ns : carry_s;
+            enter_lane = landing ? shift.landing_lane : 0u;
+        }
+        const float keep_d = d[r];
+        const std::uint32_t keep_s = s[r];
+        const float from_d = lane_below_f32(keep_d);
+        const std::uint32_t from_s = lane_below_u32(keep_s);
+        const bool is_last = shift.last_row == (std::uint32_t)r;
+        const std::uint32_t kept_lanes = is_last ? shift.last_lane : 63u;
+        float moved_d = lane > enter_lane ? from_d : lane == enter_lane ? enter_d : keep_d;
+        std::uint32_t moved_s = lane > enter_lane ? from_s : lane == enter_lane ? enter_s : keep_s;
+        moved_d = lane > kept_lanes ? __builtin_inff() : moved_d; // the dropped element, if any
+        moved_s = lane > kept_lanes ? none_slot_k : moved_s;
+        d[r] = moved_d;
+        s[r] = moved_s;
+        const float tail = read_lane_f32(moved_d, shift.last_lane);
+        radius = is_last && shift.full ? tail : radius;
     }
 
     /// top.top() — the worst kept distance (index.hpp:891). Requires size > 0.
@@ -286,13 +360,13 @@ template <int epl_ak, bool global_ak> struct top_gt {
         if constexpr (epl_ak == 0) {
             return uniform_f32(cand_distance(scratch_gt<global_ak>::load(cells + (size - 1))));
         } else {
-            const std::uint32_t index = size - 1;
-            const std::uint32_t base = lane_id() * epl_ak;
-            float mine = d[0]; // in the owning lane: the last entry whose global index does not exceed `index`
+            const std::uint32_t index = size - 1, row = index / 64, lane = index % 64;
+            float result = 0.f;
 #pragma unroll
-            for (int i = 1; i < epl_ak; ++i)
-                mine = base + i <= index ? d[i] : mine;
-            return read_lane_f32(mine, index / epl_ak);
+            for (int r = 0; r < epl_ak; ++r)
+                if ((std::uint32_t)r == row) // wave-uniform
+                    result = read_lane_f32(d[r], lane);
+            return result;
         }
     }
 
@@ -315,10 +389,10 @@ template <int epl_ak, bool global_ak> struct top_gt {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < epl_ak; ++i) {
-                const std::uint32_t g = lane_id() * epl_ak + i;
-                const float distance = d[i];       // copy the vector ELEMENTS out first: bit-casting `d[i]` itself
-                const std::uint32_t slot = s[i];   // reads element 0 of the vector
+            for (int r = 0; r < epl_ak; ++r) {
+                const std::uint32_t g = 64u * r + lane_id();
+                const float distance = d[r];       // copy the vector ELEMENTS out first: bit-casting `d[r]` itself
+                const std::uint32_t slot = s[r];   // reads element 0 of the vector
                 if (g < wanted) {
                     keys[g] = g < found ? (args.emit_slots ? (std::uint64_t)slot : ix.keys[slot]) : 0;
                     bits[g] = g < found ? __builtin_bit_cast(std::uint32_t, distance) : signaling_nan_bits_k;
@@ -666,6 +740,23 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     const std::uint32_t visits_mask = global_ak ? 0u : args.hash_cap - 1;
     const std::uint32_t visits_limit = global_ak ? 0xFFFFFFFFu : args.hash_cap - args.hash_cap / 4; // 75 % load
 
+    // diagnostic phase clock (USEARCH_AMD_PHASES=1): 0 setup+descent, 1 pop+list fetch, 2 visited set, 3 distances,
+    // 4 commit, 5 result dump
+#ifdef USEARCH_AMD_PHASES // diagnostic build only (`make PHASES=1`): the clock reads cost registers and waits
+    std::uint64_t phase_mark = args.phases ? __builtin_amdgcn_s_memtime() : 0;
+    std::uint64_t phase_ticks[6] = {0, 0, 0, 0, 0, 0};
+    std::uint32_t diagnostic_pushes = 0, diagnostic_ready = 0, diagnostic_rechecks = 0;
+    std::uint64_t diagnostic_push_ticks = 0, diagnostic_insert_ticks = 0;
+    auto tick = [&](int phase) {
+        if (args.phases) {
+            const std::uint64_t now = __builtin_amdgcn_s_memtime();
+            phase_ticks[phase] += now - phase_mark;
+            phase_mark = now;
+        }
+    };
+#else
+    auto tick = [](int) {};
+#endif
     const std::uint64_t query_row = args.query_ids ? args.query_ids[q] : q;
     const query_norm_t a2 = stage_query<metric_ak, scalar_ak, lanes_ak>(
         ix, args.queries + query_row * args.query_stride, query_lds);
@@ -688,7 +779,7 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
         computed += count;
     };
     auto allowed = [&](std::uint32_t slot) -> bool { // index_dense.hpp:2071-2081 without a user predicate
-        return !ix.has_tombstones || ix.keys[slot] != free_key_k;
+        return !ix.has_tombstones || uniform_u32(ix.keys[slot] != free_key_k ? 1u : 0u) != 0;
     };
 
     // ---- search_for_one_: greedy descent through levels max_level … 1 (index.hpp:3964-4003)
@@ -744,9 +835,18 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     heap_push<global_ak>(next, next_size, -radius, closest);
     visits_set<mode_ak>(visits, visits_mask, closest, lane == 0);
     visits_count = 1;
-    if (allowed(closest))
-        top.insert(radius, closest, ef);
+    if (allowed(closest)) {
+        float unused = radius;
+        top.insert(radius, closest, ef, unused);
+    }
 
+    const std::uint32_t cells = beam_level ? ix.m : ix.m0;
+    auto list_of = [&](std::uint32_t slot) -> const std::uint32_t* {
+        return beam_level ? ix.upper + (std::uint64_t)(ix.upper_ref[slot] + (beam_level - 1)) * ix.m
+                          : ix.nbr0 + (std::uint64_t)slot * ix.m0;
+    };
+    std::uint32_t ahead_slot = none_slot_k, ahead_cell = none_slot_k; // list tile requested ahead of its hop
+    tick(0);
     while (next_size) {
         const cand_t candidate = mem::load(next);
         const float candidate_distance = -uniform_f32(cand_distance(candidate));
@@ -755,13 +855,26 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
         heap_pop<global_ak>(next, next_size);
         ++cycles;
         const std::uint32_t expanded = uniform_u32(cand_slot(candidate));
-        const std::uint32_t* list = beam_level
-                                        ? ix.upper + (std::uint64_t)(ix.upper_ref[expanded] + (beam_level - 1)) * ix.m
-                                        : ix.nbr0 + (std::uint64_t)expanded * ix.m0;
-        const std::uint32_t cells = beam_level ? ix.m : ix.m0;
+        const std::uint32_t* list = list_of(expanded);
+        const bool list_ready = expanded == ahead_slot; // its first tile was requested one hop ago
+#ifdef USEARCH_AMD_PHASES
+        diagnostic_ready += list_ready ? 1u : 0u;
+#endif
+        const std::uint32_t ready_cell = ahead_cell;
+        std::uint32_t first_cell = none_slot_k;
+        if (!list_ready && lane < cells)
+            first_cell = list[lane];
+        // The frontier's new best is the likeliest next hop (unless this hop finds something closer): request its list now,
+        // so that the row arrives behind this hop's vector traffic instead of in front of the next hop's.
+        ahead_slot = none_slot_k;
+        if (next_size) {
+            ahead_slot = uniform_u32(cand_slot(mem::load(next)));
+            ahead_cell = lane < cells ? list_of(ahead_slot)[lane] : none_slot_k;
+        }
         for (std::uint32_t tile = 0; tile < cells; tile += 64) {
             const std::uint32_t cell = tile + lane;
-            const std::uint32_t neighbor = cell < cells ? list[cell] : none_slot_k;
+            const std::uint32_t neighbor =
+                tile == 0 ? (list_ready ? ready_cell : first_cell) : (cell < cells ? list[cell] : none_slot_k);
             const bool present = neighbor != none_slot_k;
             const std::uint32_t present_count = popcount64(ballot(present));
             if (!present_count)
@@ -771,8 +884,10 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                 break;
             }
             // visits.set(successor) for the whole tile at once; duplicates inside a list were removed on upload
+            tick(1);
             const bool fresh = visits_set<mode_ak>(visits, visits_mask, neighbor, present);
             const std::uint64_t fresh_mask = ballot(fresh);
+            tick(2);
             const std::uint32_t count = popcount64(fresh_mask);
             visits_count += count;
             if (!count)
@@ -781,6 +896,7 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                 mem::store(cand_slots + rank_below(fresh_mask, lane), neighbor); // keeps list order
             wave_sync<global_ak>();
             measure(count);
+            tick(3);
 
             // commit in list order with the reference's tests (index.hpp:4233-4240)
             const float mine = lane < count ? mem::load(cand_distances + lane) : 0.f;
@@ -790,17 +906,30 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                 const std::uint32_t i = (std::uint32_t)__ffsll((long long)pending) - 1;
                 pending &= pending - 1;
                 const float d = read_lane_f32(mine, i);
+#ifdef USEARCH_AMD_PHASES
+                ++diagnostic_rechecks;
+#endif
                 if (!(top.size < ef || d < radius))
                     continue;
                 const std::uint32_t successor = read_lane_u32(mine_slot, i);
+#ifdef USEARCH_AMD_PHASES
+                ++diagnostic_pushes;
+                const std::uint64_t t0 = __builtin_amdgcn_s_memtime();
+#endif
                 heap_push<global_ak>(next, next_size, -d, successor);
-                if (allowed(successor)) {
-                    top.insert(d, successor, ef);
-                    radius = top.worst(); // top.top() = worst kept
-                }
+#ifdef USEARCH_AMD_PHASES
+                const std::uint64_t t1 = __builtin_amdgcn_s_memtime();
+#endif
+                if (allowed(successor))
+                    top.insert(d, successor, ef, radius); // radius = top.top() once full
+#ifdef USEARCH_AMD_PHASES
+                const std::uint64_t t2 = __builtin_amdgcn_s_memtime();
+                diagnostic_push_ticks += t1 - t0, diagnostic_insert_ticks += t2 - t1;
+#endif
             }
             peak_next = next_size > peak_next ? next_size : peak_next;
             wave_sync<global_ak>();
+            tick(4);
         }
         if (overflow)
             break;
@@ -814,6 +943,19 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     }
     const std::uint32_t found = top.size < wanted ? top.size : wanted;
     top.dump(ix, args, q, found, wanted);
+    tick(5);
+#ifdef USEARCH_AMD_PHASES
+    if (args.phases && lane == 0) {
+#pragma unroll
+        for (int phase = 0; phase < 6; ++phase)
+            atomicAdd(args.phases + phase, (unsigned long long)phase_ticks[phase]);
+        atomicAdd(args.phases + 6, (unsigned long long)diagnostic_pushes);
+        atomicAdd(args.phases + 7, (unsigned long long)diagnostic_ready);
+        atomicAdd(args.phases + 8, (unsigned long long)diagnostic_push_ticks);
+        atomicAdd(args.phases + 9, (unsigned long long)diagnostic_insert_ticks);
+        atomicAdd(args.phases + 10, (unsigned long long)diagnostic_rechecks);
+    }
+#endif
     if (lane == 0) {
         args.counts[q] = found;
         args.visited[q] = cycles;
@@ -837,15 +979,19 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
  *  (`unroll`) against how many waves per SIMD the register allocator must leave room for (`waves`).
  */
 enum kernel_variant_t : int {
-    variant_u4_w4_k = 0,  ///< 4 loads in flight, ≤ 128 VGPRs: 16 waves per CU
-    variant_u8_w3_k = 1,  ///< 8 loads in flight, ≤ 168 VGPRs: 12 waves per CU (8 loads under 128 VGPRs spills: measured 2× slower)
-    variant_u12_w2_k = 2, ///< 12 loads in flight (a whole 768-d f16 row per lane group), ≤ 256 VGPRs: 8 waves per CU
+    variant_u4_w4_k = 0,  ///< 4 loads in flight per lane
+    variant_u8_w3_k = 1,  ///< 8 loads in flight (8 loads under 128 VGPRs spills: measured 2× slower)
+    variant_u12_w2_k = 2, ///< 12 loads in flight (a whole 768-d f16 row per lane group)
 };
 constexpr int variant_unroll(int v) { return v == variant_u4_w4_k ? 4 : v == variant_u12_w2_k ? 12 : 8; }
-constexpr int variant_waves(int v) { return v == variant_u12_w2_k ? 2 : v == variant_u8_w3_k ? 3 : 4; }
+/// Waves per SIMD the register budget of an instantiation is cut for (512 VGPRs per SIMD lane: 128 → 4, 168 → 3, 256 → 2);
+/// from the allocations the compiler reports for the widest rows (cos, G = 8) with `top` in `epl` register rows.
+constexpr int kernel_waves(int variant, int epl) {
+    return variant == variant_u4_w4_k ? (epl >= 8 ? 3 : 4) : variant == variant_u8_w3_k ? (epl >= 16 ? 2 : 3) : 2;
+}
 
 template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak>
-__global__ __launch_bounds__(64, variant_waves(variant_ak)) void search_kernel(const snapshot_view_t ix,
+__global__ __launch_bounds__(64, kernel_waves(variant_ak, epl_ak)) void search_kernel(const snapshot_view_t ix,
                                                                                const search_args_t args) {
     constexpr int unroll_ak = variant_unroll(variant_ak);
     extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
@@ -952,8 +1098,7 @@ __global__ __launch_bounds__(64) void exact_kernel(const snapshot_view_t ix, con
             const float d = read_lane_f32(mine, i);
             if (top.size == wanted && d > worst)
                 continue;
-            if (top.insert(d, read_lane_u32(mine_slot, i), wanted))
-                worst = top.worst();
+            top.insert(d, read_lane_u32(mine_slot, i), wanted, worst);
         }
         wave_sync<false>();
     }

@@ -22,7 +22,7 @@ hipError_t launch_search_one(const launch_params_t& p, const snapshot_view_t& vi
     return hipGetLastError();
 }
 
-/// `top` in registers with 1 / 4 / 8 entries per lane (expansion ≤ 64 / 256 / 512), or in scratch memory (0).
+/// `top` in registers with 1 / 4 / 8 / 16 entries per lane (expansion ≤ 64 / 256 / 512 / 1024), or in scratch memory (0).
 template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak>
 hipError_t launch_search_epl(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
     switch (p.entries_per_lane) {
@@ -30,6 +30,7 @@ hipError_t launch_search_epl(const launch_params_t& p, const snapshot_view_t& vi
     case 1: return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 1>(p, view, args);
     case 4: return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 4>(p, view, args);
     case 8: return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 8>(p, view, args);
+    case 16: return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 16>(p, view, args);
     default: return hipErrorInvalidValue;
     }
 }
