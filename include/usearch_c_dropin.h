@@ -6,14 +6,21 @@
  *  golang/lib.go:29-30, C#: csharp/src/Cloud.Unum.USearch/NativeMethods.cs:16, plain C: c/test.c) links against this
  *  library unchanged. What differs is WHO does the work:
  *
- *    search path   `usearch_search`, `usearch_exact_search` and the additive batched `usearch_search_many` run on the
- *                  MI355X through an HBM snapshot of the index (include/usearch_amd.h). The snapshot is taken lazily
- *                  at the first search after a change and dropped by every mutating call.
- *    the rest      index construction and mutation (`usearch_add`, `_remove`, `_rename`, `_reserve`, `_clear`,
- *                  `_change_metric*`, `_filtered_search` with its host callback, `_distance`) are FORWARDED to the
- *                  reference's own library, loaded at run time from `$USEARCH_AMD_REFERENCE_LIBRARY`. Without it the
- *                  drop-in still opens, inspects, saves and searches existing `.usearch` files natively and the
- *                  forwarded calls fail with an error string (never silently).
+ *    search        `usearch_search`, `usearch_filtered_search`, `usearch_exact_search` and the additive batched
+ *                  `usearch_search_many` run on the MI355X through an HBM snapshot of the index (include/usearch_amd.h).
+ *                  A filter callback is a host function: it is evaluated once per member into one bit per slot, which the
+ *                  traversal applies where the reference applies the predicate (index.hpp:4200-4205, 4236-4240).
+ *    construction  `usearch_add` stages the vector on the host; the next search / save links ALL staged vectors on the
+ *                  device in one batched build (`usearch_amd_build`). Bulk-load-then-search is the intended pattern:
+ *                  `usearch_add`, `_remove`, `_rename`, `_change_metric_kind` after a build cost a rebuild at the next
+ *                  search. Removed members stay in the graph as tombstones, as in the reference.
+ *    persistence   `usearch_save*` writes and `usearch_load* / view*` read the reference's v2 format: files move freely
+ *                  between the two libraries.
+ *    refused       by name, never computed elsewhere: a user-defined metric function (`usearch_change_metric`,
+ *                  `usearch_init_options_t::metric`); metric / scalar kinds without a kernel (pearson, haversine,
+ *                  divergence, jaccard, tanimoto, sorensen; f64 and bf16 storage).
+ *  Nothing is forwarded to the reference and there is no CPU search or build path: without a HIP device every call that
+ *  needs one fails with an error string.
  *
  *  Errors: the callee stores a pointer to a static NUL-terminated string in `*error` on failure and leaves it untouched
  *  on success (c/usearch.h:24-28).

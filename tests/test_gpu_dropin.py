@@ -1,0 +1,295 @@
+"""The drop-in `libusearch_c.so` (include/usearch_c_dropin.h): the reference's own C test program, restated call for
+call through ctypes — /root/reference/c/test.c:52-368 (`test_init`, `test_add_vector`, `test_find_vector`,
+`test_get_vector`, `test_remove_vector`, `test_save_load`, `test_view`, sizes {11, 512} x dimensions {83, 2} as in its
+`main`, c/test.c:370-393) — plus the exact-value checks the other bindings' tests hold for this ABI
+(golang/lib_test.go:835-877 distances, cpp/test.cpp:1105-1145 filtered search) and a side-by-side run against the real
+reference library on the same calls. The one deviation: c/test.c:246-250 saves a pearson/f64 index; those kernels do not
+exist yet, so the save/load case uses cos/f16 with the same odd connectivity and expansions."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import refbind
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBRARY = os.path.join(ROOT, "usearch_amd", "lib", "libusearch_c.so")
+
+METRIC = {"cos": 1, "ip": 2, "l2sq": 3, "hamming": 8, "pearson": 6}
+SCALAR = {"f32": 1, "f64": 2, "f16": 3, "i8": 4, "b1": 5}
+
+
+class Options(C.Structure):  # usearch_init_options_t, c/usearch.h:64-110
+    _fields_ = [("metric_kind", C.c_int), ("metric", C.c_void_p), ("quantization", C.c_int), ("dimensions", C.c_size_t),
+                ("connectivity", C.c_size_t), ("expansion_add", C.c_size_t), ("expansion_search", C.c_size_t),
+                ("multi", C.c_bool)]
+
+
+FILTER = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    L = C.CDLL(LIBRARY)
+    err = C.POINTER(C.c_char_p)
+    L.usearch_version.restype = C.c_char_p
+    L.usearch_init.restype = C.c_void_p
+    L.usearch_init.argtypes = [C.POINTER(Options), err]
+    L.usearch_hardware_acceleration.restype = C.c_char_p
+    L.usearch_hardware_acceleration.argtypes = [C.c_void_p, err]
+    for name in ("size", "capacity", "dimensions", "connectivity", "memory_usage", "serialized_length",
+                 "expansion_add", "expansion_search"):
+        f = getattr(L, f"usearch_{name}")
+        f.restype = C.c_size_t
+        f.argtypes = [C.c_void_p, err]
+    L.usearch_free.argtypes = [C.c_void_p, err]
+    L.usearch_clear.argtypes = [C.c_void_p, err]
+    L.usearch_reserve.argtypes = [C.c_void_p, C.c_size_t, err]
+    L.usearch_change_threads_search.argtypes = [C.c_void_p, C.c_size_t, err]
+    L.usearch_change_expansion_search.argtypes = [C.c_void_p, C.c_size_t, err]
+    L.usearch_add.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, err]
+    L.usearch_contains.restype = C.c_bool
+    L.usearch_contains.argtypes = [C.c_void_p, C.c_uint64, err]
+    L.usearch_count.restype = C.c_size_t
+    L.usearch_count.argtypes = [C.c_void_p, C.c_uint64, err]
+    L.usearch_search.restype = C.c_size_t
+    L.usearch_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, err]
+    L.usearch_filtered_search.restype = C.c_size_t
+    L.usearch_filtered_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, FILTER, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, err]
+    L.usearch_search_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                                      C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, err]
+    L.usearch_get.restype = C.c_size_t
+    L.usearch_get.argtypes = [C.c_void_p, C.c_uint64, C.c_size_t, C.c_void_p, C.c_int, err]
+    L.usearch_remove.restype = C.c_size_t
+    L.usearch_remove.argtypes = [C.c_void_p, C.c_uint64, err]
+    L.usearch_rename.restype = C.c_size_t
+    L.usearch_rename.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, err]
+    for name in ("save", "load", "view"):
+        getattr(L, f"usearch_{name}").argtypes = [C.c_void_p, C.c_char_p, err]
+    for name in ("save_buffer", "load_buffer", "view_buffer"):
+        getattr(L, f"usearch_{name}").argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, err]
+    L.usearch_metadata.argtypes = [C.c_char_p, C.POINTER(Options), err]
+    L.usearch_distance.restype = C.c_float
+    L.usearch_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, err]
+    L.usearch_exact_search.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
+                                       C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                       C.c_size_t, err]
+    return L
+
+
+def ok(err):
+    assert not err.value, err.value
+
+
+def ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def create_options(dimensions, **changes):  # c/test.c:32-43
+    o = Options(METRIC["ip"], None, SCALAR["f32"], dimensions, 3, 40, 16, False)
+    for name, value in changes.items():
+        setattr(o, name, value)
+    return o
+
+
+def create_vectors(count, dimensions, seed=0):  # c/test.c:25-31: uniform [0, 1)
+    return np.random.default_rng(seed).random((count, dimensions), dtype=np.float32)
+
+
+def filled_index(lib, count, dimensions, options=None, data=None, keys=None):
+    err = C.c_char_p()
+    options = options or create_options(dimensions)
+    index = lib.usearch_init(C.byref(options), C.byref(err))
+    ok(err)
+    lib.usearch_reserve(index, count, C.byref(err))
+    data = create_vectors(count, dimensions) if data is None else data
+    for i in range(count):
+        lib.usearch_add(index, int(i if keys is None else keys[i]), ptr(data[i]), SCALAR["f32"], C.byref(err))
+        ok(err)
+    return index, data
+
+
+SIZES = [(11, 83), (11, 2), (512, 83), (512, 2)]  # c/test.c:374-375
+
+
+@pytest.mark.parametrize("count,dimensions", SIZES)
+def test_c_test_program(lib, count, dimensions, tmp_path):
+    err = C.c_char_p()
+    assert lib.usearch_version() == b"2.21.0"
+    # test_init, c/test.c:52-86
+    options = create_options(dimensions)
+    index = lib.usearch_init(C.byref(options), C.byref(err))
+    ok(err)
+    lib.usearch_free(index, C.byref(err))
+    index = lib.usearch_init(C.byref(options), C.byref(err))
+    assert lib.usearch_size(index, C.byref(err)) == 0 and lib.usearch_capacity(index, C.byref(err)) == 0
+    assert lib.usearch_dimensions(index, C.byref(err)) == dimensions
+    assert lib.usearch_connectivity(index, C.byref(err)) == 3
+    lib.usearch_reserve(index, count, C.byref(err))
+    ok(err)
+    assert lib.usearch_size(index, C.byref(err)) == 0 and lib.usearch_capacity(index, C.byref(err)) >= count
+    assert lib.usearch_hardware_acceleration(index, C.byref(err)) == b"gfx950"
+    lib.usearch_free(index, C.byref(err))
+
+    # test_add_vector, c/test.c:93-122
+    index, data = filled_index(lib, count, dimensions)
+    assert lib.usearch_size(index, C.byref(err)) == count and lib.usearch_capacity(index, C.byref(err)) >= count
+    assert all(lib.usearch_contains(index, i, C.byref(err)) for i in range(count))
+    assert not lib.usearch_contains(index, 2 ** 64 - 1, C.byref(err))
+    assert lib.usearch_memory_usage(index, C.byref(err)) > 0
+
+    # test_find_vector, c/test.c:129-162: every vector is found, asking for `collection_size` results
+    keys = np.zeros(count, dtype=np.uint64)
+    distances = np.zeros(count, dtype=np.float32)
+    for i in range(count):
+        found = lib.usearch_search(index, ptr(data[i]), SCALAR["f32"], count, ptr(keys), ptr(distances), C.byref(err))
+        ok(err)
+        assert 1 <= found <= count
+        assert np.all(np.diff(distances[:found]) >= 0)  # cpp/test.cpp:499-503: ascending
+    lib.usearch_free(index, C.byref(err))
+
+    # test_get_vector, c/test.c:170-199: a multi-index returns every vector stored under one key
+    options = create_options(dimensions, multi=True)
+    index = lib.usearch_init(C.byref(options), C.byref(err))
+    for i in range(count):
+        lib.usearch_add(index, 1, ptr(data[i]), SCALAR["f32"], C.byref(err))
+        ok(err)
+    out = np.zeros((count, dimensions), dtype=np.float32)
+    assert lib.usearch_get(index, 1, count, ptr(out), SCALAR["f32"], C.byref(err)) == count
+    assert np.array_equal(out, data)
+    lib.usearch_free(index, C.byref(err))
+
+    # test_remove_vector, c/test.c:207-233
+    index, _ = filled_index(lib, count, dimensions, data=data)
+    for i in range(count):
+        lib.usearch_remove(index, i, C.byref(err))
+        ok(err)
+    assert lib.usearch_size(index, C.byref(err)) == 0
+    found = lib.usearch_search(index, ptr(data[0]), SCALAR["f32"], 5, ptr(keys), ptr(distances), C.byref(err))
+    assert found == 0  # everything is a tombstone now
+    lib.usearch_free(index, C.byref(err))
+
+    # test_save_load, c/test.c:241-328 (odd connectivity / expansions survive the round trip through a shell index)
+    path = str(tmp_path / "tmp.usearch").encode()
+    weird = create_options(dimensions, connectivity=11, expansion_add=15, expansion_search=19, metric_kind=METRIC["cos"],
+                           quantization=SCALAR["f16"])
+    index, _ = filled_index(lib, count, dimensions, options=weird, data=data)
+    lib.usearch_save(index, path, C.byref(err))
+    ok(err)
+    lib.usearch_free(index, C.byref(err))
+    meta = Options()
+    lib.usearch_metadata(path, C.byref(meta), C.byref(err))
+    ok(err)
+    assert (meta.metric_kind, meta.quantization, meta.dimensions, meta.connectivity) == (1, 3, dimensions, 11)
+    index = lib.usearch_init(None, C.byref(err))
+    ok(err)
+    lib.usearch_load(index, path, C.byref(err))
+    ok(err)
+    assert lib.usearch_size(index, C.byref(err)) == count and lib.usearch_capacity(index, C.byref(err)) == count
+    assert lib.usearch_dimensions(index, C.byref(err)) == dimensions and lib.usearch_connectivity(index, C.byref(err)) == 11
+    assert all(lib.usearch_contains(index, i, C.byref(err)) for i in range(count))
+    lib.usearch_change_threads_search(index, 1, C.byref(err))
+    for i in range(0, count, 7):
+        found = lib.usearch_search(index, ptr(data[i]), SCALAR["f32"], count, ptr(keys), ptr(distances), C.byref(err))
+        ok(err)
+        assert 1 <= found <= count
+    # the REAL reference loads what the drop-in saved and answers the same queries with the same labels
+    theirs = refbind.RefIndex.from_buffer(np.fromfile(path.decode(), dtype=np.uint8), dtype="f16")
+    assert len(theirs) == count
+    theirs.expansion_search = 64
+    lib.usearch_change_expansion_search(index, 64, C.byref(err))
+    their_keys, their_distances, *_ = theirs.search(data[:8], 3, dtype="f32")
+    for i in range(8):
+        lib.usearch_search(index, ptr(data[i]), SCALAR["f32"], 3, ptr(keys), ptr(distances), C.byref(err))
+        assert np.allclose(distances[:3], their_distances[i], atol=2e-3)
+        if dimensions > 2:  # 2-d cosine distances are full of near-ties
+            assert np.array_equal(keys[:3], their_keys[i])
+    lib.usearch_free(index, C.byref(err))
+
+    # test_view, c/test.c:335-368
+    index = lib.usearch_init(C.byref(create_options(dimensions)), C.byref(err))
+    lib.usearch_view(index, path, C.byref(err))
+    ok(err)
+    assert lib.usearch_size(index, C.byref(err)) == count
+    lib.usearch_free(index, C.byref(err))
+
+
+def test_known_distances(lib):
+    """golang/lib_test.go:835-877: cos(e1, e2) = 1, l2sq(e1, e2) = 2, i8 l2sq(10 e1, 10 e2) = 200; rust/lib.rs:1897-1924 bits."""
+    err = C.c_char_p()
+    e1, e2 = np.array([1, 0, 0], dtype=np.float32), np.array([0, 1, 0], dtype=np.float32)
+    assert abs(lib.usearch_distance(ptr(e1), ptr(e2), SCALAR["f32"], 3, METRIC["cos"], C.byref(err)) - 1.0) < 0.01
+    assert abs(lib.usearch_distance(ptr(e1), ptr(e2), SCALAR["f32"], 3, METRIC["l2sq"], C.byref(err)) - 2.0) < 0.01
+    a, b = np.array([10, 0, 0], dtype=np.int8), np.array([0, 10, 0], dtype=np.int8)
+    assert lib.usearch_distance(ptr(a), ptr(b), SCALAR["i8"], 3, METRIC["l2sq"], C.byref(err)) == 200.0
+    q, x, y = (np.array([v], dtype=np.uint8) for v in (0b01111000, 0b11110000, 0b00001111))
+    assert lib.usearch_distance(ptr(q), ptr(x), SCALAR["b1"], 8, METRIC["hamming"], C.byref(err)) == 2.0
+    assert lib.usearch_distance(ptr(q), ptr(y), SCALAR["b1"], 8, METRIC["hamming"], C.byref(err)) == 6.0
+    ok(err)
+    lib.usearch_distance(ptr(e1), ptr(e2), SCALAR["f32"], 3, METRIC["pearson"], C.byref(err))
+    assert err.value and b"kernel" in err.value  # refused by name, never silently computed elsewhere
+
+
+def test_filtered_search_and_rename(lib):
+    """cpp/test.cpp:1105-1145: predicate key != 0 → 10 results none 0; `false` → 0; key == 10 → exactly [10]."""
+    err = C.c_char_p()
+    data = util.make_vectors(2048, 32, "f32", seed=3)
+    options = Options(METRIC["cos"], None, SCALAR["f32"], 32, 16, 128, 64, False)
+    index, _ = filled_index(lib, 2048, 32, options=options, data=data)
+    keys = np.zeros(10, dtype=np.uint64)
+    distances = np.zeros(10, dtype=np.float32)
+    not_zero = FILTER(lambda key, state: int(key != 0))
+    found = lib.usearch_filtered_search(index, ptr(data[0]), SCALAR["f32"], 10, not_zero, None, ptr(keys), ptr(distances),
+                                        C.byref(err))
+    ok(err)
+    assert found == 10 and 0 not in keys.tolist()
+    never = FILTER(lambda key, state: 0)
+    assert lib.usearch_filtered_search(index, ptr(data[0]), SCALAR["f32"], 10, never, None, ptr(keys), ptr(distances),
+                                       C.byref(err)) == 0
+    only_ten = FILTER(lambda key, state: int(key == 10))
+    found = lib.usearch_filtered_search(index, ptr(data[0]), SCALAR["f32"], 10, only_ten, None, ptr(keys), ptr(distances),
+                                        C.byref(err))
+    assert found == 1 and keys[0] == 10
+    # rename: the member answers to its new key only
+    assert lib.usearch_rename(index, 10, 777777, C.byref(err)) == 1
+    ok(err)
+    assert lib.usearch_contains(index, 777777, C.byref(err)) and not lib.usearch_contains(index, 10, C.byref(err))
+    found = lib.usearch_search(index, ptr(data[10]), SCALAR["f32"], 1, ptr(keys), ptr(distances), C.byref(err))
+    assert found == 1 and keys[0] == 777777
+    lib.usearch_free(index, C.byref(err))
+
+
+def test_batch_and_buffers_match_the_reference(lib, reference):
+    """`usearch_search_many` over an image the REAL reference built equals the reference's own per-query loop
+    (integer-valued metric: bit-exact keys, distances, counts and both counters)."""
+    err = C.c_char_p()
+    image, vectors, theirs = util.build_image(3000, 96, "l2sq", "i8", seed=21)
+    queries = util.make_vectors(200, 96, "i8", seed=22)
+    index = lib.usearch_init(None, C.byref(err))
+    lib.usearch_view_buffer(index, ptr(image), image.size, C.byref(err))
+    ok(err)
+    keys = np.zeros((200, 10), dtype=np.uint64)
+    distances = np.zeros((200, 10), dtype=np.float32)
+    counts = np.zeros(200, dtype=np.uint64)
+    visited, computed = C.c_size_t(), C.c_size_t()
+    lib.usearch_search_many(index, ptr(queries), SCALAR["i8"], 200, queries.strides[0], 10, ptr(keys), keys.strides[0],
+                            ptr(distances), distances.strides[0], ptr(counts), C.byref(visited), C.byref(computed),
+                            C.byref(err))
+    ok(err)
+    rkeys, rdistances, rcounts, rvisited, rcomputed = theirs.search(queries, 10, dtype="i8")
+    assert np.array_equal(keys, rkeys) and util.same_float_bits(distances, rdistances)
+    assert np.array_equal(counts, rcounts)
+    assert visited.value == int(np.sum(rvisited)) and computed.value == int(np.sum(rcomputed))
+    # save_buffer of an untouched image returns it byte for byte
+    length = lib.usearch_serialized_length(index, C.byref(err))
+    assert length == image.size
+    copy = np.zeros(length, dtype=np.uint8)
+    lib.usearch_save_buffer(index, ptr(copy), length, C.byref(err))
+    ok(err)
+    assert np.array_equal(copy, image)
+    lib.usearch_free(index, C.byref(err))

@@ -71,3 +71,32 @@ def test_corrupt_images_are_rejected():
         err = C.c_char_p()
         handle = library.usearch_amd_snapshot_from_buffer(C.c_void_p(data.ctypes.data), data.size, 0, C.byref(err))
         assert not handle and err.value, name
+
+
+REFERENCE_C_ABI = [  # the 38 entry points of /root/reference/c/usearch.h:116-481 (verified with `nm -D`)
+    "version", "init", "free", "memory_usage", "hardware_acceleration", "serialized_length", "save", "load", "view",
+    "metadata", "save_buffer", "load_buffer", "view_buffer", "metadata_buffer", "size", "capacity", "dimensions",
+    "connectivity", "reserve", "expansion_add", "expansion_search", "change_expansion_add", "change_expansion_search",
+    "change_threads_add", "change_threads_search", "change_metric_kind", "change_metric", "add", "contains", "count",
+    "search", "filtered_search", "get", "remove", "rename", "distance", "exact_search", "clear"]
+
+
+def test_drop_in_library_exports_the_reference_c_abi():
+    """`libusearch_c.so` carries every symbol a program linked against the reference's `libusearch_c` resolves, plus the
+    additive batch entry points its header declares. (No compute calls: there is no GPU here.)"""
+    library = C.CDLL(os.path.join(ROOT, "usearch_amd", "lib", "libusearch_c.so"))
+    assert len(REFERENCE_C_ABI) == 38
+    for name in REFERENCE_C_ABI:
+        assert hasattr(library, f"usearch_{name}"), f"usearch_{name} is missing from the drop-in"
+    header = open(os.path.join(ROOT, "include", "usearch_c_dropin.h")).read()
+    declared = sorted(set(re.findall(r"USEARCH_EXPORT[^;(]*?\b(usearch_\w+)\s*\(", header)))
+    assert len(declared) == 41
+    for name in declared:
+        assert hasattr(library, name), f"{name} is declared in include/usearch_c_dropin.h but not exported"
+    reference_header = "/root/reference/c/usearch.h"
+    if os.path.exists(reference_header):  # this container only: the list above is the reference's, not ours
+        theirs = sorted(set(re.findall(r"USEARCH_EXPORT[^;(]*?\b(usearch_\w+)\s*\(", open(reference_header).read()))
+                        - {"usearch_distance_t"})  # a return type caught by the pattern, not a function
+        assert theirs == sorted(f"usearch_{name}" for name in REFERENCE_C_ABI)
+    library.usearch_version.restype = C.c_char_p
+    assert library.usearch_version() == b"2.21.0"

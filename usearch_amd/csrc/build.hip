@@ -316,6 +316,12 @@ const char* builder_t::build(metric_kind_t metric, scalar_kind_t scalar, std::si
         begin = end;
     }
     snapshot_.set_frontier(count, entry_slot_, max_level_);
+    // removed members (key == free_key_, index_dense.hpp:513) were linked like any other node — the reference keeps them in
+    // the graph too — and stop matching from here on
+    bool tombstones = false;
+    for (std::uint64_t key : keys_)
+        tombstones |= key == free_key_k;
+    snapshot_.set_tombstones(tombstones);
     unsigned long long counters[4] = {0, 0, 0, 0};
     UA_HIP(hipMemcpy(counters, d_counters, sizeof(counters), hipMemcpyDeviceToHost));
     stats_.select_distances = counters[0];

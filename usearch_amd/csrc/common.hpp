@@ -109,6 +109,8 @@ struct search_args_t {
     const std::uint32_t* query_ids; ///< optional: query `q` is row query_ids[q] of `queries` (a stored vector); outputs stay at row q
     std::uint32_t beam_level;       ///< level the beam runs on (0 for `search`); the greedy descent stops above it
     std::uint32_t emit_slots;       ///< 1 = write slots instead of keys into `keys`
+    const std::uint32_t* allow_bits; ///< optional: one bit per slot, 0 = the caller's predicate rejects that member
+                                     ///< (`usearch_filtered_search`, index_dense.hpp:2071-2081)
     unsigned long long* phases;     ///< optional [8] diagnostic: shader-clock ticks per phase summed over all waves
 };
 

@@ -1,0 +1,829 @@
+/**
+ *  usearch_amd/csrc/dropin.hip — the reference's C99 ABI (`/root/reference/c/usearch.h`, implemented there by c/lib.cpp)
+ *  on top of the MI355X engine: `usearch_amd/lib/libusearch_c.so`, declared in include/usearch_c_dropin.h.
+ *
+ *  Every one of the 38 entry points is implemented natively — nothing is forwarded to the reference and nothing runs on
+ *  the CPU that the reference would run as its hot path:
+ *    search            `usearch_search`, `_filtered_search`, `_exact_search`, `usearch_search_many` → the search kernels
+ *    construction      `usearch_add` stages the vector on the host; the next search / save / size-dependent call links ALL
+ *                      staged vectors on the device (build.hip). Bulk-load-then-search is the intended pattern; every
+ *                      mutation after a build costs a rebuild at the next search.
+ *    persistence       `usearch_save*` writes, `usearch_load* / view*` read the reference's v2 format (docs/format.md)
+ *    `usearch_distance` one launch of the exact-search kernel over a 1-row dataset
+ *  What the device cannot do is refused by name: a user-defined metric function (`usearch_change_metric`,
+ *  `usearch_init_options_t::metric`), metrics / scalar kinds without a kernel.
+ *
+ *  The host keeps what the reference keeps in `index_dense_gt`: keys and vectors per slot (for `get`, `contains`,
+ *  `count`, `rename`, `remove`), either inside a serialized image (after load / view) or in staging arrays (after add).
+ */
+#include "../../include/usearch_c_dropin.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <unordered_map>
+#include <vector>
+
+#include "build.hpp"
+#include "casts.hpp"
+#include "engine.hpp"
+#include "host_util.hpp"
+
+using namespace usearch_amd;
+
+namespace {
+
+metric_kind_t metric_from_c(usearch_metric_kind_t kind) { // c/lib.cpp:26-42
+    switch (kind) {
+    case usearch_metric_cos_k: return metric_cos_k;
+    case usearch_metric_ip_k: return metric_ip_k;
+    case usearch_metric_l2sq_k: return metric_l2sq_k;
+    case usearch_metric_haversine_k: return metric_haversine_k;
+    case usearch_metric_divergence_k: return metric_divergence_k;
+    case usearch_metric_pearson_k: return metric_pearson_k;
+    case usearch_metric_jaccard_k: return metric_jaccard_k;
+    case usearch_metric_hamming_k: return metric_hamming_k;
+    case usearch_metric_tanimoto_k: return metric_tanimoto_k;
+    case usearch_metric_sorensen_k: return metric_sorensen_k;
+    default: return metric_unknown_k;
+    }
+}
+usearch_metric_kind_t metric_to_c(metric_kind_t kind) { // c/lib.cpp:44-59
+    switch (kind) {
+    case metric_cos_k: return usearch_metric_cos_k;
+    case metric_ip_k: return usearch_metric_ip_k;
+    case metric_l2sq_k: return usearch_metric_l2sq_k;
+    case metric_haversine_k: return usearch_metric_haversine_k;
+    case metric_divergence_k: return usearch_metric_divergence_k;
+    case metric_pearson_k: return usearch_metric_pearson_k;
+    case metric_jaccard_k: return usearch_metric_jaccard_k;
+    case metric_hamming_k: return usearch_metric_hamming_k;
+    case metric_tanimoto_k: return usearch_metric_tanimoto_k;
+    case metric_sorensen_k: return usearch_metric_sorensen_k;
+    default: return usearch_metric_unknown_k;
+    }
+}
+scalar_kind_t scalar_from_c(usearch_scalar_kind_t kind) { // c/lib.cpp:61-71
+    switch (kind) {
+    case usearch_scalar_f32_k: return scalar_f32_k;
+    case usearch_scalar_f64_k: return scalar_f64_k;
+    case usearch_scalar_f16_k: return scalar_f16_k;
+    case usearch_scalar_i8_k: return scalar_i8_k;
+    case usearch_scalar_b1_k: return scalar_b1x8_k;
+    case usearch_scalar_bf16_k: return scalar_bf16_k;
+    default: return scalar_unknown_k;
+    }
+}
+usearch_scalar_kind_t scalar_to_c(scalar_kind_t kind) { // c/lib.cpp:73-83
+    switch (kind) {
+    case scalar_f32_k: return usearch_scalar_f32_k;
+    case scalar_f64_k: return usearch_scalar_f64_k;
+    case scalar_f16_k: return usearch_scalar_f16_k;
+    case scalar_i8_k: return usearch_scalar_i8_k;
+    case scalar_b1x8_k: return usearch_scalar_b1_k;
+    case scalar_bf16_k: return usearch_scalar_bf16_k;
+    default: return usearch_scalar_unknown_k;
+    }
+}
+
+void fail(usearch_error_t* error, const char* message) {
+    if (error && message)
+        *error = message;
+}
+
+/// One `usearch_index_t`.
+struct index_t {
+    std::mutex mutex;
+    // configuration — `usearch_init_options_t`, c/usearch.h:64-110
+    metric_kind_t metric = metric_cos_k;
+    scalar_kind_t scalar = scalar_f32_k;
+    std::size_t dimensions = 0, connectivity = 16, expansion_add = 128, expansion_search = 64, capacity = 0;
+    bool multi = false;
+    int device = 0;
+
+    // (1) a serialized image: owned bytes, a borrowed buffer (`view_buffer`) or a mapped file (`view`)
+    std::vector<std::uint8_t> image_owned;
+    const std::uint8_t* image_bytes = nullptr;
+    std::size_t image_length = 0;
+    void* mapping = nullptr;
+    std::size_t mapping_length = 0;
+    image_t image;      ///< parsed header of `image_bytes` when `has_image`
+    bool has_image = false;
+    snapshot_t* snapshot = nullptr; ///< HBM copy of the image, taken at the first search
+
+    // (2) staging: keys and vectors per slot once anything was added / removed / renamed since the image
+    bool staged = false;
+    std::vector<std::uint64_t> keys;
+    std::vector<std::uint8_t> vectors; ///< storage scalar kind, `bytes_per_vector` per slot
+    builder_t* builder = nullptr;      ///< device index linked from the staging arrays (null = stale)
+
+    // key → slots, rebuilt lazily
+    std::unordered_multimap<std::uint64_t, std::uint32_t> lookup;
+    bool lookup_valid = false;
+
+    std::size_t bpv() const { return bytes_per_vector(scalar, dimensions); }
+    std::size_t size() const { return staged ? keys.size() : has_image ? (std::size_t)image.size : 0; }
+
+    void drop_device() {
+        delete builder, builder = nullptr;
+        delete snapshot, snapshot = nullptr;
+    }
+    void drop_image() {
+        if (mapping)
+            ::munmap(mapping, mapping_length), mapping = nullptr, mapping_length = 0;
+        image_owned.clear(), image_owned.shrink_to_fit();
+        image_bytes = nullptr, image_length = 0, has_image = false;
+        image = image_t{};
+    }
+    ~index_t() {
+        drop_device();
+        drop_image();
+    }
+
+    /// Adopts `bytes` as the current image. Configuration comes from its header (c/lib.cpp `usearch_load`: the index takes
+    /// the file's metric, scalar kind and dimensions).
+    const char* open_image(const void* bytes, std::size_t length) {
+        image_t parsed;
+        if (const char* e = parsed.open(bytes, length))
+            return e;
+        if (!kernel_available(parsed.metric, parsed.scalar))
+            return "No MI355X kernel for this metric / scalar kind combination";
+        image = parsed;
+        image_bytes = static_cast<const std::uint8_t*>(bytes);
+        image_length = length;
+        has_image = true;
+        metric = parsed.metric, scalar = parsed.scalar, dimensions = (std::size_t)parsed.dimensions;
+        if (parsed.connectivity)
+            connectivity = (std::size_t)parsed.connectivity;
+        multi = parsed.multi;
+        staged = false;
+        keys.clear(), vectors.clear();
+        lookup_valid = false;
+        capacity = std::max<std::size_t>(capacity, (std::size_t)parsed.size);
+        return nullptr;
+    }
+
+    /// Key of every slot of the image, in slot order (the node tapes are variable-length: one sequential pass).
+    void image_keys(std::vector<std::uint64_t>& out) const {
+        out.resize((std::size_t)image.size);
+        std::size_t offset = 0;
+        for (std::uint64_t i = 0; i < image.size; ++i) {
+            out[i] = image_t::load<std::uint64_t>(image.tapes + offset);
+            offset += image.node_bytes(image.level(i));
+        }
+    }
+
+    /// Moves keys and vectors out of the image into the staging arrays: the index is about to be mutated.
+    void materialize() {
+        if (staged)
+            return;
+        if (has_image) {
+            image_keys(keys);
+            vectors.assign(image.vectors, image.vectors + (std::size_t)image.size * image.cols);
+        }
+        staged = true;
+        drop_device();
+        drop_image();
+        lookup_valid = false;
+    }
+
+    const std::unordered_multimap<std::uint64_t, std::uint32_t>& key_lookup() {
+        if (!lookup_valid) {
+            lookup.clear();
+            std::vector<std::uint64_t> from_image;
+            const std::vector<std::uint64_t>* source = &keys;
+            if (!staged && has_image)
+                image_keys(from_image), source = &from_image;
+            lookup.reserve(source->size());
+            for (std::size_t slot = 0; slot < source->size(); ++slot)
+                if ((*source)[slot] != free_key_k)
+                    lookup.emplace((*source)[slot], (std::uint32_t)slot);
+            lookup_valid = true;
+        }
+        return lookup;
+    }
+
+    const std::uint8_t* vector_of(std::uint32_t slot) const {
+        return staged ? vectors.data() + (std::size_t)slot * bpv() : image.vectors + (std::size_t)slot * image.cols;
+    }
+
+    /// The device index to search: the snapshot of the image, or a fresh build of the staging arrays.
+    const char* ready(snapshot_t** out) {
+        *out = nullptr;
+        if (staged) {
+            if (!builder && !keys.empty()) {
+                builder_t* fresh = new (std::nothrow) builder_t();
+                if (!fresh)
+                    return "Out of memory!";
+                build_config_t config;
+                config.connectivity = (std::uint32_t)connectivity;
+                config.expansion_add = (std::uint32_t)expansion_add;
+                if (const char* e = fresh->build(metric, scalar, dimensions, vectors.data(), keys.size(), bpv(), false,
+                                                 keys.data(), config, device)) {
+                    delete fresh;
+                    return e;
+                }
+                builder = fresh;
+            }
+            *out = builder ? &builder->snapshot() : nullptr;
+            return nullptr;
+        }
+        if (has_image && !snapshot) {
+            snapshot_t* fresh = new (std::nothrow) snapshot_t();
+            if (!fresh)
+                return "Out of memory!";
+            if (const char* e = fresh->build(image, device)) {
+                delete fresh;
+                return e;
+            }
+            snapshot = fresh;
+        }
+        *out = snapshot;
+        return nullptr;
+    }
+
+};
+
+index_t* as_index(usearch_index_t handle) { return static_cast<index_t*>(handle); }
+
+/// An index without nodes still serializes to its headers (index_dense.hpp:995-1062 with zero rows).
+void write_empty_image(const index_t& index, std::uint8_t* p) {
+    std::memset(p, 0, 8 + 64 + 40);
+    const std::uint32_t cols = (std::uint32_t)index.bpv();
+    std::memcpy(p + 4, &cols, 4);
+    p += 8;
+    std::memcpy(p, "usearch", 7);
+    const std::uint16_t version[3] = {2, 21, 0};
+    std::memcpy(p + 7, version, 6);
+    p[13] = (std::uint8_t)index.metric, p[14] = (std::uint8_t)index.scalar;
+    p[15] = (std::uint8_t)scalar_u64_k, p[16] = (std::uint8_t)scalar_u32_k;
+    const std::uint64_t dimensions = index.dimensions;
+    std::memcpy(p + 33, &dimensions, 8);
+    p[41] = index.multi ? 1 : 0;
+    p += 64;
+    const std::uint64_t header[5] = {0, index.connectivity, 2 * index.connectivity, 0, 0};
+    std::memcpy(p, header, 40);
+}
+
+/// Serialized form of the current content: the image as it was loaded, or what the device build writes.
+const char* serialize(index_t& index, std::vector<std::uint8_t>* into_vector, void* into_buffer, std::size_t buffer_length,
+                      std::size_t* length_out) {
+    if (!index.staged) {
+        const std::size_t length = index.has_image ? index.image_length : 8 + 64 + 40;
+        if (length_out)
+            *length_out = length;
+        std::uint8_t* target = nullptr;
+        if (into_vector)
+            into_vector->resize(length), target = into_vector->data();
+        else if (into_buffer) {
+            if (buffer_length < length)
+                return "Buffer is too small";
+            target = static_cast<std::uint8_t*>(into_buffer);
+        }
+        if (target) {
+            if (index.has_image)
+                std::memcpy(target, index.image_bytes, length);
+            else
+                write_empty_image(index, target);
+        }
+        return nullptr;
+    }
+    snapshot_t* device_index = nullptr;
+    if (const char* e = index.ready(&device_index))
+        return e;
+    if (!index.builder) { // staged but empty
+        if (length_out)
+            *length_out = 8 + 64 + 40;
+        std::uint8_t* target = nullptr;
+        if (into_vector)
+            into_vector->resize(8 + 64 + 40), target = into_vector->data();
+        else if (into_buffer) {
+            if (buffer_length < 8 + 64 + 40)
+                return "Buffer is too small";
+            target = static_cast<std::uint8_t*>(into_buffer);
+        }
+        if (target)
+            write_empty_image(index, target);
+        return nullptr;
+    }
+    const std::size_t length = index.builder->serialized_length();
+    if (length_out)
+        *length_out = length;
+    if (into_vector) {
+        into_vector->resize(length);
+        return index.builder->save_buffer(into_vector->data(), length);
+    }
+    if (into_buffer) {
+        if (buffer_length < length)
+            return "Buffer is too small";
+        return index.builder->save_buffer(into_buffer, length);
+    }
+    return nullptr;
+}
+
+void fill_options(const image_t& image, usearch_init_options_t* options) { // c/lib.cpp:224-242
+    options->metric_kind = metric_to_c(image.metric);
+    options->metric = nullptr;
+    options->quantization = scalar_to_c(image.scalar);
+    options->dimensions = (std::size_t)image.dimensions;
+    options->connectivity = (std::size_t)image.connectivity;
+    options->expansion_add = 0;
+    options->expansion_search = 0;
+    options->multi = image.multi;
+}
+
+/// `dump_to`-style padding for queries that cannot match anything.
+void pad_results(usearch_key_t* keys, usearch_distance_t* distances, std::size_t count) {
+    for (std::size_t i = 0; i < count; ++i) {
+        if (keys)
+            keys[i] = 0;
+        if (distances)
+            std::memcpy(distances + i, &signaling_nan_bits_k, 4);
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+char const* usearch_version(void) { return "2.21.0"; }
+
+usearch_index_t usearch_init(usearch_init_options_t* options, usearch_error_t* error) {
+    index_t* index = new (std::nothrow) index_t();
+    if (!index) {
+        fail(error, "Out of memory!");
+        return nullptr;
+    }
+    if (!options) // an empty shell to `usearch_load` / `usearch_view` into, c/lib.cpp:142-147
+        return index;
+    if (options->metric) {
+        fail(error, "User-defined metric functions cannot run on the device");
+        delete index;
+        return nullptr;
+    }
+    index->metric = metric_from_c(options->metric_kind);
+    index->scalar = scalar_from_c(options->quantization);
+    if (index->metric == metric_unknown_k || index->scalar == scalar_unknown_k) {
+        fail(error, index->metric == metric_unknown_k ? "Unknown metric kind!" : "Unknown scalar kind!");
+        delete index;
+        return nullptr;
+    }
+    if (!kernel_available(index->metric, index->scalar)) {
+        fail(error, "No MI355X kernel for this metric / scalar kind combination");
+        delete index;
+        return nullptr;
+    }
+    index->dimensions = options->dimensions;
+    if (options->connectivity)
+        index->connectivity = options->connectivity;
+    if (options->expansion_add)
+        index->expansion_add = options->expansion_add;
+    if (options->expansion_search)
+        index->expansion_search = options->expansion_search;
+    index->multi = options->multi;
+    return index;
+}
+
+void usearch_free(usearch_index_t handle, usearch_error_t*) { delete as_index(handle); }
+
+size_t usearch_memory_usage(usearch_index_t handle, usearch_error_t*) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    std::size_t bytes = index.image_owned.size() + index.vectors.size() + index.keys.size() * 8;
+    if (index.snapshot)
+        bytes += index.snapshot->device_bytes();
+    if (index.builder)
+        bytes += index.builder->snapshot().device_bytes();
+    return bytes;
+}
+
+char const* usearch_hardware_acceleration(usearch_index_t, usearch_error_t*) { return "gfx950"; }
+
+size_t usearch_serialized_length(usearch_index_t handle, usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    std::size_t length = 0;
+    if (const char* e = serialize(index, nullptr, nullptr, 0, &length))
+        fail(error, e);
+    return length;
+}
+
+void usearch_save_buffer(usearch_index_t handle, void* buffer, size_t length, usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    if (const char* e = serialize(index, nullptr, buffer, length, nullptr))
+        fail(error, e);
+}
+
+void usearch_save(usearch_index_t handle, char const* path, usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    std::vector<std::uint8_t> bytes;
+    if (const char* e = serialize(index, &bytes, nullptr, 0, nullptr))
+        return fail(error, e);
+    std::FILE* file = std::fopen(path, "wb");
+    if (!file)
+        return fail(error, "Can't open file!");
+    const bool ok = std::fwrite(bytes.data(), 1, bytes.size(), file) == bytes.size();
+    std::fclose(file);
+    if (!ok)
+        fail(error, "Failed to write to file");
+}
+
+void usearch_load_buffer(usearch_index_t handle, void const* buffer, size_t length, usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    index.drop_device();
+    index.drop_image();
+    index.image_owned.assign(static_cast<const std::uint8_t*>(buffer), static_cast<const std::uint8_t*>(buffer) + length);
+    if (const char* e = index.open_image(index.image_owned.data(), length)) {
+        index.drop_image();
+        fail(error, e);
+    }
+}
+
+void usearch_view_buffer(usearch_index_t handle, void const* buffer, size_t length, usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    index.drop_device();
+    index.drop_image();
+    if (const char* e = index.open_image(buffer, length)) // the caller's buffer is borrowed for the index lifetime
+        fail(error, e);
+}
+
+static const char* map_file(char const* path, void** mapped, std::size_t* length) {
+    int fd = ::open(path, O_RDONLY);
+    if (fd < 0)
+        return "Can't open file!";
+    struct stat st;
+    if (::fstat(fd, &st) != 0 || st.st_size <= 0) {
+        ::close(fd);
+        return "Can't infer file size";
+    }
+    void* m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED)
+        return "Can't memory-map the file";
+    *mapped = m, *length = (std::size_t)st.st_size;
+    return nullptr;
+}
+
+void usearch_view(usearch_index_t handle, char const* path, usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    index.drop_device();
+    index.drop_image();
+    void* mapped = nullptr;
+    std::size_t length = 0;
+    if (const char* e = map_file(path, &mapped, &length))
+        return fail(error, e);
+    index.mapping = mapped, index.mapping_length = length;
+    if (const char* e = index.open_image(mapped, length)) {
+        index.drop_image();
+        fail(error, e);
+    }
+}
+
+void usearch_load(usearch_index_t handle, char const* path, usearch_error_t* error) {
+    void* mapped = nullptr;
+    std::size_t length = 0;
+    if (const char* e = map_file(path, &mapped, &length))
+        return fail(error, e);
+    usearch_load_buffer(handle, mapped, length, error); // copies: the file may change or vanish afterwards
+    ::munmap(mapped, length);
+}
+
+void usearch_metadata_buffer(void const* buffer, size_t length, usearch_init_options_t* options, usearch_error_t* error) {
+    image_t image;
+    if (const char* e = image.open(buffer, length))
+        return fail(error, e);
+    fill_options(image, options);
+}
+
+void usearch_metadata(char const* path, usearch_init_options_t* options, usearch_error_t* error) {
+    void* mapped = nullptr;
+    std::size_t length = 0;
+    if (const char* e = map_file(path, &mapped, &length))
+        return fail(error, e);
+    usearch_metadata_buffer(mapped, length, options, error);
+    ::munmap(mapped, length);
+}
+
+size_t usearch_size(usearch_index_t handle, usearch_error_t*) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    if (!index.staged)
+        return index.has_image ? (std::size_t)index.image.count_present : 0;
+    std::size_t present = 0;
+    for (std::uint64_t key : index.keys)
+        present += key != free_key_k;
+    return present;
+}
+
+size_t usearch_capacity(usearch_index_t handle, usearch_error_t*) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    return std::max(index.capacity, index.size());
+}
+
+size_t usearch_dimensions(usearch_index_t handle, usearch_error_t*) { return as_index(handle)->dimensions; }
+size_t usearch_connectivity(usearch_index_t handle, usearch_error_t*) { return as_index(handle)->connectivity; }
+
+void usearch_reserve(usearch_index_t handle, size_t capacity, usearch_error_t*) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    index.capacity = std::max(index.capacity, capacity);
+    if (index.staged) {
+        index.keys.reserve(capacity);
+        index.vectors.reserve(capacity * index.bpv());
+    }
+}
+
+size_t usearch_expansion_add(usearch_index_t handle, usearch_error_t*) { return as_index(handle)->expansion_add; }
+size_t usearch_expansion_search(usearch_index_t handle, usearch_error_t*) { return as_index(handle)->expansion_search; }
+void usearch_change_expansion_add(usearch_index_t handle, size_t expansion, usearch_error_t*) {
+    as_index(handle)->expansion_add = expansion;
+}
+void usearch_change_expansion_search(usearch_index_t handle, size_t expansion, usearch_error_t*) {
+    as_index(handle)->expansion_search = expansion;
+}
+// the device schedules its own waves: the reference's per-thread contexts (index_dense.hpp:931-936) have no counterpart
+void usearch_change_threads_add(usearch_index_t, size_t, usearch_error_t*) {}
+void usearch_change_threads_search(usearch_index_t, size_t, usearch_error_t*) {}
+
+void usearch_change_metric_kind(usearch_index_t handle, usearch_metric_kind_t kind, usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    const metric_kind_t metric = metric_from_c(kind);
+    if (!kernel_available(metric, index.scalar))
+        return fail(error, "No MI355X kernel for this metric / scalar kind combination");
+    if (metric == index.metric)
+        return;
+    index.materialize(); // the graph was linked under the old metric
+    index.metric = metric;
+    index.drop_device();
+}
+
+void usearch_change_metric(usearch_index_t, usearch_metric_t, void*, usearch_metric_kind_t, usearch_error_t* error) {
+    fail(error, "User-defined metric functions cannot run on the device");
+}
+
+void usearch_add(usearch_index_t handle, usearch_key_t key, void const* vector, usearch_scalar_kind_t vector_kind,
+                 usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    const scalar_kind_t kind = scalar_from_c(vector_kind);
+    if (kind == scalar_unknown_k)
+        return fail(error, "Unknown scalar kind!");
+    if (key == free_key_k)
+        return fail(error, "Free key is reserved");
+    if (!index.dimensions || !index.bpv())
+        return fail(error, "Index is not initialized");
+    if (!index.multi && index.key_lookup().count(key))
+        return fail(error, "Duplicate keys not allowed in high-level wrappers");
+    index.materialize();
+    const std::size_t bpv = index.bpv(), slot = index.keys.size();
+    if (slot + 1 >= none_slot_k)
+        return fail(error, "Index is too large for 32-bit slots");
+    index.vectors.resize((slot + 1) * bpv);
+    std::uint8_t* target = index.vectors.data() + slot * bpv;
+    std::memset(target, 0, bpv);
+    if (!cast_vector(kind, index.scalar, static_cast<const std::uint8_t*>(vector), index.dimensions, target))
+        std::memcpy(target, vector, bpv);
+    index.keys.push_back(key);
+    if (index.lookup_valid)
+        index.lookup.emplace(key, (std::uint32_t)slot);
+    delete index.builder, index.builder = nullptr; // relinked at the next search
+}
+
+bool usearch_contains(usearch_index_t handle, usearch_key_t key, usearch_error_t*) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    return index.key_lookup().count(key) != 0;
+}
+
+size_t usearch_count(usearch_index_t handle, usearch_key_t key, usearch_error_t*) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    return index.key_lookup().count(key);
+}
+
+static size_t search_locked(index_t& index, void const* queries, scalar_kind_t kind, std::size_t queries_count,
+                            std::size_t queries_stride, std::size_t count, usearch_key_t* keys, std::size_t keys_stride,
+                            usearch_distance_t* distances, std::size_t distances_stride, std::size_t* counts,
+                            std::size_t* visited_total, std::size_t* computed_total, const std::uint32_t* allow_bits,
+                            usearch_error_t* error) {
+    if (!queries_count || !count)
+        return 0;
+    snapshot_t* device_index = nullptr;
+    if (const char* e = index.ready(&device_index)) {
+        fail(error, e);
+        return 0;
+    }
+    std::vector<std::uint64_t> found(queries_count, 0), visited(queries_count, 0), computed(queries_count, 0);
+    std::vector<std::uint64_t> dense_keys(queries_count * count);
+    std::vector<float> dense_distances(queries_count * count);
+    if (!device_index) { // nothing indexed yet: index.hpp:3034-3037
+        pad_results(reinterpret_cast<usearch_key_t*>(dense_keys.data()), dense_distances.data(), dense_keys.size());
+    } else if (const char* e = device_index->search_host(queries, kind, queries_count, queries_stride, count,
+                                                         index.expansion_search, dense_keys.data(), dense_distances.data(),
+                                                         found.data(), visited.data(), computed.data(), search_tuning_t{},
+                                                         nullptr, allow_bits)) {
+        fail(error, e);
+        return 0;
+    }
+    std::size_t total_visited = 0, total_computed = 0;
+    for (std::size_t q = 0; q < queries_count; ++q) {
+        if (keys)
+            std::memcpy(reinterpret_cast<std::uint8_t*>(keys) + q * keys_stride, dense_keys.data() + q * count, count * 8);
+        if (distances)
+            std::memcpy(reinterpret_cast<std::uint8_t*>(distances) + q * distances_stride,
+                        dense_distances.data() + q * count, count * 4);
+        if (counts)
+            counts[q] = (std::size_t)found[q];
+        total_visited += (std::size_t)visited[q], total_computed += (std::size_t)computed[q];
+    }
+    if (visited_total)
+        *visited_total = total_visited;
+    if (computed_total)
+        *computed_total = total_computed;
+    return (std::size_t)found[0];
+}
+
+size_t usearch_search(usearch_index_t handle, void const* query, usearch_scalar_kind_t query_kind, size_t count,
+                      usearch_key_t* keys, usearch_distance_t* distances, usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    const scalar_kind_t kind = scalar_from_c(query_kind);
+    if (kind == scalar_unknown_k) {
+        fail(error, "Unknown scalar kind!");
+        return 0;
+    }
+    return search_locked(index, query, kind, 1, bytes_per_vector(kind, index.dimensions), count, keys, count * 8, distances,
+                         count * 4, nullptr, nullptr, nullptr, nullptr, error);
+}
+
+void usearch_search_many(usearch_index_t handle, void const* queries, usearch_scalar_kind_t query_kind,
+                         size_t queries_count, size_t queries_stride, size_t count, usearch_key_t* keys,
+                         size_t keys_stride, usearch_distance_t* distances, size_t distances_stride, size_t* counts,
+                         size_t* visited_members, size_t* computed_distances, usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    const scalar_kind_t kind = scalar_from_c(query_kind);
+    if (kind == scalar_unknown_k)
+        return fail(error, "Unknown scalar kind!");
+    search_locked(index, queries, kind, queries_count, queries_stride, count, keys, keys_stride, distances,
+                  distances_stride, counts, visited_members, computed_distances, nullptr, error);
+}
+
+size_t usearch_filtered_search(usearch_index_t handle, void const* query, usearch_scalar_kind_t query_kind, size_t count,
+                               int (*filter)(usearch_key_t key, void* filter_state), void* filter_state,
+                               usearch_key_t* keys, usearch_distance_t* distances, usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    const scalar_kind_t kind = scalar_from_c(query_kind);
+    if (kind == scalar_unknown_k) {
+        fail(error, "Unknown scalar kind!");
+        return 0;
+    }
+    if (!filter)
+        return search_locked(index, query, kind, 1, bytes_per_vector(kind, index.dimensions), count, keys, count * 8,
+                             distances, count * 4, nullptr, nullptr, nullptr, nullptr, error);
+    // The callback is a host function: run it once per member and hand the device one bit per slot. The traversal then
+    // applies it where the reference does (index.hpp:4200-4205, 4236-4240), so results are the reference's as long as the
+    // predicate is a pure function of the key.
+    std::vector<std::uint64_t> from_image;
+    const std::vector<std::uint64_t>* member_keys = &index.keys;
+    if (!index.staged && index.has_image)
+        index.image_keys(from_image), member_keys = &from_image;
+    std::vector<std::uint32_t> bits((member_keys->size() + 31) / 32 + 1, 0);
+    for (std::size_t slot = 0; slot < member_keys->size(); ++slot)
+        if ((*member_keys)[slot] != free_key_k && filter((*member_keys)[slot], filter_state))
+            bits[slot >> 5] |= 1u << (slot & 31);
+    return search_locked(index, query, kind, 1, bytes_per_vector(kind, index.dimensions), count, keys, count * 8, distances,
+                         count * 4, nullptr, nullptr, nullptr, bits.data(), error);
+}
+
+size_t usearch_get(usearch_index_t handle, usearch_key_t key, size_t count, void* vector, usearch_scalar_kind_t vector_kind,
+                   usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    const scalar_kind_t kind = scalar_from_c(vector_kind);
+    if (kind == scalar_unknown_k) {
+        fail(error, "Unknown scalar kind!");
+        return 0;
+    }
+    const std::size_t out_bytes = bytes_per_vector(kind, index.dimensions);
+    auto range = index.key_lookup().equal_range(key);
+    std::vector<std::uint32_t> slots;
+    for (auto it = range.first; it != range.second; ++it)
+        slots.push_back(it->second);
+    std::sort(slots.begin(), slots.end()); // insertion order: the hash table's own order is unspecified
+    std::size_t exported = 0;
+    for (; exported < slots.size() && exported < count; ++exported) {
+        std::uint8_t* target = static_cast<std::uint8_t*>(vector) + exported * out_bytes;
+        const std::uint8_t* stored = index.vector_of(slots[exported]);
+        std::memset(target, 0, out_bytes);
+        if (!cast_vector(index.scalar, kind, stored, index.dimensions, target))
+            std::memcpy(target, stored, out_bytes);
+    }
+    return exported;
+}
+
+size_t usearch_remove(usearch_index_t handle, usearch_key_t key, usearch_error_t*) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    if (!index.key_lookup().count(key))
+        return 0;
+    index.materialize();
+    auto range = index.key_lookup().equal_range(key);
+    std::size_t removed = 0;
+    for (auto it = range.first; it != range.second; ++it, ++removed)
+        index.keys[it->second] = free_key_k; // a tombstone: the member keeps routing, stops matching (index_dense.hpp:1479-1511)
+    index.lookup.erase(key);
+    delete index.builder, index.builder = nullptr;
+    return removed;
+}
+
+size_t usearch_rename(usearch_index_t handle, usearch_key_t from, usearch_key_t to, usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    if (to == free_key_k) {
+        fail(error, "Free key is reserved");
+        return 0;
+    }
+    if (!index.key_lookup().count(from))
+        return 0;
+    if (!index.multi && index.lookup.count(to)) {
+        fail(error, "Renaming impossible, the key is already in use");
+        return 0;
+    }
+    index.materialize();
+    std::vector<std::uint32_t> slots;
+    auto range = index.key_lookup().equal_range(from);
+    for (auto it = range.first; it != range.second; ++it)
+        slots.push_back(it->second);
+    index.lookup.erase(from);
+    for (std::uint32_t slot : slots) {
+        index.keys[slot] = to;
+        index.lookup.emplace(to, slot);
+    }
+    delete index.builder, index.builder = nullptr;
+    return slots.size();
+}
+
+usearch_distance_t usearch_distance(void const* first, void const* second, usearch_scalar_kind_t scalar_kind,
+                                    size_t dimensions, usearch_metric_kind_t metric_kind, usearch_error_t* error) {
+    std::uint64_t key = 0;
+    float distance = 0.f;
+    const scalar_kind_t scalar = scalar_from_c(scalar_kind);
+    const std::size_t bpv = bytes_per_vector(scalar, dimensions);
+    if (const char* e = exact_search_dataset_host(metric_from_c(metric_kind), scalar, dimensions, second, 1, bpv, first, 1,
+                                                  bpv, 1, &key, 8, &distance, 4))
+        fail(error, e);
+    return distance;
+}
+
+void usearch_exact_search(void const* dataset, size_t dataset_size, size_t dataset_stride, void const* queries,
+                          size_t queries_size, size_t queries_stride, usearch_scalar_kind_t scalar_kind, size_t dimensions,
+                          usearch_metric_kind_t metric_kind, size_t count, size_t /*threads*/, usearch_key_t* keys,
+                          size_t keys_stride, usearch_distance_t* distances, size_t distances_stride,
+                          usearch_error_t* error) {
+    if (const char* e = exact_search_dataset_host(metric_from_c(metric_kind), scalar_from_c(scalar_kind), dimensions, dataset,
+                                                  dataset_size, dataset_stride, queries, queries_size, queries_stride, count,
+                                                  keys, keys_stride, distances, distances_stride))
+        fail(error, e);
+}
+
+void usearch_clear(usearch_index_t handle, usearch_error_t*) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    index.drop_device();
+    index.drop_image();
+    index.keys.clear(), index.vectors.clear();
+    index.staged = false;
+    index.lookup.clear(), index.lookup_valid = false;
+}
+
+void usearch_gpu_sync(usearch_index_t handle, usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    snapshot_t* device_index = nullptr;
+    if (const char* e = index.ready(&device_index))
+        fail(error, e);
+}
+
+void usearch_gpu_release(usearch_index_t handle, usearch_error_t*) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    index.drop_device();
+}
+
+} // extern "C"

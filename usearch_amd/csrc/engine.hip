@@ -444,6 +444,7 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
         args.query_ids = extras->query_ids;
         args.beam_level = extras->beam_level;
         args.emit_slots = extras->emit_slots ? 1u : 0u;
+        args.allow_bits = extras->allow_bits;
     }
 
     launch_params_t params{};
@@ -624,7 +625,7 @@ const char* snapshot_t::search_host(const void* queries, scalar_kind_t query_kin
                                     std::size_t stride_bytes, std::size_t wanted, std::size_t expansion,
                                     std::uint64_t* keys, float* distances, std::uint64_t* counts,
                                     std::uint64_t* visited, std::uint64_t* computed, const search_tuning_t& tuning,
-                                    search_stats_t* stats) {
+                                    search_stats_t* stats, const std::uint32_t* allow_bits_host) {
     if (stats)
         *stats = search_stats_t{};
     if (!count || !wanted)
@@ -671,9 +672,23 @@ const char* snapshot_t::search_host(const void* queries, scalar_kind_t query_kin
     std::uint64_t* d_computed = reinterpret_cast<std::uint64_t*>(reinterpret_cast<std::uint8_t*>(d_visited) + pad(count * 8));
 
     UA_HIP(hipMemcpy(d_queries, source, bpv * count, hipMemcpyHostToDevice));
-    if (const char* e = search_device(d_queries, count, bpv, wanted, expansion, d_keys, d_distances, d_counts, d_visited,
-                                      d_computed, nullptr, tuning, stats, false))
-        return e;
+    search_extras_t extras;
+    std::uint32_t* d_allow = nullptr;
+    if (allow_bits_host && view_.size) {
+        const std::size_t words = (view_.size + 31) / 32;
+        UA_HIP(hipMalloc((void**)&d_allow, words * 4));
+        if (hipMemcpy(d_allow, allow_bits_host, words * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d_allow);
+            return "Failed to upload the predicate bitmap";
+        }
+        extras.allow_bits = d_allow;
+    }
+    const char* search_error = search_device(d_queries, count, bpv, wanted, expansion, d_keys, d_distances, d_counts,
+                                             d_visited, d_computed, nullptr, tuning, stats, false, &extras);
+    if (d_allow)
+        (void)hipFree(d_allow);
+    if (search_error)
+        return search_error;
     if (keys)
         UA_HIP(hipMemcpy(keys, d_keys, count * wanted * 8, hipMemcpyDeviceToHost));
     if (distances)

@@ -43,6 +43,7 @@ struct search_extras_t {
     const std::uint32_t* query_ids = nullptr; ///< device: query q is row query_ids[q] of `queries`
     std::uint32_t beam_level = 0;             ///< level the beam runs on
     bool emit_slots = false;                  ///< slots instead of keys in the `keys` output
+    const std::uint32_t* allow_bits = nullptr; ///< device: one bit per slot, 0 = rejected by the caller's predicate
 };
 
 class snapshot_t {
@@ -88,6 +89,7 @@ class snapshot_t {
     void set_frontier(std::uint64_t size, std::uint32_t entry_slot, std::uint32_t max_level) {
         view_.size = size, view_.entry_slot = entry_slot, view_.max_level = max_level;
     }
+    void set_tombstones(bool any) { view_.has_tombstones = any ? 1u : 0u; }
     std::uint32_t* mutable_nbr0() { return static_cast<std::uint32_t*>(d_nbr0_); }
     std::uint32_t* mutable_upper() { return static_cast<std::uint32_t*>(d_upper_); }
     hipStream_t stream() const { return stream_; }
@@ -97,7 +99,8 @@ class snapshot_t {
     const char* search_host(const void* queries, scalar_kind_t query_kind, std::size_t count, std::size_t stride_bytes,
                             std::size_t wanted, std::size_t expansion, std::uint64_t* keys, float* distances,
                             std::uint64_t* counts, std::uint64_t* visited, std::uint64_t* computed,
-                            const search_tuning_t& tuning, search_stats_t* stats);
+                            const search_tuning_t& tuning, search_stats_t* stats,
+                            const std::uint32_t* allow_bits_host = nullptr);
 
     /// Telemetry of the last search_device call: per query {peak frontier size, visited-set size}; host copy.
     const char* last_peaks(std::uint32_t* out, std::size_t queries);

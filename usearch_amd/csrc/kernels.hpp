@@ -778,8 +778,17 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                                                                            cand_distances, count);
         computed += count;
     };
-    auto allowed = [&](std::uint32_t slot) -> bool { // index_dense.hpp:2071-2081 without a user predicate
-        return !ix.has_tombstones || uniform_u32(ix.keys[slot] != free_key_k ? 1u : 0u) != 0;
+    // index_dense.hpp:2071-2081: a member is a result candidate unless it is a tombstone or the caller's predicate
+    // (evaluated on the host into one bit per slot) rejects it; it is traversed either way
+    auto allowed = [&](std::uint32_t slot) -> bool {
+        if (!ix.has_tombstones && !args.allow_bits)
+            return true;
+        bool ok = true;
+        if (ix.has_tombstones)
+            ok = ix.keys[slot] != free_key_k;
+        if (ok && args.allow_bits)
+            ok = ((args.allow_bits[slot >> 5] >> (slot & 31)) & 1u) != 0;
+        return uniform_u32(ok ? 1u : 0u) != 0;
     };
 
     // ---- search_for_one_: greedy descent through levels max_level … 1 (index.hpp:3964-4003)
