@@ -233,13 +233,22 @@ def main() -> None:
     sample = min(args.recall_queries, args.queries)
     if rank == 0 and not sharded and sample:
         t0 = time.time()
-        truth = index.search(queries_host[:sample], args.k, dtype=args.dtype, exact=True).keys
-        log(f"[bench] exact ground truth for {sample} queries in {time.time() - t0:.1f}s")
+        exact = index.search(queries_host[:sample], args.k, dtype=args.dtype, exact=True)
+        truth, truth_distances = exact.keys, exact.distances
+        # integer-valued metrics (Hamming, i8) tie massively: any result at least as close as the exact k-th neighbour is a
+        # correct one, whatever its key (the usual tie-aware recall); float metrics compare keys
+        by_distance = args.dtype in ("b1", "i8")
+        log(f"[bench] exact ground truth for {sample} queries in {time.time() - t0:.1f}s"
+            + (" (recall counted by distance: ties)" if by_distance else ""))
         sweep = [args.expansion] if args.expansion else [64, 96, 128, 192, 256, 320, 384, 448, 512, 576, 640, 704, 768, 896, 1024]
         for ef in sweep:
             search_step(ef, False)
             found = keys_dev[:sample].cpu().numpy().astype(np.uint64)
-            recall = float(np.mean([len(np.intersect1d(found[i], truth[i])) / args.k for i in range(sample)]))
+            if by_distance:
+                found_distances = dist_dev[:sample].cpu().numpy()
+                recall = float(np.mean(found_distances <= truth_distances[:, -1:]))
+            else:
+                recall = float(np.mean([len(np.intersect1d(found[i], truth[i])) / args.k for i in range(sample)]))
             expansion = ef
             log(f"[bench] ef={ef}: recall@{args.k} = {recall:.4f} on {sample} queries")
             if recall >= 0.95:
