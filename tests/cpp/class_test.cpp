@@ -1,0 +1,78 @@
+// tests/cpp/class_test.cpp — include/usearch_amd.hpp used the way C++ callers use `index_dense_gt`
+// (/root/reference/cpp/test.cpp:200-260 `test_minimal_three_vectors`-style flow, 499-503 ordering, 1105-1145 filtered search).
+// `class_test link` only proves that the header compiles and the drop-in resolves (no GPU); `class_test run` needs an MI355X.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "usearch_amd.hpp"
+
+#define EXPECT(condition)                                                                                              \
+    do {                                                                                                               \
+        if (!(condition)) {                                                                                            \
+            std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #condition);                                         \
+            return 1;                                                                                                  \
+        }                                                                                                              \
+    } while (0)
+
+int main(int argc, char** argv) {
+    std::printf("usearch %s\n", usearch_version());
+    if (argc < 2 || std::strcmp(argv[1], "run") != 0)
+        return 0;
+    using namespace usearch_amd;
+    const std::size_t dimensions = 64, count = 1500;
+    std::mt19937 generator(7);
+    std::normal_distribution<float> normal;
+    std::vector<float> data(count * dimensions);
+    for (float& x : data)
+        x = normal(generator);
+
+    auto made = index_dense_t::make(dimensions, usearch_metric_cos_k, usearch_scalar_f32_k);
+    EXPECT(made);
+    index_dense_t index = std::move(made.index);
+    EXPECT(index.try_reserve(count));
+    for (std::size_t i = 0; i < count; ++i)
+        EXPECT(index.add(1000 + i, data.data() + i * dimensions));
+    EXPECT(index.size() == count && index.dimensions() == dimensions && index.contains(1000) && !index.contains(1));
+
+    // every vector finds itself first; distances ascend
+    for (std::size_t i = 0; i < count; i += 37) {
+        auto result = index.search(data.data() + i * dimensions, 10);
+        EXPECT(result && result.size() == 10);
+        EXPECT(result[0].key == 1000 + i && std::fabs(result[0].distance) < 1e-3f);
+        for (std::size_t j = 1; j < result.size(); ++j)
+            EXPECT(result[j - 1].distance <= result[j].distance);
+    }
+    // the same through the batched call
+    auto batch = index.search_many(data.data(), usearch_scalar_f32_k, 200, dimensions * sizeof(float), 5);
+    EXPECT(batch);
+    for (std::size_t i = 0; i < 200; ++i)
+        EXPECT(batch.counts[i] == 5 && batch.keys[i * 5] == 1000 + i);
+    EXPECT(batch.computed_distances > 0 && batch.visited_members > 0);
+    // predicate
+    auto odd = index.filtered_search(data.data(), 10, [](vector_key_t key) { return key % 2 == 1; });
+    EXPECT(odd && odd.size() == 10);
+    for (std::size_t j = 0; j < odd.size(); ++j)
+        EXPECT(odd[j].key % 2 == 1);
+    // get / rename / remove
+    std::vector<float> back(dimensions);
+    EXPECT(index.get(1005, back.data()) == 1 && std::memcmp(back.data(), data.data() + 5 * dimensions, dimensions * 4) == 0);
+    EXPECT(index.rename(1005, 5) == 1 && index.contains(5) && !index.contains(1005));
+    EXPECT(index.remove(1006) == 1 && index.size() == count - 1);
+    auto after = index.search(data.data() + 6 * dimensions, 3);
+    for (std::size_t j = 0; j < after.size(); ++j)
+        EXPECT(after[j].key != 1006);
+    // save → a second object loads it and answers alike
+    EXPECT(index.save("/tmp/usearch_amd_class_test.usearch"));
+    auto reopened = index_dense_t::make("/tmp/usearch_amd_class_test.usearch");
+    EXPECT(reopened && reopened.index.size() == count - 1 && reopened.index.connectivity() == index.connectivity());
+    auto a = index.search(data.data() + 99 * dimensions, 10), b = reopened.index.search(data.data() + 99 * dimensions, 10);
+    EXPECT(a.size() == b.size());
+    for (std::size_t j = 0; j < a.size(); ++j)
+        EXPECT(a[j].key == b[j].key && a[j].distance == b[j].distance);
+    std::remove("/tmp/usearch_amd_class_test.usearch");
+    std::printf("class test passed\n");
+    return 0;
+}

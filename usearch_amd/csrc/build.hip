@@ -372,7 +372,10 @@ const char* builder_t::save_buffer(void* buffer, std::size_t length) {
     p[14] = (std::uint8_t)scalar_;
     p[15] = (std::uint8_t)scalar_u64_k;
     p[16] = (std::uint8_t)scalar_u32_k;
-    const std::uint64_t present = n, deleted = 0, dimensions = dimensions_;
+    std::uint64_t deleted = 0; // members whose key is the tombstone value (index_dense.hpp:1051-1052)
+    for (std::uint64_t key : keys_)
+        deleted += key == free_key_k;
+    const std::uint64_t present = n - deleted, dimensions = dimensions_;
     std::memcpy(p + 17, &present, 8);
     std::memcpy(p + 25, &deleted, 8);
     std::memcpy(p + 33, &dimensions, 8);
