@@ -10,6 +10,7 @@
 #include <unistd.h>
 
 #include <new>
+#include <vector>
 
 #include "build.hpp"
 #include "casts.hpp"
@@ -142,9 +143,62 @@ __global__ __launch_bounds__(64) void containers_kernel(const std::uint32_t* kin
         *popped_count = pops, *top_count = top_size;
 }
 
+/**
+ *  Micro-benchmark of the register-resident `top`: every wave inserts `count` pseudo-random distances under the
+ *  traversal's acceptance rule and reports its shader-clock ticks and how many were accepted (diagnostic only).
+ */
+template <int epl_ak>
+__global__ __launch_bounds__(64) void top_bench_kernel(std::uint32_t count, std::uint32_t limit, unsigned long long* out) {
+    top_gt<epl_ak, false> top;
+    top.reset(nullptr);
+    std::uint32_t state = 12345u + blockIdx.x * 977u;
+    float radius = __builtin_inff();
+    std::uint32_t accepted = 0;
+    const std::uint64_t begin = __builtin_amdgcn_s_memtime();
+    for (std::uint32_t i = 0; i < count; ++i) {
+        state = state * 1664525u + 1013904223u;
+        const float d = uniform_f32((float)(state >> 8) * (1.0f / 16777216.0f));
+        if (top.size < limit || d < radius) {
+            top.insert(d, i, limit, radius);
+            ++accepted;
+        }
+    }
+    const std::uint64_t end = __builtin_amdgcn_s_memtime();
+    float checksum = 0.f; // keeps the buffer alive
+#pragma unroll
+    for (int r = 0; r < epl_ak; ++r)
+        checksum += top.d[r] == __builtin_inff() ? 0.f : top.d[r];
+    if (lane_id() == 0) {
+        out[2 * blockIdx.x] = end - begin;
+        out[2 * blockIdx.x + 1] = ((unsigned long long)accepted << 32) | __builtin_bit_cast(std::uint32_t, checksum);
+    }
+}
+
 } // namespace usearch_amd
 
 extern "C" {
+
+/** Diagnostic: ticks[wave] and accepted[wave] of `top_bench_kernel` (entries per lane 4, 8 or 16). Not in the public header. */
+__attribute__((visibility("default"))) void usearch_amd_bench_top(uint32_t epl, uint32_t count, uint32_t limit,
+                                                                   uint32_t waves, uint64_t* ticks, uint64_t* accepted,
+                                                                   usearch_amd_error_t* error) {
+    unsigned long long* d_out = nullptr;
+    if (hipMalloc((void**)&d_out, (size_t)waves * 16) != hipSuccess)
+        return fail(error, "hipMalloc failed");
+    if (epl == 4)
+        hipLaunchKernelGGL(top_bench_kernel<4>, dim3(waves), dim3(64), 0, nullptr, count, limit, d_out);
+    else if (epl == 8)
+        hipLaunchKernelGGL(top_bench_kernel<8>, dim3(waves), dim3(64), 0, nullptr, count, limit, d_out);
+    else
+        hipLaunchKernelGGL(top_bench_kernel<16>, dim3(waves), dim3(64), 0, nullptr, count, limit, d_out);
+    std::vector<unsigned long long> host((size_t)waves * 2);
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(host.data(), d_out, host.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        fail(error, "top bench failed");
+    for (uint32_t w = 0; w < waves; ++w)
+        ticks[w] = host[2 * w], accepted[w] = host[2 * w + 1] >> 32;
+    (void)hipFree(d_out);
+}
 
 int usearch_amd_device_count(usearch_amd_error_t* error) {
     int count = 0;

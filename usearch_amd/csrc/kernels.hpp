@@ -232,18 +232,19 @@ UA_DEVICE float lane_below_f32(float v) {
 
 /**
  *  `top` as the search kernel holds it.
- *    epl_ak > 0   in REGISTERS, striped layout: entry `g` of the ascending array lives in lane g % 64 of register row
- *                 g / 64 (epl_ak rows, capacity 64·epl_ak ≥ expansion), unused cells hold +inf. An insert costs one ballot per
- *                 row up to the landing row plus one DPP lane shift per row from the landing row on — rows below the
- *                 landing position are skipped by wave-uniform branches, nothing touches LDS.
+ *    epl_ak > 0   in REGISTERS, blocked layout: lane L owns entries [L·epl, (L+1)·epl) of the ascending array (capacity
+ *                 64·epl ≥ expansion), unused cells hold +inf. An insert is decided cell by cell from purely local
+ *                 information — a cell keeps its value while that is smaller than the new distance, takes the new element
+ *                 if the cell below it is smaller, and its lower neighbour's value otherwise — so it is straight-line
+ *                 vector code: no position to compute, no ballot, no scalar round trip (the measured cost of an insert was
+ *                 the VALU→SALU→branch latency chain of those, not its instruction count).
  *    epl_ak == 0  in scratch memory (LDS, or the global slab of the fallback mode): any expansion.
  *  Same observable behaviour as sorted_buffer_gt (index.hpp:845-956) either way.
  */
 template <int epl_ak, bool global_ak> struct top_gt {
     static constexpr int regs_k = epl_ak > 0 ? epl_ak : 1;
-    // plain arrays that are only ever indexed by compile-time constants (every loop over them is fully unrolled, the row
-    // chain of `insert` is a template per row): SROA turns each cell into its own SSA value, so the control flow between
-    // rows merges single registers. (An ext_vector is merged as a whole: 2·epl register copies at every row boundary.)
+    // plain arrays that are only ever indexed by compile-time constants (every loop over them is fully unrolled): SROA turns
+    // each cell into its own SSA value
     float d[regs_k];
     std::uint32_t s[regs_k];
     cand_t* cells = nullptr;
@@ -257,8 +258,10 @@ template <int epl_ak, bool global_ak> struct top_gt {
             d[i] = __builtin_inff(), s[i] = none_slot_k;
     }
 
-    /// insert(element, limit), index.hpp:928-939. When the buffer is full afterwards, `radius` receives top().distance
-    /// (index.hpp:891); before that the traversal never reads it (every use is guarded by `size == limit`).
+    /// insert(element, limit), index.hpp:928-939, under the traversal's precondition: the buffer is not full, or `nd` is
+    /// smaller than its last element (so the element always lands; index.hpp:931-933 never refuses it). When the buffer is
+    /// full afterwards, `radius` receives top().distance (index.hpp:891); before that the traversal never reads it
+    /// (every use is guarded by `size == limit`).
     UA_DEVICE bool insert(float nd, std::uint32_t ns, std::uint32_t limit, float& radius) {
         if constexpr (epl_ak == 0) {
             const bool inserted = sorted_insert<global_ak>(cells, size, limit, nd, ns);
@@ -266,108 +269,52 @@ template <int epl_ak, bool global_ak> struct top_gt {
                 radius = worst();
             return inserted;
         } else {
-            // lower_bound: entries strictly smaller (the +inf padding never is). Straight-line on purpose: in this
-            // scalar-heavy code a taken branch costs more than the ballot it would skip.
-            std::uint32_t position = 0;
+            const std::uint32_t lane = lane_id();
+            // the cell below this lane's first cell is the last cell of the lane below; below cell 0 lies -inf
+            float below_d = lane_below_f32(d[epl_ak - 1]);
+            const std::uint32_t below_s = lane_below_u32(s[epl_ak - 1]);
+            below_d = lane == 0 ? -__builtin_inff() : below_d;
+            // lower_bound placement: the landing cell is the first one that is not smaller than `nd` (new before equal)
+            bool smaller[regs_k + 1];
+            smaller[0] = below_d < nd;
 #pragma unroll
-            for (int r = 0; r < epl_ak; ++r)
-                position += popcount64(ballot(d[r] < nd));
-            if (position == limit)
-                return false;
-            // entries [position, last] move one cell up: inside a row to the next lane, from lane 63 to lane 0 of the next
-            // row; what leaves cell `limit - 1` of a full buffer is dropped. Rows above the last element hold padding only
-            // and rows below the landing row do not move: enter the (descending) row chain at the last row, leave it after
-            // the landing row — every row still sees the old content of the row below it.
-            // (`size` is wave-uniform by construction; saying so keeps the row chain on the scalar branch unit)
-            const std::uint32_t last = uniform_u32(size < limit ? size : limit - 1); // last element after this insert
-            shift_t shift;
-            shift.landing_row = position / 64, shift.landing_lane = position % 64;
-            shift.last_row = last / 64, shift.last_lane = last % 64;
-            shift.full = last + 1 == uniform_u32(limit);
-            shift.nd = nd, shift.ns = ns;
-#define UA_TOP_ROW(r)                                                                                                  \
-    case r:                                                                                                            \
-        if constexpr (r < epl_ak) {                                                                                    \
-            shift_row<r>(shift, radius);                                                                               \
-            if (shift.landing_row == r)                                                                                \
-                break;                                                                                                 \
-        }                                                                                                              \
-        [[fallthrough]];
-            switch (shift.last_row) {
-                UA_TOP_ROW(15)
-                UA_TOP_ROW(14)
-                UA_TOP_ROW(13)
-                UA_TOP_ROW(12)
-                UA_TOP_ROW(11)
-                UA_TOP_ROW(10)
-                UA_TOP_ROW(9)
-                UA_TOP_ROW(8)
-                UA_TOP_ROW(7)
-                UA_TOP_ROW(6)
-                UA_TOP_ROW(5)
-                UA_TOP_ROW(4)
-                UA_TOP_ROW(3)
-                UA_TOP_ROW(2)
-                UA_TOP_ROW(1)
-                UA_TOP_ROW(0)
-            default: break;
+            for (int i = 0; i < epl_ak; ++i)
+                smaller[i + 1] = d[i] < nd;
+#pragma unroll
+            for (int i = epl_ak - 1; i >= 0; --i) { // descending: cell i still reads the old cell i - 1
+                const float under_d = i > 0 ? d[i > 0 ? i - 1 : 0] : below_d;
+                const std::uint32_t under_s = i > 0 ? s[i > 0 ? i - 1 : 0] : below_s;
+                const float moved_d = smaller[i] ? nd : under_d;
+                const std::uint32_t moved_s = smaller[i] ? ns : under_s;
+                d[i] = smaller[i + 1] ? d[i] : moved_d;
+                s[i] = smaller[i + 1] ? s[i] : moved_s;
             }
-#undef UA_TOP_ROW
-            size = last + 1;
+            // wave-uniform bookkeeping; none of it waits for the vector work above
+            const bool full = uniform_u32(size) == uniform_u32(limit);
+            if (full && limit < 64u * epl_ak) { // what left cell `limit - 1` of a full buffer sits in cell `limit`: drop it
+                const std::uint32_t drop_lane = limit / epl_ak, drop_cell = limit % epl_ak;
+#pragma unroll
+                for (int i = 0; i < epl_ak; ++i)
+                    if (drop_cell == (std::uint32_t)i) {
+                        d[i] = lane == drop_lane ? __builtin_inff() : d[i];
+                        s[i] = lane == drop_lane ? none_slot_k : s[i];
+                    }
+            }
+            size += full ? 0u : 1u;
+            if (size == limit) {
+                const std::uint32_t last_lane = (limit - 1) / epl_ak, last_cell = (limit - 1) % epl_ak;
+#pragma unroll
+                for (int i = 0; i < epl_ak; ++i)
+                    if (last_cell == (std::uint32_t)i)
+                        radius = read_lane_f32(d[i], last_lane);
+            }
             return true;
         }
     }
 
-    struct shift_t {
-        std::uint32_t landing_row, landing_lane, last_row, last_lane, ns;
-        float nd;
-        bool full;
-    };
-
-    /// One row of an insert, branch-free: element X enters at lane L and the lanes above L take their lower neighbour's
-    /// value — in the landing row X is the new element, in the rows above it X is what left lane 63 of the row below
-    /// and L = 0. The last row also restores the +inf padding behind the last element and reports the new radius.
-    template <int r> UA_DEVICE void shift_row(const shift_t& shift, float& radius) {
-        const std::uint32_t lane = lane_id();
-        const bool landing = shift.landing_row == (std::uint32_t)r;
-        float enter_d = shift.nd;
-        std::uint32_t enter_s = shift.ns, enter_lane = shift.landing_lane;
-        if constexpr (r > 0) {
-            const float carry_d = read_lane_f32(d[r - 1], 63);
-            const std::uint32_t carry_s = read_lane_u32(s[r - 1], 63);
-            enter_d = landing ? shift.nd : carry_d;
-            enter_s = landing ? shift.ns : carry_s;
-            enter_lane = landing ? shift.landing_lane : 0u;
-        }
-        const float keep_d = d[r];
-        const std::uint32_t keep_s = s[r];
-        const float from_d = lane_below_f32(keep_d);
-        const std::uint32_t from_s = lane_below_u32(keep_s);
-        const bool is_last = shift.last_row == (std::uint32_t)r;
-        const std::uint32_t kept_lanes = is_last ? shift.last_lane : 63u;
-        float moved_d = lane > enter_lane ? from_d : lane == enter_lane ? enter_d : keep_d;
-        std::uint32_t moved_s = lane > enter_lane ? from_s : lane == enter_lane ? enter_s : keep_s;
-        moved_d = lane > kept_lanes ? __builtin_inff() : moved_d; // the dropped element, if any
-        moved_s = lane > kept_lanes ? none_slot_k : moved_s;
-        d[r] = moved_d;
-        s[r] = moved_s;
-        const float tail = read_lane_f32(moved_d, shift.last_lane);
-        radius = is_last && shift.full ? tail : radius;
-    }
-
-    /// top.top() — the worst kept distance (index.hpp:891). Requires size > 0.
+    /// top.top() — the worst kept distance (index.hpp:891). Requires size > 0. (Scratch-memory layout only.)
     UA_DEVICE float worst() const {
-        if constexpr (epl_ak == 0) {
-            return uniform_f32(cand_distance(scratch_gt<global_ak>::load(cells + (size - 1))));
-        } else {
-            const std::uint32_t index = size - 1, row = index / 64, lane = index % 64;
-            float result = 0.f;
-#pragma unroll
-            for (int r = 0; r < epl_ak; ++r)
-                if ((std::uint32_t)r == row) // wave-uniform
-                    result = read_lane_f32(d[r], lane);
-            return result;
-        }
+        return uniform_f32(cand_distance(scratch_gt<global_ak>::load(cells + (size - 1))));
     }
 
     /// dump_to(keys, distances, capacity = wanted) with the key 0 / signalling-NaN padding of index.hpp:2707-2722.
@@ -389,10 +336,10 @@ template <int epl_ak, bool global_ak> struct top_gt {
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < epl_ak; ++r) {
-                const std::uint32_t g = 64u * r + lane_id();
-                const float distance = d[r];       // copy the vector ELEMENTS out first: bit-casting `d[r]` itself
-                const std::uint32_t slot = s[r];   // reads element 0 of the vector
+            for (int i = 0; i < epl_ak; ++i) {
+                const std::uint32_t g = lane_id() * epl_ak + i;
+                const float distance = d[i];
+                const std::uint32_t slot = s[i];
                 if (g < wanted) {
                     keys[g] = g < found ? (args.emit_slots ? (std::uint64_t)slot : ix.keys[slot]) : 0;
                     bits[g] = g < found ? __builtin_bit_cast(std::uint32_t, distance) : signaling_nan_bits_k;
@@ -845,8 +792,8 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     visits_set<mode_ak>(visits, visits_mask, closest, lane == 0);
     visits_count = 1;
     if (allowed(closest)) {
-        float unused = radius;
-        top.insert(radius, closest, ef, unused);
+        float first_radius = radius;
+        top.insert(radius, closest, ef, first_radius);
     }
 
     const std::uint32_t cells = beam_level ? ix.m : ix.m0;
