@@ -187,3 +187,24 @@ def test_large_expansion(reference):
     for expansion in (256, 1000):
         got = check_against_oracle(index, image, queries, 10, "f32", expansion)
         assert got.stats.mode == 2  # the visited set no longer fits LDS next to 8 waves per CU
+
+
+@pytest.mark.parametrize("metric,dtype,ndim", [("hamming", "b1", 64), ("cos", "f16", 48)])
+def test_every_result_buffer_shape(reference, metric, dtype, ndim):
+    """The result buffer lives in 1 / 4 / 8 / 16 registers per lane or in LDS depending on the expansion: every shape, the
+    boundaries between them, and `wanted == expansion` (the whole buffer is dumped, across lanes) — on a tie-heavy metric
+    (insertion order among equal distances is the reference's lower_bound rule, index.hpp:928-939) and a float one."""
+    from usearch_amd import Index
+    image, _, ref_index = util.build_image(6000, ndim, metric, dtype, seed=31)
+    index = Index.restore(image)
+    queries = util.make_vectors(24, ndim, dtype, seed=32)
+    for expansion in (1, 10, 63, 64, 65, 255, 256, 257, 512, 513, 700, 1024, 1025, 1500):
+        for k in {1, 10, min(expansion, 1100)}:
+            if k > expansion:
+                continue
+            got = check_against_oracle(index, image, queries, k, dtype, expansion)
+            if metric == "hamming":  # integer distances: the real reference agrees bit for bit, ties included
+                ref_index.expansion_search = expansion
+                rkeys, rdists, rcounts, *_ = ref_index.search(queries, k, dtype=dtype, threads=1)
+                assert np.array_equal(got.keys, rkeys) and util.same_float_bits(got.distances, rdists)
+                assert np.array_equal(got.counts, rcounts)

@@ -808,7 +808,6 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
         const float candidate_distance = -uniform_f32(cand_distance(candidate));
         if (candidate_distance > radius && top.size == ef) // index.hpp:4210, strict `>`
             break;
-        heap_pop<global_ak>(next, next_size);
         ++cycles;
         const std::uint32_t expanded = uniform_u32(cand_slot(candidate));
         const std::uint32_t* list = list_of(expanded);
@@ -820,13 +819,22 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
         std::uint32_t first_cell = none_slot_k;
         if (!list_ready && lane < cells)
             first_cell = list[lane];
-        // The frontier's new best is the likeliest next hop (unless this hop finds something closer): request its list now,
-        // so that the row arrives behind this hop's vector traffic instead of in front of the next hop's.
-        ahead_slot = none_slot_k;
-        if (next_size) {
-            ahead_slot = uniform_u32(cand_slot(mem::load(next)));
-            ahead_cell = lane < cells ? list_of(ahead_slot)[lane] : none_slot_k;
-        }
+        // next.pop() only touches LDS: it runs in the shadow of a memory round trip — of the list load when the list was
+        // not requested ahead, else of the first probe of the visited set. Right after it the frontier's new best is the
+        // likeliest next hop (unless this hop finds something closer): its list is requested then, so that the row
+        // arrives behind this hop's vector traffic instead of in front of the next hop's.
+        bool popped = false;
+        auto pop_now = [&]() {
+            heap_pop<global_ak>(next, next_size);
+            popped = true;
+            ahead_slot = none_slot_k;
+            if (next_size) {
+                ahead_slot = uniform_u32(cand_slot(mem::load(next)));
+                ahead_cell = lane < cells ? list_of(ahead_slot)[lane] : none_slot_k;
+            }
+        };
+        if (!list_ready || cells > 64 || mode_ak == scratch_global_k)
+            pop_now();
         for (std::uint32_t tile = 0; tile < cells; tile += 64) {
             const std::uint32_t cell = tile + lane;
             const std::uint32_t neighbor =
@@ -835,13 +843,29 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
             const std::uint32_t present_count = popcount64(ballot(present));
             if (!present_count)
                 break;
-            if (visits_count + present_count > visits_limit || next_size + present_count > args.next_cap) {
+            if (visits_count + present_count > visits_limit ||
+                next_size - (popped ? 0u : 1u) + present_count > args.next_cap) {
                 overflow = true;
                 break;
             }
             // visits.set(successor) for the whole tile at once; duplicates inside a list were removed on upload
             tick(1);
-            const bool fresh = visits_set<mode_ak>(visits, visits_mask, neighbor, present);
+            bool fresh;
+            if constexpr (mode_ak == scratch_global_k) {
+                fresh = visits_set<mode_ak>(visits, visits_mask, neighbor, present);
+            } else {
+                std::uint32_t h = hash_slot(neighbor) & visits_mask;
+                std::uint32_t old = neighbor; // an absent lane probes nothing
+                if (present)
+                    old = atomicCAS(visits + h, none_slot_k, neighbor);
+                if (!popped)
+                    pop_now();
+                while (old != none_slot_k && old != neighbor) { // linear probing, index.hpp:1085-1211
+                    h = (h + 1) & visits_mask;
+                    old = atomicCAS(visits + h, none_slot_k, neighbor);
+                }
+                fresh = present && old == none_slot_k;
+            }
             const std::uint64_t fresh_mask = ballot(fresh);
             tick(2);
             const std::uint32_t count = popcount64(fresh_mask);
@@ -889,6 +913,8 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
         }
         if (overflow)
             break;
+        if (!popped) // a node without neighbours: nothing was probed
+            pop_now();
     }
 
     // ---- results: shrink to `wanted`, dump_to with padding (index.hpp:3067-3073, 2707-2722)
