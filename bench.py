@@ -35,8 +35,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (≈6.3 TB/s achievable on streaming copies)
-DTYPE_BYTES = {"f32": 4.0, "f16": 2.0, "i8": 1.0, "b1": 0.125}
-NUMPY_STORAGE = {"f32": np.float32, "f16": np.float16, "i8": np.int8, "b1": np.uint8}
+DTYPE_BYTES = {"f32": 4.0, "f16": 2.0, "bf16": 2.0, "f64": 8.0, "i8": 1.0, "b1": 0.125}
+NUMPY_STORAGE = {"f32": np.float32, "f16": np.float16, "bf16": np.uint16, "f64": np.float64, "i8": np.int8, "b1": np.uint8}
 
 
 def host_cores() -> int:
@@ -71,6 +71,10 @@ def synthetic_vectors(count: int, dim: int, dtype: str, seed: int, basis_seed: i
             out.append(x)
         elif dtype == "f16":
             out.append(x.astype(np.float16))
+        elif dtype == "f64":
+            out.append(x.astype(np.float64))
+        elif dtype == "bf16":  # bit patterns; truncation like the reference's f32_to_bf16 (index_plugins.hpp:453-469)
+            out.append((np.ascontiguousarray(x).view(np.uint32) >> 16).astype(np.uint16))
         elif dtype == "i8":
             out.append(np.clip(np.rint(x * (127.0 / 24.0)), -127, 127).astype(np.int8))
         elif dtype == "b1":
@@ -99,6 +103,10 @@ def synthetic_vectors_device(count: int, dim: int, dtype: str, seed: int, device
             block = x
         elif dtype == "f16":
             block = x.to(torch.float16)
+        elif dtype == "f64":
+            block = x.to(torch.float64)
+        elif dtype == "bf16":  # truncation like the reference's f32_to_bf16 (index_plugins.hpp:453-469)
+            block = (x.contiguous().view(torch.int32) >> 16).to(torch.int16)
         elif dtype == "i8":
             block = torch.clamp(torch.round(x * (127.0 / 24.0)), -127, 127).to(torch.int8)
         else:  # b1: sign bits, MSB first (cast_to_b1x8_gt, index_plugins.hpp:1139-1158)

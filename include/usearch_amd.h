@@ -143,6 +143,19 @@ USEARCH_AMD_EXPORT void usearch_amd_exact_search_many(usearch_amd_snapshot_t sna
                                                       float* kernel_ms, usearch_amd_error_t* error);
 
 /**
+ *  Closest member on a given LEVEL of the hierarchy for a batch of queries — `index_dense_gt::cluster(query, level)`
+ *  (index_dense.hpp:788-793 → index_gt::cluster, index.hpp:3089-3125): the greedy descent of `search_for_one_` from the top
+ *  level down to `level`, without the level-0 beam. Level 0 and 1 both end on level 1's winner, a level above the top one
+ *  returns the entry point. Host buffers, queries in any scalar kind; `keys`, `distances`, `visited`, `computed` hold one
+ *  cell per query (the counters as `cluster_result_t` reports them; either may be NULL). An empty index yields key 0 and a
+ *  signalling NaN (the reference fails that call with "No clusters to identify").
+ */
+USEARCH_AMD_EXPORT void usearch_amd_cluster_many(usearch_amd_snapshot_t snapshot, void const* queries, int query_kind,
+                                                 size_t queries_count, size_t queries_stride, size_t level,
+                                                 usearch_amd_key_t* keys, usearch_amd_distance_t* distances,
+                                                 uint64_t* visited, uint64_t* computed, usearch_amd_error_t* error);
+
+/**
  *  Exact search of a raw host dataset — `usearch_exact_search` (c/usearch.h:467-474, c/lib.cpp:468-501): keys are row
  *  offsets of `dataset`. `metric_kind` / `scalar_kind` use the C enumerators of c/usearch.h:40-62. Ties between equal
  *  distances (unspecified in the reference: `std::partial_sort` by distance) resolve to the later row first.

@@ -28,6 +28,9 @@ namespace usearch_amd {
 using vector_key_t = usearch_key_t;   ///< `default_key_t`, index_dense.hpp:2229
 using distance_t = usearch_distance_t;
 using f16_bits_t = std::uint16_t;     ///< half-precision scalars travel as their bit pattern (index_plugins.hpp:394-428)
+struct bf16_bits_t {                  ///< brain floats travel as their bit pattern too (index_plugins.hpp:430-470): a distinct
+    std::uint16_t bits;               ///< type, so that the overloads below can tell them from IEEE halves
+};
 struct b1x8_t {                       ///< eight bits per byte, MSB first (index_plugins.hpp:1139-1158)
     std::uint8_t byte;
 };
@@ -115,12 +118,16 @@ class index_dense_t {
     add_result_t add(vector_key_t key, f16_bits_t const* vector) { return add_(key, vector, usearch_scalar_f16_k); }
     add_result_t add(vector_key_t key, std::int8_t const* vector) { return add_(key, vector, usearch_scalar_i8_k); }
     add_result_t add(vector_key_t key, b1x8_t const* vector) { return add_(key, vector, usearch_scalar_b1_k); }
+    add_result_t add(vector_key_t key, double const* vector) { return add_(key, vector, usearch_scalar_f64_k); }
+    add_result_t add(vector_key_t key, bf16_bits_t const* vector) { return add_(key, vector, usearch_scalar_bf16_k); }
 
     // ---- search: index_dense.hpp:767-772 (`thread` is accepted and ignored: the batch is the parallelism)
     search_result_t search(float const* q, std::size_t wanted, std::size_t = 0, bool exact = false) const { return search_(q, usearch_scalar_f32_k, 1, 0, wanted, exact); }
     search_result_t search(f16_bits_t const* q, std::size_t wanted, std::size_t = 0, bool exact = false) const { return search_(q, usearch_scalar_f16_k, 1, 0, wanted, exact); }
     search_result_t search(std::int8_t const* q, std::size_t wanted, std::size_t = 0, bool exact = false) const { return search_(q, usearch_scalar_i8_k, 1, 0, wanted, exact); }
     search_result_t search(b1x8_t const* q, std::size_t wanted, std::size_t = 0, bool exact = false) const { return search_(q, usearch_scalar_b1_k, 1, 0, wanted, exact); }
+    search_result_t search(double const* q, std::size_t wanted, std::size_t = 0, bool exact = false) const { return search_(q, usearch_scalar_f64_k, 1, 0, wanted, exact); }
+    search_result_t search(bf16_bits_t const* q, std::size_t wanted, std::size_t = 0, bool exact = false) const { return search_(q, usearch_scalar_bf16_k, 1, 0, wanted, exact); }
 
     /// The whole batch in one call: row `i` of the results holds query `i`'s `wanted` cells (`counts[i]` of them filled).
     struct batch_result_t {

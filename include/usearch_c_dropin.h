@@ -17,8 +17,9 @@
  *    persistence   `usearch_save*` writes and `usearch_load* / view*` read the reference's v2 format: files move freely
  *                  between the two libraries.
  *    refused       by name, never computed elsewhere: a user-defined metric function (`usearch_change_metric`,
- *                  `usearch_init_options_t::metric`); metric / scalar kinds without a kernel (pearson, haversine,
- *                  divergence, jaccard, tanimoto, sorensen; f64 and bf16 storage).
+ *                  `usearch_init_options_t::metric`); a metric / scalar pair outside the reference's own dispatch table
+ *                  (index_plugins.hpp:1930-2008 — e.g. haversine over half floats, divergence over i8): every pair inside it
+ *                  has a kernel.
  *  Nothing is forwarded to the reference and there is no CPU search or build path: without a HIP device every call that
  *  needs one fails with an error string.
  *

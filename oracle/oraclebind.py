@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_LIB_PATH = os.path.join(HERE, "_build", "libusearch_oracle.so")
 
 # on-disk enum values (index_plugins.hpp:113-159)
-METRIC = {"ip": ord("i"), "cos": ord("c"), "l2sq": ord("e"), "hamming": ord("b")}
+METRIC = {"ip": ord("i"), "cos": ord("c"), "l2sq": ord("e"), "hamming": ord("b"), "pearson": ord("p"),
+          "haversine": ord("h"), "divergence": ord("d"), "jaccard": ord("j"), "tanimoto": ord("t"), "sorensen": ord("s")}
 SCALAR = {"b1": 1, "bf16": 4, "f64": 10, "f32": 11, "f16": 12, "i8": 23}
 SCALAR_NAME = {v: k for k, v in SCALAR.items()}
 METRIC_NAME = {v: k for k, v in METRIC.items()}
@@ -73,6 +74,8 @@ def lib() -> C.CDLL:
         L.uo_search.restype = C.c_size_t
         L.uo_search.argtypes = [C.POINTER(_Index), C.c_void_p, C.c_uint8, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.uo_cluster_many.argtypes = [C.POINTER(_Index), C.c_void_p, C.c_uint8, C.c_size_t, C.c_size_t, C.c_size_t,
+                                      C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.uo_merge_into.restype = C.c_size_t
         L.uo_merge_into.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
                                     C.c_size_t]
@@ -146,6 +149,20 @@ class OracleIndex:
                                  int(exact), lanes, _ptr(keys), _ptr(dists), _ptr(counts), _ptr(visited),
                                  _ptr(computed))
         return keys, dists, counts, visited, computed
+
+    def cluster(self, queries: np.ndarray, level: int, dtype: Optional[str] = None, lanes: int = 0):
+        """`index_dense_gt::cluster(query, level)` for a batch → (keys[Q], distances[Q], visited[Q], computed[Q])."""
+        dtype = dtype or self.dtype
+        queries = np.ascontiguousarray(queries)
+        q = len(queries)
+        keys = np.zeros(q, dtype=np.uint64)
+        dists = np.zeros(q, dtype=np.float32)
+        visited = np.zeros(q, dtype=np.uint64)
+        computed = np.zeros(q, dtype=np.uint64)
+        if q:
+            lib().uo_cluster_many(C.byref(self.ix), _ptr(queries), SCALAR[dtype], q, queries.strides[0], level, lanes,
+                                  _ptr(keys), _ptr(dists), _ptr(visited), _ptr(computed))
+        return keys, dists, visited, computed
 
     def filtered_search(self, query: np.ndarray, k: int, predicate, dtype: Optional[str] = None,
                         expansion: int = 64, lanes: int = 0):

@@ -19,6 +19,8 @@
 #include <omp.h>
 #endif
 
+#include <limits>
+
 #include <usearch/index_dense.hpp>
 
 extern "C" {
@@ -138,6 +140,50 @@ void uref_search_many(usearch_index_t handle, void const* queries, usearch_scala
         std::size_t found = r.dump_to(keys + i * k, distances + i * k, k);
         if (counts)
             counts[i] = found;
+        if (visited)
+            visited[i] = r.visited_members;
+        if (computed)
+            computed[i] = r.computed_distances;
+    }
+}
+
+/**
+ *  Batched `index_dense_gt::cluster(query, level)` (index_dense.hpp:788-793 → index_gt::cluster, index.hpp:3089-3125),
+ *  one query per OpenMP task like the search loop above. keys / distances / counters are [count] arrays; a failed call
+ *  ("No clusters to identify" on an empty index) leaves key 0 and a signalling NaN.
+ */
+void uref_cluster_many(usearch_index_t handle, void const* queries, usearch_scalar_kind_t kind, size_t count,
+                       size_t stride_bytes, size_t level, size_t threads, usearch_key_t* keys,
+                       usearch_distance_t* distances, uint64_t* visited, uint64_t* computed) {
+    index_dense_t& index = *reinterpret_cast<index_dense_t*>(handle);
+    scalar_kind_t cpp_kind = to_cpp(kind);
+    if (!threads)
+        threads = (size_t)uref_max_threads();
+    ensure_threads(index, threads);
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(static, 32) num_threads(threads)
+#endif
+    for (std::size_t i = 0; i < count; ++i) {
+        std::size_t thread = 0;
+#if defined(_OPENMP)
+        thread = (std::size_t)omp_get_thread_num();
+#endif
+        char const* q = (char const*)queries + i * stride_bytes;
+        index_dense_t::cluster_result_t r;
+        switch (cpp_kind) {
+        case scalar_kind_t::f32_k: r = index.cluster((f32_t const*)q, level, thread); break;
+        case scalar_kind_t::f64_k: r = index.cluster((f64_t const*)q, level, thread); break;
+        case scalar_kind_t::f16_k: r = index.cluster((f16_t const*)q, level, thread); break;
+        case scalar_kind_t::bf16_k: r = index.cluster((bf16_t const*)q, level, thread); break;
+        case scalar_kind_t::i8_k: r = index.cluster((i8_t const*)q, level, thread); break;
+        default: r = index.cluster((b1x8_t const*)q, level, thread); break;
+        }
+        keys[i] = 0;
+        distances[i] = std::numeric_limits<usearch_distance_t>::signaling_NaN();
+        if (r) {
+            keys[i] = r.cluster.member.key;
+            distances[i] = r.cluster.distance;
+        }
         if (visited)
             visited[i] = r.visited_members;
         if (computed)

@@ -16,9 +16,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF_LIB_PATH = os.path.join(HERE, "_ref", "libusearch_ref.so")
 
 # c/usearch.h:40-62
-METRIC = {"cos": 1, "ip": 2, "l2sq": 3, "hamming": 8}
+METRIC = {"cos": 1, "ip": 2, "l2sq": 3, "haversine": 4, "divergence": 5, "pearson": 6, "jaccard": 7, "hamming": 8,
+          "tanimoto": 9, "sorensen": 10}
 SCALAR = {"f32": 1, "f64": 2, "f16": 3, "i8": 4, "b1": 5, "bf16": 6}
-NP_DTYPE = {"f32": np.float32, "f64": np.float64, "f16": np.float16, "i8": np.int8, "b1": np.uint8}
+NP_DTYPE = {"f32": np.float32, "f64": np.float64, "f16": np.float16, "i8": np.int8, "b1": np.uint8,
+            "bf16": np.uint16}  # numpy has no bfloat16: bf16 rows travel as their uint16 bit patterns
 
 
 class InitOptions(C.Structure):
@@ -79,6 +81,8 @@ def lib() -> C.CDLL:
                                            C.c_int, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p,
                                            C.c_size_t, C.c_void_p, C.c_size_t, err_p]
         L.uref_max_threads.restype = C.c_int
+        L.uref_cluster_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.uref_add_many.restype = C.c_size_t
         L.uref_add_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t]
         L.uref_search_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int,
@@ -188,6 +192,20 @@ class RefIndex:
             lib().uref_search_many(self.handle, _ptr(queries), SCALAR[dtype], q, queries.strides[0], k, int(exact),
                                    threads, _ptr(keys), _ptr(dists), _ptr(counts), _ptr(visited), _ptr(computed))
         return keys, dists, counts, visited, computed
+
+    def cluster(self, queries: np.ndarray, level: int, dtype: Optional[str] = None, threads: int = 0):
+        """Batched `index_dense_gt::cluster(query, level)` → (keys[Q], distances[Q], visited[Q], computed[Q])."""
+        dtype = dtype or self.dtype
+        queries = np.ascontiguousarray(queries)
+        q = len(queries)
+        keys = np.zeros(q, dtype=np.uint64)
+        dists = np.zeros(q, dtype=np.float32)
+        visited = np.zeros(q, dtype=np.uint64)
+        computed = np.zeros(q, dtype=np.uint64)
+        if q:
+            lib().uref_cluster_many(self.handle, _ptr(queries), SCALAR[dtype], q, queries.strides[0], level, threads,
+                                    _ptr(keys), _ptr(dists), _ptr(visited), _ptr(computed))
+        return keys, dists, visited, computed
 
     def search_one(self, query: np.ndarray, k: int, dtype: Optional[str] = None):
         """The C-ABI hot signature itself: `usearch_search` (`c/usearch.h:371-374`)."""

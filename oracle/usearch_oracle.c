@@ -105,6 +105,14 @@ int uo_open(uo_index_t* ix, const void* image, size_t length, const char** error
     ix->rows = ld32(p);
     ix->cols = ld32(p + 4);
     p += 8;
+    /* `use_64_bit_dimensions` images announce the matrix with two u64 instead; sniffed the way the reference does it
+     * (index_dense_metadata_from_buffer, index_dense.hpp:321-371): where does the "usearch" magic turn up? */
+    if (length >= 16 && !(ix->rows * ix->cols + 8 + 64 <= length && memcmp(ix->image + ix->rows * ix->cols + 8, "usearch", 7) == 0)) {
+        uint64_t rows64 = ld64(ix->image), cols64 = ld64(ix->image + 8);
+        if (cols64 && rows64 <= length / cols64 && rows64 * cols64 + 16 + 64 <= length &&
+            memcmp(ix->image + rows64 * cols64 + 16, "usearch", 7) == 0)
+            ix->rows = rows64, ix->cols = cols64, p = ix->image + 16;
+    }
     if ((uint64_t)(end - p) < ix->rows * ix->cols + 64) { *error = "File is corrupted and lacks a header"; return 1; }
     ix->vectors = p;
     p += ix->rows * ix->cols;
@@ -177,12 +185,17 @@ uint32_t uo_neighbors(const uo_index_t* ix, uint64_t slot, int level, uint32_t* 
 static const uint8_t* vector_at(const uo_index_t* ix, uint64_t slot) { return ix->vectors + slot * ix->cols; }
 
 /* ------------------------------------------------------------------------------------------------------------------
- *  Metrics (index_plugins.hpp:1309-1414, 1583-1630). Float accumulation layout is explicit — see header.
+ *  Metrics (index_plugins.hpp:1309-1657, dispatch 1930-2008). Float accumulation layout is explicit — see header.
+ *
+ *  Which struct the reference instantiates per (metric, scalar) — `configure_with_autovec`, 1930-2008:
+ *    ip / cos / l2sq / pearson   bf16, f16, f32 → result f32;  f64 → result f64;  i8 → metric_{cos,l2sq}_i8_t (int32) or
+ *                                metric_{ip,pearson}_gt<i8_t, f32_t> (float accumulation of small integers)
+ *    divergence                  bf16, f16, f32 (f32 arithmetic), f64;   haversine  f32, f64 (first two scalars)
+ *    hamming / tanimoto (= jaccard) / sorensen   b1x8 bytes
+ *  Every result is narrowed to `float` (distance_punned_t, 1660; `equidimensional_`, 2010-2014).
  * ---------------------------------------------------------------------------------------------------------------- */
 #define UO_CHUNK 16 /* bytes dealt to one lane at a time */
 #define UO_MAX_LANES 64
-
-typedef struct { float ab, a2, b2, l2; } acc_t;
 
 static float load_float(uint8_t scalar_kind, const uint8_t* p, uint64_t i) {
     switch (scalar_kind) {
@@ -193,63 +206,104 @@ static float load_float(uint8_t scalar_kind, const uint8_t* p, uint64_t i) {
     default: return 0.f;
     }
 }
+static double load_f64(const uint8_t* p, uint64_t i) { double d; memcpy(&d, p + 8 * i, 8); return d; }
 
-static void accumulate(acc_t* acc, float a, float b) {
-    acc->ab = fmaf(a, b, acc->ab);
-    acc->a2 = fmaf(a, a, acc->a2);
-    acc->b2 = fmaf(b, b, acc->b2);
-    float t = a - b;
-    acc->l2 = fmaf(t, t, acc->l2);
+/* The running sums of every equidimensional metric: ab = Σab, a2 = Σa², b2 = Σb², l2 = Σ(a-b)² (ip, cos, l2sq);
+ * sa = Σa, sb = Σb (pearson, 1478-1520); kp, kq = the two Kullback-Leibler sums of divergence (1526-1551). Generated
+ * twice: f32 arithmetic (result_t = f32_t) and f64 arithmetic (result_t = f64_t).
+ *
+ * lanes <= 0: the reference loop order — one chain per accumulator in element order, unfused multiply-add. The
+ * reference lets the compiler reassociate (`omp simd reduction`), so last-bit agreement with one particular build of
+ * it is neither promised nor needed.
+ * lanes = G:  16-byte chunks dealt round-robin to G lanes, one fused chain per lane in chunk order, XOR butterfly. */
+#define UO_DEFINE_SUMS(NAME, T, FMA, LOG, EPSILON, LOAD_A, LOAD_B, PER_CHUNK)                                           \
+    typedef struct { T ab, a2, b2, l2, sa, sb, kp, kq; } NAME##_acc_t;                                                  \
+    static void NAME##_step(NAME##_acc_t* acc, T a, T b, int with_logs, int fused) {                                    \
+        T t = a - b;                                                                                                    \
+        if (fused) {                                                                                                    \
+            acc->ab = FMA(a, b, acc->ab), acc->a2 = FMA(a, a, acc->a2), acc->b2 = FMA(b, b, acc->b2);                   \
+            acc->l2 = FMA(t, t, acc->l2);                                                                               \
+        } else {                                                                                                        \
+            acc->ab += a * b, acc->a2 += a * a, acc->b2 += b * b, acc->l2 += t * t;                                     \
+        }                                                                                                               \
+        acc->sa += a, acc->sb += b;                                                                                     \
+        if (with_logs) {                                                                                                \
+            T m = (a + b) / 2 + EPSILON;                                                                                \
+            acc->kp += a * LOG((a + EPSILON) / m);                                                                      \
+            acc->kq += b * LOG((b + EPSILON) / m);                                                                      \
+        }                                                                                                               \
+    }                                                                                                                   \
+    static T NAME##_butterfly(T* v, int lanes) {                                                                        \
+        T tmp[UO_MAX_LANES];                                                                                            \
+        for (int off = lanes / 2; off >= 1; off >>= 1) {                                                                \
+            for (int l = 0; l < lanes; ++l)                                                                             \
+                tmp[l] = v[l] + v[l ^ off];                                                                             \
+            memcpy(v, tmp, sizeof(T) * (size_t)lanes);                                                                  \
+        }                                                                                                               \
+        return v[0];                                                                                                    \
+    }                                                                                                                   \
+    static NAME##_acc_t NAME##_sums(uint8_t scalar_kind, const uint8_t* a, const uint8_t* b, uint64_t dims, int lanes,  \
+                                    int with_logs) {                                                                    \
+        (void)scalar_kind;                                                                                              \
+        NAME##_acc_t total;                                                                                             \
+        memset(&total, 0, sizeof(total));                                                                               \
+        if (lanes <= 0) {                                                                                               \
+            for (uint64_t i = 0; i < dims; ++i)                                                                         \
+                NAME##_step(&total, LOAD_A, LOAD_B, with_logs, 0);                                                      \
+            return total;                                                                                               \
+        }                                                                                                               \
+        uint64_t per_chunk = PER_CHUNK;                                                                                 \
+        uint64_t chunks = (dims + per_chunk - 1) / per_chunk;                                                           \
+        NAME##_acc_t lane[UO_MAX_LANES];                                                                                \
+        memset(lane, 0, sizeof(lane));                                                                                  \
+        for (uint64_t c = 0; c < chunks; ++c)                                                                           \
+            for (uint64_t i = c * per_chunk; i < (c + 1) * per_chunk && i < dims; ++i)                                  \
+                NAME##_step(&lane[c % (uint64_t)lanes], LOAD_A, LOAD_B, with_logs, 1);                                  \
+        T v[UO_MAX_LANES];                                                                                              \
+        T* fields[8] = {&total.ab, &total.a2, &total.b2, &total.l2, &total.sa, &total.sb, &total.kp, &total.kq};        \
+        for (int f = 0; f < 8; ++f) {                                                                                   \
+            for (int l = 0; l < lanes; ++l)                                                                             \
+                v[l] = *(T*)((uint8_t*)&lane[l] + ((uint8_t*)fields[f] - (uint8_t*)&total));                            \
+            *fields[f] = NAME##_butterfly(v, lanes);                                                                    \
+        }                                                                                                               \
+        return total;                                                                                                   \
+    }                                                                                                                   \
+    /* pearson: metric_pearson_gt 1478-1520 */                                                                          \
+    static T NAME##_pearson(const NAME##_acc_t* s, uint64_t dims) {                                                     \
+        if (dims <= 1)                                                                                                  \
+            return 0;                                                                                                   \
+        T n = (T)dims;                                                                                                  \
+        T denom = (n * s->a2 - s->sa * s->sa) * (n * s->b2 - s->sb * s->sb);                                            \
+        if (denom == 0)                                                                                                 \
+            return 0;                                                                                                   \
+        T corr = n * s->ab - s->sa * s->sb;                                                                             \
+        return 1 - corr / (T)sqrt((double)denom);                                                                       \
+    }
+
+#define UO_FLOAT_PER_CHUNK (UO_CHUNK / (uo_bytes_per_vector(scalar_kind, 8) / 8))
+UO_DEFINE_SUMS(f32, float, fmaf, logf, 1.1920928955078125e-7f, load_float(scalar_kind, a, i), load_float(scalar_kind, b, i),
+               UO_FLOAT_PER_CHUNK)
+UO_DEFINE_SUMS(f64, double, fma, log, 2.220446049250313e-16, load_f64(a, i), load_f64(b, i), 2)
+
+/* metric_haversine_gt 1636-1657: latitude, longitude in degrees; angle_to_radians 203 */
+static float haversine_f32(const uint8_t* a, const uint8_t* b) {
+    const float pi = (float)3.14159265358979323846;
+    float lat_a = load_float(UO_SCALAR_F32, a, 0), lon_a = load_float(UO_SCALAR_F32, a, 1);
+    float lat_b = load_float(UO_SCALAR_F32, b, 0), lon_b = load_float(UO_SCALAR_F32, b, 1);
+    float lat_delta = ((lat_b - lat_a) * pi / 180.f) / 2, lon_delta = ((lon_b - lon_a) * pi / 180.f) / 2;
+    float cla = lat_a * pi / 180.f, clb = lat_b * pi / 180.f;
+    float s1 = sinf(lat_delta), s2 = sinf(lon_delta);
+    float x = s1 * s1 + cosf(cla) * cosf(clb) * (s2 * s2);
+    return 2 * asinf(sqrtf(x));
 }
-
-/* XOR butterfly, offsets lanes/2 … 1: every lane ends with the same bit pattern (fp add is commutative). */
-static float butterfly(float* v, int lanes) {
-    float tmp[UO_MAX_LANES];
-    for (int off = lanes / 2; off >= 1; off >>= 1) {
-        for (int l = 0; l < lanes; ++l)
-            tmp[l] = v[l] + v[l ^ off];
-        memcpy(v, tmp, sizeof(float) * (size_t)lanes);
-    }
-    return v[0];
-}
-
-static acc_t float_sums(uint8_t scalar_kind, const uint8_t* a, const uint8_t* b, uint64_t dims, int lanes) {
-    acc_t total = {0, 0, 0, 0};
-    if (lanes <= 0) {
-        /* Reference loop order: one chain per accumulator, element order (index_plugins.hpp:1322-1323, 1347-1351,
-         * 1378-1382). The reference itself lets the compiler reassociate (`omp simd reduction`), so last-bit
-         * agreement with a particular reference build is neither promised nor needed. */
-        float ab = 0, a2 = 0, b2 = 0, l2 = 0;
-        for (uint64_t i = 0; i < dims; ++i) {
-            float ai = load_float(scalar_kind, a, i), bi = load_float(scalar_kind, b, i);
-            ab += ai * bi;
-            a2 += ai * ai;
-            b2 += bi * bi;
-            l2 += (ai - bi) * (ai - bi);
-        }
-        total.ab = ab, total.a2 = a2, total.b2 = b2, total.l2 = l2;
-        return total;
-    }
-    size_t bytes_per_scalar = uo_bytes_per_vector(scalar_kind, 8) / 8;
-    uint64_t per_chunk = UO_CHUNK / bytes_per_scalar;
-    uint64_t chunks = (dims + per_chunk - 1) / per_chunk;
-    acc_t lane[UO_MAX_LANES];
-    memset(lane, 0, sizeof(lane));
-    for (uint64_t c = 0; c < chunks; ++c) {
-        acc_t* acc = &lane[c % (uint64_t)lanes];
-        for (uint64_t e = c * per_chunk; e < (c + 1) * per_chunk && e < dims; ++e)
-            accumulate(acc, load_float(scalar_kind, a, e), load_float(scalar_kind, b, e));
-    }
-    float v[UO_MAX_LANES];
-    for (int l = 0; l < lanes; ++l) v[l] = lane[l].ab;
-    total.ab = butterfly(v, lanes);
-    for (int l = 0; l < lanes; ++l) v[l] = lane[l].a2;
-    total.a2 = butterfly(v, lanes);
-    for (int l = 0; l < lanes; ++l) v[l] = lane[l].b2;
-    total.b2 = butterfly(v, lanes);
-    for (int l = 0; l < lanes; ++l) v[l] = lane[l].l2;
-    total.l2 = butterfly(v, lanes);
-    return total;
+static float haversine_f64(const uint8_t* a, const uint8_t* b) {
+    const double pi = 3.14159265358979323846;
+    double lat_a = load_f64(a, 0), lon_a = load_f64(a, 1), lat_b = load_f64(b, 0), lon_b = load_f64(b, 1);
+    double lat_delta = ((lat_b - lat_a) * pi / 180.0) / 2, lon_delta = ((lon_b - lon_a) * pi / 180.0) / 2;
+    double cla = lat_a * pi / 180.0, clb = lat_b * pi / 180.0;
+    double s1 = sin(lat_delta), s2 = sin(lon_delta);
+    double x = s1 * s1 + cos(cla) * cos(clb) * (s2 * s2);
+    return (float)(2 * asin(sqrt(x)));
 }
 
 float uo_distance(uint8_t metric_kind, uint8_t scalar_kind, const void* av, const void* bv, uint64_t dims,
@@ -257,13 +311,29 @@ float uo_distance(uint8_t metric_kind, uint8_t scalar_kind, const void* av, cons
     const uint8_t* a = (const uint8_t*)av;
     const uint8_t* b = (const uint8_t*)bv;
     if (scalar_kind == UO_SCALAR_B1) {
-        /* metric_hamming_gt<b1x8_t> (index_plugins.hpp:1392-1414) over ceil(d/8) bytes (1744) */
-        uint64_t words = (dims + 7) / 8, matches = 0;
-        for (uint64_t i = 0; i < words; ++i)
-            matches += (uint64_t)__builtin_popcount((unsigned)(a[i] ^ b[i]));
-        return metric_kind == UO_METRIC_HAMMING ? (float)matches : NAN;
+        /* bit-set metrics over ceil(d/8) bytes (1744): metric_hamming_gt 1392-1414, metric_tanimoto_gt 1420-1445 (jaccard
+         * maps to it, 2003-2004), metric_sorensen_gt 1451-1476. The counts are exact; the fractions are f32 divisions. */
+        uint64_t words = (dims + 7) / 8, differ = 0, both = 0, either = 0, total = 0;
+        for (uint64_t i = 0; i < words; ++i) {
+            differ += (uint64_t)__builtin_popcount((unsigned)(a[i] ^ b[i]));
+            both += (uint64_t)__builtin_popcount((unsigned)(a[i] & b[i]));
+            either += (uint64_t)__builtin_popcount((unsigned)(a[i] | b[i]));
+            total += (uint64_t)__builtin_popcount((unsigned)a[i]) + (uint64_t)__builtin_popcount((unsigned)b[i]);
+        }
+        switch (metric_kind) {
+        case UO_METRIC_HAMMING: return (float)differ;
+        case UO_METRIC_JACCARD:
+        case UO_METRIC_TANIMOTO: return 1 - (float)both / (float)either;
+        case UO_METRIC_SORENSEN: return 1 - 2 * (float)both / (float)total;
+        default: return NAN;
+        }
     }
-    if (scalar_kind == UO_SCALAR_I8 && metric_kind != UO_METRIC_IP) {
+    if (metric_kind == UO_METRIC_HAVERSINE) {
+        if (scalar_kind == UO_SCALAR_F32) return haversine_f32(a, b);
+        if (scalar_kind == UO_SCALAR_F64) return haversine_f64(a, b);
+        return NAN;
+    }
+    if (scalar_kind == UO_SCALAR_I8 && (metric_kind == UO_METRIC_L2SQ || metric_kind == UO_METRIC_COS)) {
         int32_t ab = 0, a2 = 0, b2 = 0, l2 = 0;
         for (uint64_t i = 0; i < dims; ++i) {
             int16_t ai = (int8_t)a[i], bi = (int8_t)b[i];
@@ -272,13 +342,27 @@ float uo_distance(uint8_t metric_kind, uint8_t scalar_kind, const void* av, cons
         }
         if (metric_kind == UO_METRIC_L2SQ) /* metric_l2sq_i8_t 1613-1630 */
             return (float)l2;
-        if (metric_kind == UO_METRIC_COS) { /* metric_cos_i8_t 1583-1607, incl. the `ab == 0 → 0` quirk */
-            float a2f = sqrtf((float)a2), b2f = sqrtf((float)b2);
-            return (ab != 0) ? (1.f - (float)ab / (a2f * b2f)) : 0.f;
-        }
-        return NAN;
+        /* metric_cos_i8_t 1583-1607, incl. the `ab == 0 → 0` quirk */
+        float a2f = sqrtf((float)a2), b2f = sqrtf((float)b2);
+        return (ab != 0) ? (1.f - (float)ab / (a2f * b2f)) : 0.f;
     }
-    acc_t s = float_sums(scalar_kind, a, b, dims, lanes);
+    if (scalar_kind == UO_SCALAR_I8 && metric_kind == UO_METRIC_DIVERGENCE)
+        return NAN; /* no such instantiation (1991-2001) */
+    if (scalar_kind == UO_SCALAR_F64) {
+        f64_acc_t s = f64_sums(scalar_kind, a, b, dims, lanes, metric_kind == UO_METRIC_DIVERGENCE);
+        switch (metric_kind) {
+        case UO_METRIC_IP: return (float)(1 - s.ab);
+        case UO_METRIC_COS:
+            if (s.a2 == 0 && s.b2 == 0) return 0.f;
+            if (s.a2 == 0 || s.b2 == 0) return 1.f;
+            return (float)(1 - s.ab / (sqrt(s.a2) * sqrt(s.b2)));
+        case UO_METRIC_L2SQ: return (float)s.l2;
+        case UO_METRIC_PEARSON: return (float)f64_pearson(&s, dims);
+        case UO_METRIC_DIVERGENCE: return (float)((s.kp + s.kq) / 2);
+        default: return NAN;
+        }
+    }
+    f32_acc_t s = f32_sums(scalar_kind, a, b, dims, lanes, metric_kind == UO_METRIC_DIVERGENCE);
     switch (metric_kind) {
     case UO_METRIC_IP: return 1.f - s.ab; /* metric_ip_gt 1309-1326 */
     case UO_METRIC_COS: {                 /* metric_cos_gt 1334-1359 */
@@ -287,6 +371,8 @@ float uo_distance(uint8_t metric_kind, uint8_t scalar_kind, const void* av, cons
         return 1.f - s.ab / (sqrtf(s.a2) * sqrtf(s.b2));
     }
     case UO_METRIC_L2SQ: return s.l2; /* metric_l2sq_gt 1365-1385 */
+    case UO_METRIC_PEARSON: return f32_pearson(&s, dims);
+    case UO_METRIC_DIVERGENCE: return (s.kp + s.kq) / 2; /* metric_divergence_gt 1526-1551 */
     default: return NAN;
     }
 }
@@ -321,6 +407,7 @@ int uo_cast(uint8_t from, uint8_t to, const void* inv, uint64_t dims, void* outv
             else if (to == UO_SCALAR_F16) { uint16_t h = f32_to_f16((float)bit); memcpy(out + 2 * i, &h, 2); }
             else if (to == UO_SCALAR_I8) out[i] = (uint8_t)bit;
             else if (to == UO_SCALAR_F64) { double d = bit; memcpy(out + 8 * i, &d, 8); }
+            else if (to == UO_SCALAR_BF16) { uint16_t h = bit ? 0x3F80u : 0u; memcpy(out + 2 * i, &h, 2); }
         }
         return 1;
     }
@@ -349,6 +436,13 @@ int uo_cast(uint8_t from, uint8_t to, const void* inv, uint64_t dims, void* outv
                 /* f16_bits_t(int)/float → float division, then f16_bits_t(float) (index_plugins.hpp:486-496, 1198) */
                 float q = f16_to_f32(f32_to_f16((float)x)) / 127.f;
                 uint16_t h = f32_to_f16(q);
+                memcpy(out + 2 * i, &h, 2);
+            } else if (to == UO_SCALAR_BF16) {
+                /* bf16_bits_t(int) is exact for |x| <= 127 (8 significant bits); the quotient is truncated (f32_to_bf16, 453-469) */
+                float q = (float)x / 127.f;
+                uint32_t bits;
+                memcpy(&bits, &q, 4);
+                uint16_t h = (uint16_t)(bits >> 16);
                 memcpy(out + 2 * i, &h, 2);
             }
         }
@@ -654,6 +748,34 @@ void uo_search_many(const uo_index_t* ix, const void* queries, uint8_t query_kin
                                    visited ? visited + q : NULL, computed ? computed + q : NULL);
         if (counts) counts[q] = n;
     }
+    ctx_free(&c);
+}
+
+void uo_cluster_many(const uo_index_t* ix, const void* queries, uint8_t query_kind, size_t count, size_t stride,
+                     size_t level, int lanes, uint64_t* keys, float* distances, uint64_t* visited, uint64_t* computed) {
+    /* index_gt::cluster (index.hpp:3089-3125) behind index_dense_gt::cluster_ (index_dense.hpp:788-793): the greedy descent
+     * of search_for_one_ from the top level down to `level` (target level = level - 1, or 0), then ONE more evaluation of
+     * the winner's distance (3115), which the counters include. An empty index fails with "No clusters to identify":
+     * key 0 / signalling NaN here. */
+    ctx_t c;
+    if (!ctx_init(&c, ix, lanes, NULL, NULL)) return;
+    size_t bpv = uo_bytes_per_vector(ix->scalar_kind, ix->dimensions);
+    uint8_t* casted = (uint8_t*)calloc(bpv + 16, 1);
+    for (size_t q = 0; q < count; ++q) {
+        const uint8_t* query = (const uint8_t*)queries + q * stride;
+        c.computed_distances = c.iteration_cycles = 0;
+        memset(casted, 0, bpv + 16);
+        c.query = uo_cast(query_kind, ix->scalar_kind, query, ix->dimensions, casted) ? casted : query;
+        keys[q] = 0, distances[q] = signaling_nan();
+        if (ix->size) {
+            uint32_t member = search_for_one(&c, (uint32_t)ix->entry_slot, (int)ix->max_level, level ? (int)level - 1 : 0);
+            keys[q] = uo_key(ix, member);
+            distances[q] = measure(&c, member);
+        }
+        if (visited) visited[q] = c.iteration_cycles;
+        if (computed) computed[q] = c.computed_distances;
+    }
+    free(casted);
     ctx_free(&c);
 }
 

@@ -73,6 +73,28 @@ int main(int argc, char** argv) {
     for (std::size_t j = 0; j < a.size(); ++j)
         EXPECT(a[j].key == b[j].key && a[j].distance == b[j].distance);
     std::remove("/tmp/usearch_amd_class_test.usearch");
+
+    // the remaining scalar overloads of index_dense.hpp:760-772: doubles (pearson, as c/test.c:246-250 configures it) and
+    // brain floats as bit patterns
+    auto doubles = index_dense_t::make(dimensions, usearch_metric_pearson_k, usearch_scalar_f64_k);
+    EXPECT(doubles);
+    std::vector<double> wide(data.begin(), data.begin() + 300 * dimensions);
+    for (std::size_t i = 0; i < 300; ++i)
+        EXPECT(doubles.index.add(i, wide.data() + i * dimensions));
+    auto nearest = doubles.index.search(wide.data() + 17 * dimensions, 3);
+    EXPECT(nearest && nearest.size() == 3 && nearest[0].key == 17 && std::fabs(nearest[0].distance) < 1e-6f);
+    auto brains = index_dense_t::make(dimensions, usearch_metric_cos_k, usearch_scalar_bf16_k);
+    EXPECT(brains);
+    std::vector<bf16_bits_t> narrow(300 * dimensions);
+    for (std::size_t i = 0; i < narrow.size(); ++i) {
+        std::uint32_t bits;
+        std::memcpy(&bits, &data[i], 4);
+        narrow[i].bits = (std::uint16_t)(bits >> 16);
+    }
+    for (std::size_t i = 0; i < 300; ++i)
+        EXPECT(brains.index.add(i, narrow.data() + i * dimensions));
+    auto brain_hit = brains.index.search(narrow.data() + 5 * dimensions, 3);
+    EXPECT(brain_hit && brain_hit[0].key == 5 && std::fabs(brain_hit[0].distance) < 1e-3f);
     std::printf("class test passed\n");
     return 0;
 }

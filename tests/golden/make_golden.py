@@ -4,7 +4,7 @@
 Run where /root/reference is mounted (it compiles `oracle/_ref/libusearch_ref.so` from the reference's own sources through
 `oracle/Makefile` if needed):
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [--all]
 
 Each `tests/golden/<name>.npz` holds a small index image serialized by the reference (`usearch_save_buffer`), seeded
 queries, and what the reference itself answers for them (`index_dense_gt::search`, single-threaded): keys, distances,
@@ -33,6 +33,15 @@ CASES = [
     ("cos_i8_33", "cos", "i8", 33, 300, 16, 10, 64, 24),
     ("hamming_b1_128", "hamming", "b1", 128, 800, 16, 10, 64, 48),
     ("hamming_b1_72", "hamming", "b1", 72, 300, 4, 3, 8, 24),
+    # the rest of the reference's metric x scalar dispatch table (index_plugins.hpp:1930-2008)
+    ("cos_bf16_64", "cos", "bf16", 64, 300, 16, 10, 64, 24),
+    ("l2sq_f64_16", "l2sq", "f64", 16, 300, 8, 5, 32, 24),
+    ("pearson_f32_24", "pearson", "f32", 24, 300, 16, 10, 64, 24),
+    ("pearson_i8_40", "pearson", "i8", 40, 300, 16, 10, 64, 24),
+    ("divergence_f32_32", "divergence", "f32", 32, 300, 16, 10, 64, 24),
+    ("haversine_f32_2", "haversine", "f32", 2, 400, 16, 10, 64, 32),
+    ("tanimoto_b1_128", "tanimoto", "b1", 128, 500, 16, 10, 64, 32),
+    ("sorensen_b1_72", "sorensen", "b1", 72, 300, 8, 5, 32, 24),
 ]
 
 
@@ -40,11 +49,14 @@ def main():
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libusearch_ref.so")):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
     from tests import util
+    regenerate_all = "--all" in sys.argv  # default: only the fixtures that are not there yet
     for name, metric, dtype, ndim, n, connectivity, k, expansion, nq in CASES:
+        if os.path.exists(os.path.join(HERE, f"{name}.npz")) and not regenerate_all:
+            continue
         removed = np.arange(5, n, 7) + 1000 if name == "cos_f32_24" else ()
         image, vectors, index = util.build_image(n, ndim, metric, dtype, seed=101, connectivity=connectivity,
                                                  remove=removed)
-        queries = util.make_vectors(nq, ndim, dtype, seed=202)
+        queries = util.make_vectors(nq, ndim, dtype, seed=202, metric=metric)
         queries[: nq // 4] = vectors[: nq // 4]
         index.expansion_search = expansion
         keys, distances, counts, visited, computed = index.search(queries, k, dtype=dtype, threads=1)

@@ -103,6 +103,44 @@ def test_built_graph_is_valid_and_as_good_as_the_references(reference, metric, d
     assert np.array_equal(redo.keys, got.keys) and util.same_float_bits(redo.distances, got.distances)
 
 
+OTHER_PAIRS = [
+    # the rest of the reference's metric x scalar dispatch table: metric, dtype, ndim, n
+    ("cos", "bf16", 64, 3000), ("l2sq", "f64", 24, 3000), ("pearson", "f32", 48, 3000), ("pearson", "i8", 64, 3000),
+    ("divergence", "f32", 32, 2500), ("haversine", "f32", 2, 3000), ("tanimoto", "b1", 128, 4000),
+    ("sorensen", "b1", 256, 3000),
+]
+
+
+@pytest.mark.parametrize("metric,dtype,ndim,n", OTHER_PAIRS)
+def test_build_with_the_other_metric_scalar_pairs(reference, metric, dtype, ndim, n):
+    """Construction runs the same distance loop as the search, so every pair with a search kernel builds too."""
+    vectors = util.make_vectors(n, ndim, dtype, seed=21, metric=metric)
+    queries = util.make_vectors(200, ndim, dtype, seed=22, metric=metric)
+    built = usearch_amd.build(vectors, metric, dtype, connectivity=16, expansion_add=128, max_batch=512)
+    assert built.stats.dropped_requests == 0
+    image = built.save_buffer()
+    check_structure(image, n, 16)
+    theirs = refbind.RefIndex.from_buffer(image, view=False, dtype=dtype)
+    assert len(theirs) == n
+    own = refbind.RefIndex(ndim, metric, dtype, connectivity=16, expansion_add=128)
+    own.add(np.arange(n, dtype=np.uint64), vectors, threads=1)
+    truth_d = theirs.search(queries, 10, dtype=dtype, exact=True)[1]
+    ours_d, own_d = theirs.search(queries, 10, dtype=dtype)[1], own.search(queries, 10, dtype=dtype)[1]
+    slack = 1e-6 * np.maximum(1.0, np.abs(truth_d[:, -1]))  # recall by distance: robust to ties between equal distances
+    ours_recall = float(np.mean(ours_d[:, -1] <= truth_d[:, -1] + slack))
+    own_recall = float(np.mean(own_d[:, -1] <= truth_d[:, -1] + slack))
+    assert ours_recall >= own_recall - 0.05, (ours_recall, own_recall)
+    got = built.index.search(queries, 10, dtype=dtype)
+    okeys, odistances, ocounts, ovisited, ocomputed = util.oracle_search(image, queries, 10, dtype, expansion=64,
+                                                                         lanes=built.index.lanes_per_row)
+    assert np.array_equal(got.counts, ocounts)
+    if util.layout_exact(metric):
+        assert np.array_equal(got.keys, okeys) and util.same_float_bits(got.distances, odistances)
+        assert np.array_equal(got.visited_per_query, ovisited) and np.array_equal(got.computed_per_query, ocomputed)
+    else:
+        assert (got.keys == okeys).mean() > 0.98
+
+
 def test_build_is_reproducible_and_takes_device_vectors():
     import ctypes
     vectors = util.make_vectors(4000, 96, "f16", seed=5)

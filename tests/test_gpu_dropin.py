@@ -3,8 +3,7 @@ call through ctypes — /root/reference/c/test.c:52-368 (`test_init`, `test_add_
 `test_get_vector`, `test_remove_vector`, `test_save_load`, `test_view`, sizes {11, 512} x dimensions {83, 2} as in its
 `main`, c/test.c:370-393) — plus the exact-value checks the other bindings' tests hold for this ABI
 (golang/lib_test.go:835-877 distances, cpp/test.cpp:1105-1145 filtered search) and a side-by-side run against the real
-reference library on the same calls. The one deviation: c/test.c:246-250 saves a pearson/f64 index; those kernels do not
-exist yet, so the save/load case uses cos/f16 with the same odd connectivity and expansions."""
+reference library on the same calls (the save / load case with c/test.c:246-250's own pearson / f64 configuration)."""
 import ctypes as C
 import os
 
@@ -19,7 +18,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBRARY = os.path.join(ROOT, "usearch_amd", "lib", "libusearch_c.so")
 
-METRIC = {"cos": 1, "ip": 2, "l2sq": 3, "hamming": 8, "pearson": 6}
+METRIC = {"cos": 1, "ip": 2, "l2sq": 3, "haversine": 4, "hamming": 8, "pearson": 6}
 SCALAR = {"f32": 1, "f64": 2, "f16": 3, "i8": 4, "b1": 5}
 
 
@@ -176,8 +175,8 @@ def test_c_test_program(lib, count, dimensions, tmp_path):
 
     # test_save_load, c/test.c:241-328 (odd connectivity / expansions survive the round trip through a shell index)
     path = str(tmp_path / "tmp.usearch").encode()
-    weird = create_options(dimensions, connectivity=11, expansion_add=15, expansion_search=19, metric_kind=METRIC["cos"],
-                           quantization=SCALAR["f16"])
+    weird = create_options(dimensions, connectivity=11, expansion_add=15, expansion_search=19,
+                           metric_kind=METRIC["pearson"], quantization=SCALAR["f64"])
     index, _ = filled_index(lib, count, dimensions, options=weird, data=data)
     lib.usearch_save(index, path, C.byref(err))
     ok(err)
@@ -185,7 +184,7 @@ def test_c_test_program(lib, count, dimensions, tmp_path):
     meta = Options()
     lib.usearch_metadata(path, C.byref(meta), C.byref(err))
     ok(err)
-    assert (meta.metric_kind, meta.quantization, meta.dimensions, meta.connectivity) == (1, 3, dimensions, 11)
+    assert (meta.metric_kind, meta.quantization, meta.dimensions, meta.connectivity) == (6, 2, dimensions, 11)
     index = lib.usearch_init(None, C.byref(err))
     ok(err)
     lib.usearch_load(index, path, C.byref(err))
@@ -199,15 +198,15 @@ def test_c_test_program(lib, count, dimensions, tmp_path):
         ok(err)
         assert 1 <= found <= count
     # the REAL reference loads what the drop-in saved and answers the same queries with the same labels
-    theirs = refbind.RefIndex.from_buffer(np.fromfile(path.decode(), dtype=np.uint8), dtype="f16")
+    theirs = refbind.RefIndex.from_buffer(np.fromfile(path.decode(), dtype=np.uint8), dtype="f64")
     assert len(theirs) == count
     theirs.expansion_search = 64
     lib.usearch_change_expansion_search(index, 64, C.byref(err))
     their_keys, their_distances, *_ = theirs.search(data[:8], 3, dtype="f32")
     for i in range(8):
         lib.usearch_search(index, ptr(data[i]), SCALAR["f32"], 3, ptr(keys), ptr(distances), C.byref(err))
-        assert np.allclose(distances[:3], their_distances[i], atol=2e-3)
-        if dimensions > 2:  # 2-d cosine distances are full of near-ties
+        assert np.allclose(distances[:3], their_distances[i], atol=1e-5)
+        if dimensions > 2:  # the Pearson distance of 2-d vectors is 0, 1 or 2: ties everywhere
             assert np.array_equal(keys[:3], their_keys[i])
     lib.usearch_free(index, C.byref(err))
 
@@ -231,8 +230,14 @@ def test_known_distances(lib):
     assert lib.usearch_distance(ptr(q), ptr(x), SCALAR["b1"], 8, METRIC["hamming"], C.byref(err)) == 2.0
     assert lib.usearch_distance(ptr(q), ptr(y), SCALAR["b1"], 8, METRIC["hamming"], C.byref(err)) == 6.0
     ok(err)
-    lib.usearch_distance(ptr(e1), ptr(e2), SCALAR["f32"], 3, METRIC["pearson"], C.byref(err))
-    assert err.value and b"kernel" in err.value  # refused by name, never silently computed elsewhere
+    # pearson: e1 vs e2 in 3-d → correlation -1/2 → distance 1.5 (metric_pearson_gt, index_plugins.hpp:1478-1520)
+    assert abs(lib.usearch_distance(ptr(e1), ptr(e2), SCALAR["f32"], 3, METRIC["pearson"], C.byref(err)) - 1.5) < 1e-6
+    ok(err)
+    # what the reference's dispatch table does not hold has no kernel either (haversine over half floats,
+    # index_plugins.hpp:1981-1982): refused by name, never silently computed elsewhere
+    half = np.zeros(2, dtype=np.float16)
+    lib.usearch_distance(ptr(half), ptr(half), SCALAR["f16"], 2, METRIC["haversine"], C.byref(err))
+    assert err.value and b"kernel" in err.value
 
 
 def test_filtered_search_and_rename(lib):

@@ -39,7 +39,7 @@ def test_exact_matches_reference_golden():
         meta = json.loads(str(data["meta"]))
         got = Index.restore(data["image"]).search(data["queries"], meta["k"], dtype=meta["dtype"], exact=True)
         assert np.array_equal(got.counts, data["exact_counts"])
-        if meta["dtype"] in ("i8", "b1") and meta["metric"] != "cos":
+        if util.exact_pair(meta["metric"], meta["dtype"]):
             assert np.array_equal(got.keys, data["exact_keys"]), path
             assert util.same_float_bits(got.distances, data["exact_distances"])
         else:

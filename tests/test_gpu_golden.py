@@ -23,13 +23,13 @@ def test_gpu_reproduces_reference_answers(path):
     got = index.search(data["queries"], meta["k"], expansion=meta["expansion"], dtype=meta["dtype"])
     assert np.array_equal(got.counts, data["counts"])
     found = np.arange(meta["k"])[None, :] < data["counts"][:, None]
-    if meta["dtype"] in ("i8", "b1") and meta["metric"] != "cos":
+    if util.exact_pair(meta["metric"], meta["dtype"]):
         assert np.array_equal(got.keys, data["keys"])
         assert util.same_float_bits(got.distances, data["distances"])
         assert np.array_equal(got.visited_per_query, data["visited"])
         assert np.array_equal(got.computed_per_query, data["computed"])
     else:
-        tolerance = 2e-3 if meta["dtype"] == "f16" else 1e-5
+        tolerance = util.tolerance(meta["dtype"])
         reference = np.where(found, data["distances"], 0)
         assert np.all(np.abs(np.where(found, got.distances, 0) - reference) <= tolerance * np.maximum(1, np.abs(reference)))
         assert ((got.keys == data["keys"]) | ~found).mean() > 0.99
@@ -51,3 +51,15 @@ def test_known_answer_searches():
         assert got.keys.tolist() == case["expected_keys"], case["source"]
         if case["expected_distances"]:
             assert got.distances.tolist() == case["expected_distances"]
+
+
+def test_images_with_64_bit_matrix_dimensions():
+    """`serialization_config_t::use_64_bit_dimensions` (index_dense.hpp:1006-1024): same index, two u64 in front."""
+    from usearch_amd import Index
+    data = np.load(os.path.join(GOLDEN, "l2sq_i8_96.npz"))
+    meta = json.loads(str(data["meta"]))
+    index = Index.restore(util.with_64_bit_dimensions(data["image"]))
+    assert len(index) == meta["n"]
+    got = index.search(data["queries"], meta["k"], expansion=meta["expansion"], dtype=meta["dtype"])
+    assert np.array_equal(got.keys, data["keys"]) and util.same_float_bits(got.distances, data["distances"])
+    assert np.array_equal(got.computed_per_query, data["computed"])

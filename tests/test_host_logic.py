@@ -66,11 +66,15 @@ def test_corrupt_images_are_rejected():
     rows, cols = np.frombuffer(image[:8].tobytes(), dtype=np.uint32)
     broken[8 + int(rows) * int(cols)] ^= 0xFF
     cases["no magic"] = broken
+    from tests import util
+    cases["saved without vectors"] = util.without_vectors(image)  # index_dense.hpp:1004: nothing to search in there
     for name, data in cases.items():
         data = np.ascontiguousarray(data)
         err = C.c_char_p()
         handle = library.usearch_amd_snapshot_from_buffer(C.c_void_p(data.ctypes.data), data.size, 0, C.byref(err))
         assert not handle and err.value, name
+        if name == "saved without vectors":
+            assert b"exclude_vectors" in err.value
 
 
 REFERENCE_C_ABI = [  # the 38 entry points of /root/reference/c/usearch.h:116-481 (verified with `nm -D`)

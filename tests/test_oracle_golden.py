@@ -32,13 +32,13 @@ def test_oracle_reproduces_reference_answers(path):
                                                               expansion=meta["expansion"], lanes=0)
     assert np.array_equal(counts, data["counts"])
     found = np.arange(meta["k"])[None, :] < counts[:, None]
-    if meta["dtype"] in ("i8", "b1") and meta["metric"] != "cos":
+    if util.exact_pair(meta["metric"], meta["dtype"]):
         # integer-valued distances: everything is exact, ties included (container semantics restated literally)
         assert np.array_equal(keys, data["keys"])
         assert util.same_float_bits(distances, data["distances"])
         assert np.array_equal(visited, data["visited"]) and np.array_equal(computed, data["computed"])
     else:
-        tolerance = 2e-3 if meta["dtype"] == "f16" else 1e-5
+        tolerance = util.tolerance(meta["dtype"])
         reference = np.where(found, data["distances"], 0)
         assert np.all(np.abs(np.where(found, distances, 0) - reference) <= tolerance * np.maximum(1, np.abs(reference)))
         assert ((keys == data["keys"]) | ~found).mean() > 0.99
@@ -51,7 +51,7 @@ def test_oracle_exact_search(path):
     index = oraclebind.OracleIndex(data["image"])
     keys, distances, counts, *_ = index.search(data["queries"], meta["k"], dtype=meta["dtype"], exact=True)
     assert np.array_equal(counts, data["exact_counts"])
-    if meta["dtype"] in ("i8", "b1") and meta["metric"] != "cos":
+    if util.exact_pair(meta["metric"], meta["dtype"]):
         assert np.array_equal(keys, data["exact_keys"]) and util.same_float_bits(distances, data["exact_distances"])
     else:
         assert (keys == data["exact_keys"]).mean() > 0.99
@@ -86,3 +86,14 @@ def test_merge_into_places_later_equals_first():
     count = oraclebind.merge_into(keys, dists, count, np.array([7, 8]), np.array([2.0, 2.0]), 2)
     assert count == 4
     assert keys.tolist() == [1, 8, 7, 2] and dists.tolist() == [1.0, 2.0, 2.0, 2.0]
+
+
+def test_images_with_64_bit_matrix_dimensions():
+    """`use_64_bit_dimensions` (index_dense.hpp:1006-1024) changes the first bytes only; sniffed like index_dense.hpp:321-371."""
+    data, meta = load(os.path.join(GOLDEN, "l2sq_i8_96.npz"))
+    wide = oraclebind.OracleIndex(util.with_64_bit_dimensions(data["image"]))
+    assert len(wide) == meta["n"] and wide.ndim == meta["ndim"]
+    keys, distances, counts, visited, computed = wide.search(data["queries"], meta["k"], dtype=meta["dtype"],
+                                                             expansion=meta["expansion"])
+    assert np.array_equal(keys, data["keys"]) and util.same_float_bits(distances, data["distances"])
+    assert np.array_equal(computed, data["computed"])

@@ -5,12 +5,29 @@ import numpy as np
 
 from oracle import oraclebind, refbind
 
-NP_DTYPE = {"f32": np.float32, "f16": np.float16, "i8": np.int8, "b1": np.uint8}
+NP_DTYPE = {"f32": np.float32, "f64": np.float64, "f16": np.float16, "i8": np.int8, "b1": np.uint8, "bf16": np.uint16}
 
 
-def make_vectors(n: int, ndim: int, dtype: str, seed: int, clustered: bool = True) -> np.ndarray:
-    """Seeded vectors in the storage kind. `clustered` = low-rank latent + noise so that HNSW has structure."""
+def to_bf16(x: np.ndarray) -> np.ndarray:
+    """float → bf16 bit patterns the way the reference narrows (truncation, index_plugins.hpp:453-469); numpy has no
+    bfloat16, so bf16 rows are uint16 arrays."""
+    return (np.ascontiguousarray(x, dtype=np.float32).view(np.uint32) >> 16).astype(np.uint16)
+
+
+def make_vectors(n: int, ndim: int, dtype: str, seed: int, clustered: bool = True, metric: str = "") -> np.ndarray:
+    """Seeded vectors in the storage kind. `clustered` = low-rank latent + noise so that HNSW has structure.
+    `metric` shapes the values where the metric has a domain: probability histograms for divergence, (latitude,
+    longitude) in degrees for haversine."""
     rng = np.random.default_rng(seed)
+    if metric == "haversine":
+        assert ndim == 2
+        x = np.stack([rng.uniform(-80, 80, n), rng.uniform(-180, 180, n)], axis=1)
+        return x.astype(NP_DTYPE[dtype])
+    if metric == "divergence":
+        rank = max(2, min(8, ndim // 4))
+        x = np.exp(0.7 * (rng.standard_normal((n, rank)) @ rng.standard_normal((rank, ndim))))
+        x /= x.sum(axis=1, keepdims=True)
+        return to_bf16(x) if dtype == "bf16" else x.astype(NP_DTYPE[dtype])
     if dtype == "b1":
         if clustered and ndim >= 16:
             latent = rng.standard_normal((n, 8)) @ rng.standard_normal((8, ndim))
@@ -26,14 +43,14 @@ def make_vectors(n: int, ndim: int, dtype: str, seed: int, clustered: bool = Tru
     if dtype == "i8":
         x = x / np.abs(x).max() * 100.0
         return np.clip(np.rint(x), -127, 127).astype(np.int8)
-    return x.astype(NP_DTYPE[dtype])
+    return to_bf16(x) if dtype == "bf16" else x.astype(NP_DTYPE[dtype])
 
 
 def build_image(n: int, ndim: int, metric: str, dtype: str, seed: int = 1, connectivity: int = 16,
                 expansion_add: int = 128, threads: int = 1, clustered: bool = True, keys=None, remove=()):
     """Builds an index with the REAL reference (single-threaded ⇒ deterministic graph) and serializes it.
     → (image bytes as np.uint8, vectors, RefIndex)."""
-    vectors = make_vectors(n, ndim, dtype, seed, clustered)
+    vectors = make_vectors(n, ndim, dtype, seed, clustered, metric=metric)
     index = refbind.RefIndex(ndim, metric, dtype, connectivity=connectivity, expansion_add=expansion_add)
     if keys is None:
         keys = np.arange(n, dtype=np.uint64) + 1000
@@ -45,6 +62,23 @@ def build_image(n: int, ndim: int, metric: str, dtype: str, seed: int = 1, conne
     return index.save_buffer(), vectors, index
 
 
+def exact_pair(metric: str, dtype: str) -> bool:
+    """Pairs whose distances are integer-valued, or one IEEE division of exact integers: the reference, the oracle and the
+    GPU must agree bit for bit — keys, distances, counts and both traversal counters, ties included."""
+    return dtype == "b1" or (dtype == "i8" and metric in ("l2sq", "ip"))
+
+
+def layout_exact(metric: str) -> bool:
+    """Metrics without a transcendental: the GPU result is bit-identical to the oracle run in the kernels' summation layout.
+    divergence (log) and haversine (sin, cos, asin) go through two different math libraries — tolerance there."""
+    return metric not in ("divergence", "haversine")
+
+
+def tolerance(dtype: str) -> float:
+    """|d - d_ref| <= tolerance · max(1, |d_ref|) for the float pairs (BASELINE.json north_star / SURVEY §8d)."""
+    return 2e-3 if dtype in ("f16", "bf16") else 1e-5
+
+
 def same_float_bits(a: np.ndarray, b: np.ndarray) -> bool:
     return np.array_equal(np.asarray(a, dtype=np.float32).view(np.uint32), np.asarray(b, dtype=np.float32).view(np.uint32))
 
@@ -52,3 +86,17 @@ def same_float_bits(a: np.ndarray, b: np.ndarray) -> bool:
 def oracle_search(image: np.ndarray, queries: np.ndarray, k: int, dtype: str, expansion: int = 64, lanes: int = 0,
                   exact: bool = False):
     return oraclebind.OracleIndex(image).search(queries, k, dtype=dtype, expansion=expansion, lanes=lanes, exact=exact)
+
+
+def with_64_bit_dimensions(image: np.ndarray) -> np.ndarray:
+    """The same index as the reference writes it under `serialization_config_t::use_64_bit_dimensions`
+    (index_dense.hpp:1006-1024): the matrix announced by two u64 instead of two u32, everything else unchanged."""
+    rows, cols = np.frombuffer(image[:8].tobytes(), dtype=np.uint32)
+    head = np.frombuffer(np.array([rows, cols], dtype=np.uint64).tobytes(), dtype=np.uint8)
+    return np.concatenate([head, image[8:]])
+
+
+def without_vectors(image: np.ndarray) -> np.ndarray:
+    """... and under `exclude_vectors` (index_dense.hpp:1004): the file starts with the 64-byte head."""
+    rows, cols = np.frombuffer(image[:8].tobytes(), dtype=np.uint32)
+    return image[8 + int(rows) * int(cols):].copy()

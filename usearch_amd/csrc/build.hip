@@ -22,19 +22,12 @@ double seconds_now() {
 
 hipError_t launch_build(metric_kind_t metric, scalar_kind_t scalar, const build_params_t& p, const snapshot_view_t& view,
                         const build_args_t& args) {
+    if (metric == metric_jaccard_k) // the same kernel, index_plugins.hpp:2003-2004
+        metric = metric_tanimoto_k;
 #define UA_PAIR(m, sc, name)                                                                                           \
     if (metric == m && scalar == sc)                                                                                   \
         return launch_build_##name(p, view, args);
-    UA_PAIR(metric_ip_k, scalar_f32_k, ip_f32)
-    UA_PAIR(metric_cos_k, scalar_f32_k, cos_f32)
-    UA_PAIR(metric_l2sq_k, scalar_f32_k, l2sq_f32)
-    UA_PAIR(metric_ip_k, scalar_f16_k, ip_f16)
-    UA_PAIR(metric_cos_k, scalar_f16_k, cos_f16)
-    UA_PAIR(metric_l2sq_k, scalar_f16_k, l2sq_f16)
-    UA_PAIR(metric_ip_k, scalar_i8_k, ip_i8)
-    UA_PAIR(metric_cos_k, scalar_i8_k, cos_i8)
-    UA_PAIR(metric_l2sq_k, scalar_i8_k, l2sq_i8)
-    UA_PAIR(metric_hamming_k, scalar_b1x8_k, hamming_b1)
+    USEARCH_AMD_FOR_EACH_PAIR(UA_PAIR)
 #undef UA_PAIR
     return hipErrorInvalidValue;
 }

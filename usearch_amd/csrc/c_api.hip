@@ -300,6 +300,20 @@ void usearch_amd_search_many_device(usearch_amd_snapshot_t snapshot, void const*
     stats_to_c(s, stats);
 }
 
+void usearch_amd_cluster_many(usearch_amd_snapshot_t snapshot, void const* queries, int query_kind, size_t queries_count,
+                              size_t queries_stride, size_t level, usearch_amd_key_t* keys,
+                              usearch_amd_distance_t* distances, uint64_t* visited, uint64_t* computed,
+                              usearch_amd_error_t* error) {
+    const scalar_kind_t kind = scalar_from_c(query_kind);
+    if (kind == scalar_unknown_k)
+        return fail(error, "Unknown scalar kind!");
+    if (queries_count && (!queries || !keys || !distances))
+        return fail(error, "Cluster search needs the query, key and distance buffers");
+    if (const char* e = as_snapshot(snapshot)->cluster_host(queries, kind, queries_count, queries_stride, level, keys,
+                                                            distances, visited, computed))
+        return fail(error, e);
+}
+
 void usearch_amd_exact_search_many(usearch_amd_snapshot_t snapshot, void const* queries, int query_kind,
                                    size_t queries_count, size_t queries_stride, size_t wanted, usearch_amd_key_t* keys,
                                    usearch_amd_distance_t* distances, uint64_t* counts, float* kernel_ms,

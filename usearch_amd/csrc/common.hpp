@@ -16,7 +16,6 @@ enum metric_kind_t : std::uint8_t {
     metric_cos_k = 'c',
     metric_l2sq_k = 'e',
     metric_hamming_k = 'b',
-    // present in the reference, no HIP kernel yet: listed so that they are refused by name
     metric_pearson_k = 'p',
     metric_haversine_k = 'h',
     metric_divergence_k = 'd',
@@ -48,6 +47,21 @@ inline std::size_t bytes_per_vector(scalar_kind_t kind, std::size_t dimensions) 
     case scalar_f64_k: return dimensions * 8;
     default: return 0;
     }
+}
+
+/// LDS bytes a staged query takes per 16-byte chunk of a stored row: the 16-bit float kinds are widened to f32 once.
+inline constexpr std::uint32_t query_chunk_bytes_of(scalar_kind_t kind) {
+    return (kind == scalar_f16_k || kind == scalar_bf16_k) ? 32u : 16u;
+}
+
+/// Pairs that get every build of the search kernel (three loads-in-flight depths for long rows): the BASELINE configs'
+/// and their neighbours. The other pairs of the reference's dispatch table (index_plugins.hpp:1930-2008) get the 4-deep
+/// build only — same results, one third of the compile time.
+inline constexpr bool all_kernel_builds(metric_kind_t metric, scalar_kind_t scalar) {
+    const bool common_metric = metric == metric_ip_k || metric == metric_cos_k || metric == metric_l2sq_k;
+    return (common_metric && (scalar == scalar_f32_k || scalar == scalar_f16_k || scalar == scalar_bf16_k ||
+                              scalar == scalar_i8_k)) ||
+           (metric == metric_hamming_k && scalar == scalar_b1x8_k);
 }
 
 constexpr std::uint32_t none_slot_k = 0xFFFFFFFFu;             ///< empty neighbour cell / empty hash cell
@@ -109,6 +123,8 @@ struct search_args_t {
     const std::uint32_t* query_ids; ///< optional: query `q` is row query_ids[q] of `queries` (a stored vector); outputs stay at row q
     std::uint32_t beam_level;       ///< level the beam runs on (0 for `search`); the greedy descent stops above it
     std::uint32_t emit_slots;       ///< 1 = write slots instead of keys into `keys`
+    std::uint32_t descent_only;     ///< 1 = `index_gt::cluster` (index.hpp:3089-3125): stop after the greedy descent to
+                                    ///< `beam_level` and report the member it reached (one result per query)
     const std::uint32_t* allow_bits; ///< optional: one bit per slot, 0 = the caller's predicate rejects that member
                                      ///< (`usearch_filtered_search`, index_dense.hpp:2071-2081)
     unsigned long long* phases;     ///< optional [8] diagnostic: shader-clock ticks per phase summed over all waves

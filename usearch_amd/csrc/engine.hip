@@ -54,15 +54,17 @@ const char* upload_rows(std::uint8_t* device, std::uint32_t row_stride, const st
     return nullptr;
 }
 
+/// Jaccard over bit sets IS Tanimoto in the reference's dispatch (index_plugins.hpp:2003-2004): one kernel serves both.
+static metric_kind_t kernel_metric(metric_kind_t metric) { return metric == metric_jaccard_k ? metric_tanimoto_k : metric; }
+
 bool kernel_available(metric_kind_t metric, scalar_kind_t scalar) {
-    const bool numeric_metric = metric == metric_ip_k || metric == metric_cos_k || metric == metric_l2sq_k;
-    switch (scalar) {
-    case scalar_f32_k:
-    case scalar_f16_k:
-    case scalar_i8_k: return numeric_metric;
-    case scalar_b1x8_k: return metric == metric_hamming_k;
-    default: return false;
-    }
+    metric = kernel_metric(metric);
+#define UA_PAIR(m, sc, name)                                                                                           \
+    if (metric == m && scalar == sc)                                                                                   \
+        return true;
+    USEARCH_AMD_FOR_EACH_PAIR(UA_PAIR)
+#undef UA_PAIR
+    return false;
 }
 
 snapshot_t::~snapshot_t() { release(); }
@@ -287,38 +289,22 @@ const char* snapshot_t::ensure_staging(std::size_t query_bytes, std::size_t coun
 
 static hipError_t launch_search(metric_kind_t metric, scalar_kind_t scalar, const launch_params_t& p,
                                 const snapshot_view_t& view, const search_args_t& args) {
+    metric = kernel_metric(metric);
 #define UA_PAIR(m, sc, name)                                                                                           \
     if (metric == m && scalar == sc)                                                                                   \
         return launch_search_##name(p, view, args);
-    UA_PAIR(metric_ip_k, scalar_f32_k, ip_f32)
-    UA_PAIR(metric_cos_k, scalar_f32_k, cos_f32)
-    UA_PAIR(metric_l2sq_k, scalar_f32_k, l2sq_f32)
-    UA_PAIR(metric_ip_k, scalar_f16_k, ip_f16)
-    UA_PAIR(metric_cos_k, scalar_f16_k, cos_f16)
-    UA_PAIR(metric_l2sq_k, scalar_f16_k, l2sq_f16)
-    UA_PAIR(metric_ip_k, scalar_i8_k, ip_i8)
-    UA_PAIR(metric_cos_k, scalar_i8_k, cos_i8)
-    UA_PAIR(metric_l2sq_k, scalar_i8_k, l2sq_i8)
-    UA_PAIR(metric_hamming_k, scalar_b1x8_k, hamming_b1)
+    USEARCH_AMD_FOR_EACH_PAIR(UA_PAIR)
 #undef UA_PAIR
     return hipErrorInvalidValue;
 }
 
 static hipError_t launch_distances(metric_kind_t metric, scalar_kind_t scalar, const distances_params_t& p,
                                    const snapshot_view_t& view) {
+    metric = kernel_metric(metric);
 #define UA_PAIR(m, sc, name)                                                                                           \
     if (metric == m && scalar == sc)                                                                                   \
         return launch_distances_##name(p, view);
-    UA_PAIR(metric_ip_k, scalar_f32_k, ip_f32)
-    UA_PAIR(metric_cos_k, scalar_f32_k, cos_f32)
-    UA_PAIR(metric_l2sq_k, scalar_f32_k, l2sq_f32)
-    UA_PAIR(metric_ip_k, scalar_f16_k, ip_f16)
-    UA_PAIR(metric_cos_k, scalar_f16_k, cos_f16)
-    UA_PAIR(metric_l2sq_k, scalar_f16_k, l2sq_f16)
-    UA_PAIR(metric_ip_k, scalar_i8_k, ip_i8)
-    UA_PAIR(metric_cos_k, scalar_i8_k, cos_i8)
-    UA_PAIR(metric_l2sq_k, scalar_i8_k, l2sq_i8)
-    UA_PAIR(metric_hamming_k, scalar_b1x8_k, hamming_b1)
+    USEARCH_AMD_FOR_EACH_PAIR(UA_PAIR)
 #undef UA_PAIR
     return hipErrorInvalidValue;
 }
@@ -366,7 +352,7 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
 
     // ---- scratch sizing, from measurements with the reference's own traversal (DESIGN.md "scratch sizing"): the frontier
     // peaks at 2.4-3.9 × ef and the visited set ends at 18-30 × ef entries; outliers go through the retry ladder below.
-    const std::uint32_t query_lds = view_.chunks * (scalar_ == scalar_f16_k ? 32u : 16u);
+    const std::uint32_t query_lds = view_.chunks * (query_chunk_bytes_of(scalar_));
     const std::uint32_t lds_budget = (std::uint32_t)env_size("USEARCH_AMD_LDS_BUDGET", 160 * 1024);
     std::uint32_t hash_cap = tuning.hash_cap ? tuning.hash_cap : (std::uint32_t)env_size("USEARCH_AMD_HASH_CAP", 0);
     if (!hash_cap)
@@ -383,12 +369,13 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
     const std::uint32_t chunks_per_lane = view_.chunks / lanes_;
     std::uint32_t variant_request = tuning.variant ? tuning.variant : (std::uint32_t)env_size("USEARCH_AMD_VARIANT", 0);
     int variant = variant_u4_w4_k;
-    if (lanes_ == 8 && chunks_per_lane >= 8) {
+    if (lanes_ == 8 && chunks_per_lane >= 8 && all_kernel_builds(kernel_metric(metric_), scalar_)) {
         // measured on 10M x 768 f16 (profiles/): a whole row per round trip (12 loads per lane, 8 waves per CU) beats 8 loads
         // at 12 waves per CU at every expansion — the traversal is latency-bound, fewer round trips per hop win
         variant = chunks_per_lane >= 12 ? variant_u12_w2_k : variant_u8_w3_k;
     }
-    if (variant_request && variant_request - 1 <= (std::uint32_t)variant_u12_w2_k && lanes_ == 8)
+    if (variant_request && variant_request - 1 <= (std::uint32_t)variant_u12_w2_k && lanes_ == 8 &&
+        all_kernel_builds(kernel_metric(metric_), scalar_))
         variant = (int)variant_request - 1;
     const std::uint32_t top_entries_hint = ef <= 64 ? 1u : ef <= 256 ? 4u : ef <= 512 ? 8u : ef <= 1024 ? 16u : 0u;
     const std::uint32_t variant_waves_per_cu = 4u * (std::uint32_t)kernel_waves(variant, (int)top_entries_hint);
@@ -450,6 +437,7 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
         args.query_ids = extras->query_ids;
         args.beam_level = extras->beam_level;
         args.emit_slots = extras->emit_slots ? 1u : 0u;
+        args.descent_only = extras->descent_only ? 1u : 0u;
         args.allow_bits = extras->allow_bits;
     }
 
@@ -631,7 +619,8 @@ const char* snapshot_t::search_host(const void* queries, scalar_kind_t query_kin
                                     std::size_t stride_bytes, std::size_t wanted, std::size_t expansion,
                                     std::uint64_t* keys, float* distances, std::uint64_t* counts,
                                     std::uint64_t* visited, std::uint64_t* computed, const search_tuning_t& tuning,
-                                    search_stats_t* stats, const std::uint32_t* allow_bits_host) {
+                                    search_stats_t* stats, const std::uint32_t* allow_bits_host,
+                                    const search_extras_t* more) {
     if (stats)
         *stats = search_stats_t{};
     if (!count || !wanted)
@@ -678,7 +667,7 @@ const char* snapshot_t::search_host(const void* queries, scalar_kind_t query_kin
     std::uint64_t* d_computed = reinterpret_cast<std::uint64_t*>(reinterpret_cast<std::uint8_t*>(d_visited) + pad(count * 8));
 
     UA_HIP(hipMemcpy(d_queries, source, bpv * count, hipMemcpyHostToDevice));
-    search_extras_t extras;
+    search_extras_t extras = more ? *more : search_extras_t{};
     std::uint32_t* d_allow = nullptr;
     if (allow_bits_host && view_.size) {
         const std::size_t words = (view_.size + 31) / 32;
@@ -708,21 +697,25 @@ const char* snapshot_t::search_host(const void* queries, scalar_kind_t query_kin
     return nullptr;
 }
 
+const char* snapshot_t::cluster_host(const void* queries, scalar_kind_t query_kind, std::size_t count,
+                                     std::size_t stride_bytes, std::size_t level, std::uint64_t* keys, float* distances,
+                                     std::uint64_t* visited, std::uint64_t* computed) {
+    // index_gt::cluster, index.hpp:3112-3114: search_for_one_ from the top level down to `level` (target level - 1, or 0)
+    search_extras_t extras;
+    extras.descent_only = true;
+    extras.beam_level = (std::uint32_t)std::min<std::size_t>(level ? level - 1 : 0, 0xFFFFu);
+    search_stats_t stats;
+    return search_host(queries, query_kind, count, stride_bytes, 1, 1, keys, distances, nullptr, visited, computed,
+                       search_tuning_t{}, &stats, nullptr, &extras);
+}
+
 static hipError_t launch_exact(metric_kind_t metric, scalar_kind_t scalar, const exact_params_t& p,
                                const snapshot_view_t& view) {
+    metric = kernel_metric(metric);
 #define UA_PAIR(m, sc, name)                                                                                           \
     if (metric == m && scalar == sc)                                                                                   \
         return launch_exact_##name(p, view);
-    UA_PAIR(metric_ip_k, scalar_f32_k, ip_f32)
-    UA_PAIR(metric_cos_k, scalar_f32_k, cos_f32)
-    UA_PAIR(metric_l2sq_k, scalar_f32_k, l2sq_f32)
-    UA_PAIR(metric_ip_k, scalar_f16_k, ip_f16)
-    UA_PAIR(metric_cos_k, scalar_f16_k, cos_f16)
-    UA_PAIR(metric_l2sq_k, scalar_f16_k, l2sq_f16)
-    UA_PAIR(metric_ip_k, scalar_i8_k, ip_i8)
-    UA_PAIR(metric_cos_k, scalar_i8_k, cos_i8)
-    UA_PAIR(metric_l2sq_k, scalar_i8_k, l2sq_i8)
-    UA_PAIR(metric_hamming_k, scalar_b1x8_k, hamming_b1)
+    USEARCH_AMD_FOR_EACH_PAIR(UA_PAIR)
 #undef UA_PAIR
     return hipErrorInvalidValue;
 }
@@ -773,7 +766,7 @@ const char* exact_search_device(metric_kind_t metric, scalar_kind_t scalar, std:
     if (e == hipSuccess) {
         exact_params_t p{};
         p.lanes = lanes;
-        p.lds_bytes = view.chunks * (scalar == scalar_f16_k ? 32u : 16u) + 512 + (std::uint32_t)wanted * 8 + 16;
+        p.lds_bytes = view.chunks * (query_chunk_bytes_of(scalar)) + 512 + (std::uint32_t)wanted * 8 + 16;
         p.stream = stream;
         p.queries = static_cast<const std::uint8_t*>(queries);
         p.query_stride = stride_bytes;
@@ -946,7 +939,7 @@ const char* snapshot_t::distances_host(const void* queries, std::size_t count, s
         distances_params_t p{};
         p.metric = metric_;
         p.lanes = lanes_;
-        p.lds_bytes = view_.chunks * (scalar_ == scalar_f16_k ? 32u : 16u) + 512;
+        p.lds_bytes = view_.chunks * (query_chunk_bytes_of(scalar_)) + 512;
         p.stream = stream_;
         p.queries = d_queries;
         p.query_stride = bpv;

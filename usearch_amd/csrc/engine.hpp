@@ -43,6 +43,7 @@ struct search_extras_t {
     const std::uint32_t* query_ids = nullptr; ///< device: query q is row query_ids[q] of `queries`
     std::uint32_t beam_level = 0;             ///< level the beam runs on
     bool emit_slots = false;                  ///< slots instead of keys in the `keys` output
+    bool descent_only = false;                ///< `cluster`: the greedy descent to `beam_level` alone, one result per query
     const std::uint32_t* allow_bits = nullptr; ///< device: one bit per slot, 0 = rejected by the caller's predicate
 };
 
@@ -100,7 +101,13 @@ class snapshot_t {
                             std::size_t wanted, std::size_t expansion, std::uint64_t* keys, float* distances,
                             std::uint64_t* counts, std::uint64_t* visited, std::uint64_t* computed,
                             const search_tuning_t& tuning, search_stats_t* stats,
-                            const std::uint32_t* allow_bits_host = nullptr);
+                            const std::uint32_t* allow_bits_host = nullptr, const search_extras_t* more = nullptr);
+
+    /// `index_dense_gt::cluster(query, level)` for a batch (index_dense.hpp:788-793 → index.hpp:3089-3125): host buffers, any
+    /// query scalar kind; keys / distances / visited / computed are [count] arrays.
+    const char* cluster_host(const void* queries, scalar_kind_t query_kind, std::size_t count, std::size_t stride_bytes,
+                             std::size_t level, std::uint64_t* keys, float* distances, std::uint64_t* visited,
+                             std::uint64_t* computed);
 
     /// Telemetry of the last search_device call: per query {peak frontier size, visited-set size}; host copy.
     const char* last_peaks(std::uint32_t* out, std::size_t queries);
@@ -173,16 +180,40 @@ struct launch_params_t {
     hipError_t launch_distances_##name(const struct distances_params_t&, const snapshot_view_t&);                     \
     hipError_t launch_exact_##name(const struct exact_params_t&, const snapshot_view_t&);                             \
     hipError_t launch_build_##name(const struct build_params_t&, const snapshot_view_t&, const struct build_args_t&);
-USEARCH_AMD_DECLARE_LAUNCHERS(ip_f32)
-USEARCH_AMD_DECLARE_LAUNCHERS(cos_f32)
-USEARCH_AMD_DECLARE_LAUNCHERS(l2sq_f32)
-USEARCH_AMD_DECLARE_LAUNCHERS(ip_f16)
-USEARCH_AMD_DECLARE_LAUNCHERS(cos_f16)
-USEARCH_AMD_DECLARE_LAUNCHERS(l2sq_f16)
-USEARCH_AMD_DECLARE_LAUNCHERS(ip_i8)
-USEARCH_AMD_DECLARE_LAUNCHERS(cos_i8)
-USEARCH_AMD_DECLARE_LAUNCHERS(l2sq_i8)
-USEARCH_AMD_DECLARE_LAUNCHERS(hamming_b1)
+/// Every (metric, scalar) pair with a HIP kernel — the reference's own dispatch table, `configure_with_autovec`
+/// (index_plugins.hpp:1930-2008); jaccard over bit sets is tanimoto there (2003-2004) and is mapped onto it at the boundary.
+#define USEARCH_AMD_FOR_EACH_PAIR(X) \
+    X(metric_ip_k, scalar_f32_k, ip_f32)\
+    X(metric_cos_k, scalar_f32_k, cos_f32)\
+    X(metric_l2sq_k, scalar_f32_k, l2sq_f32)\
+    X(metric_pearson_k, scalar_f32_k, pearson_f32)\
+    X(metric_ip_k, scalar_f16_k, ip_f16)\
+    X(metric_cos_k, scalar_f16_k, cos_f16)\
+    X(metric_l2sq_k, scalar_f16_k, l2sq_f16)\
+    X(metric_pearson_k, scalar_f16_k, pearson_f16)\
+    X(metric_ip_k, scalar_bf16_k, ip_bf16)\
+    X(metric_cos_k, scalar_bf16_k, cos_bf16)\
+    X(metric_l2sq_k, scalar_bf16_k, l2sq_bf16)\
+    X(metric_pearson_k, scalar_bf16_k, pearson_bf16)\
+    X(metric_ip_k, scalar_f64_k, ip_f64)\
+    X(metric_cos_k, scalar_f64_k, cos_f64)\
+    X(metric_l2sq_k, scalar_f64_k, l2sq_f64)\
+    X(metric_pearson_k, scalar_f64_k, pearson_f64)\
+    X(metric_ip_k, scalar_i8_k, ip_i8)\
+    X(metric_cos_k, scalar_i8_k, cos_i8)\
+    X(metric_l2sq_k, scalar_i8_k, l2sq_i8)\
+    X(metric_pearson_k, scalar_i8_k, pearson_i8)\
+    X(metric_divergence_k, scalar_f32_k, divergence_f32)\
+    X(metric_divergence_k, scalar_f16_k, divergence_f16)\
+    X(metric_divergence_k, scalar_bf16_k, divergence_bf16)\
+    X(metric_divergence_k, scalar_f64_k, divergence_f64)\
+    X(metric_haversine_k, scalar_f32_k, haversine_f32)\
+    X(metric_haversine_k, scalar_f64_k, haversine_f64)\
+    X(metric_hamming_k, scalar_b1x8_k, hamming_b1)\
+    X(metric_tanimoto_k, scalar_b1x8_k, tanimoto_b1)\
+    X(metric_sorensen_k, scalar_b1x8_k, sorensen_b1)
+#define USEARCH_AMD_DECLARE_PAIR(metric_kind, scalar_kind, name) USEARCH_AMD_DECLARE_LAUNCHERS(name)
+USEARCH_AMD_FOR_EACH_PAIR(USEARCH_AMD_DECLARE_PAIR)
 
 /// Launch shape of one construction linking kernel (build_kernels.hpp): `reverse` = 0 select, 1 reverse links.
 struct build_params_t {

@@ -2,7 +2,8 @@
  *  usearch_amd/csrc/image.hpp — host-side reader of a serialized USearch v2 index image.
  *
  *  Byte layout, as written by the reference (`/root/reference/include/usearch/…`):
- *    index_dense.hpp:1004-1030   [u32 rows][u32 cols = bytes per vector][rows × cols vector bytes]
+ *    index_dense.hpp:1004-1030   [u32 rows][u32 cols = bytes per vector][rows × cols vector bytes]   (or two u64 when
+ *                                saved with `use_64_bit_dimensions`; sniffed like index_dense.hpp:321-371 does)
  *    index_dense.hpp:42-79       64-byte head: "usearch" magic(7) | u16×3 version | u8 metric | u8 scalar | u8 key kind |
  *                                u8 slot kind | u64 present | u64 deleted | u64 dimensions | u8 multi | zero padding
  *    index.hpp:1863-1869         5 × u64: size, connectivity, connectivity_base, max_level, entry_slot
@@ -57,9 +58,26 @@ struct image_t {
         const std::uint8_t* const end = bytes + length;
         if (length < 8)
             return "Failed to read 32-bit dimensions of the matrix";
+        // Which of the three layouts of index_dense.hpp:1004-1030 is this? The reference sniffs it the same way
+        // (`index_dense_metadata_from_buffer`, index_dense.hpp:321-371): the 64-byte head right away = saved with
+        // `exclude_vectors`; else the magic behind a matrix announced by two u32 — or by two u64 (`use_64_bit_dimensions`).
+        if (length >= 7 && std::memcmp(p, "usearch", 7) == 0)
+            return "The image was saved without its vectors (exclude_vectors): nothing to search";
+        std::size_t dimensions_length = 8;
         rows = load<std::uint32_t>(p);
         cols = load<std::uint32_t>(p + 4);
-        p += 8;
+        const auto magic_behind = [&](std::uint64_t r, std::uint64_t c, std::size_t header) {
+            if (c && r > (std::uint64_t)length / c)
+                return false;
+            const std::uint64_t offset = r * c + header;
+            return offset + 64 <= (std::uint64_t)length && std::memcmp(bytes + offset, "usearch", 7) == 0;
+        };
+        if (!magic_behind(rows, cols, 8) && length >= 16) {
+            const std::uint64_t rows64 = load<std::uint64_t>(p), cols64 = load<std::uint64_t>(p + 8);
+            if (magic_behind(rows64, cols64, 16))
+                rows = rows64, cols = cols64, dimensions_length = 16;
+        }
+        p += dimensions_length;
         if ((std::uint64_t)(end - p) < rows * cols)
             return "Failed to read vectors";
         vectors = p;

@@ -403,48 +403,131 @@ UA_DEVICE float half_bits_to_float(std::uint32_t bits16) {
     return (float)__builtin_bit_cast(_Float16, (std::uint16_t)bits16);
 }
 
-/// What one lane accumulates for one row; which members are live depends on (metric, scalar).
+/// Scalar kinds whose arithmetic runs in f32 (`result_t = f32_t` of index_plugins.hpp:1930-2001), and the two 16-bit ones
+/// among them, which are widened to f32 once when the query is staged.
+template <int scalar_ak> constexpr bool f32_math() {
+    return scalar_ak == scalar_f32_k || scalar_ak == scalar_f16_k || scalar_ak == scalar_bf16_k;
+}
+template <int scalar_ak> constexpr bool narrow_float() { return scalar_ak == scalar_f16_k || scalar_ak == scalar_bf16_k; }
+
+/// 16 stored bits → f32: IEEE binary16 (f16_to_f32, index_plugins.hpp:398-410) or bfloat16 = the upper half of an f32
+/// (bf16_to_f32, 434-446).
+template <int scalar_ak> UA_DEVICE float narrow_bits_to_float(std::uint32_t bits16) {
+    if constexpr (scalar_ak == scalar_bf16_k)
+        return __builtin_bit_cast(float, bits16 << 16);
+    else
+        return half_bits_to_float(bits16);
+}
+
+/// What one lane accumulates for one row; which members are live depends on (metric, scalar) — the others never leave
+/// their initial constant and cost nothing.
+///   f32 math  ip: fx = Σab · cos: fx = Σab, fy = Σb² · l2sq: fx = Σ(a-b)² · pearson: fx = Σab, fy = Σb², fz = Σb ·
+///             divergence: fx, fy = the two Kullback-Leibler sums · haversine: fx = the haversine term of the pair
+///   f64       the same in dx, dy, dz
+///   i8        ix = Σab, iy = Σb², iz = Σb (pearson)
+///   b1        hamming: ix = Σpopcount(a^b) · tanimoto: ix = Σpopcount(a&b), iy = Σpopcount(a|b) ·
+///             sorensen: ix = Σpopcount(a&b), iy = Σ(popcount(a) + popcount(b))
 struct partial_t {
-    float fx = 0.f, fy = 0.f; // float kinds: fx = Σab (ip, cos) or Σ(a-b)² (l2sq); fy = Σb² (cos)
-    int ix = 0, iy = 0;       // i8: ix = Σab, iy = Σb²;  b1: ix = Σpopcount(a^b)
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    double dx = 0.0, dy = 0.0, dz = 0.0;
+    int ix = 0, iy = 0, iz = 0;
 };
 
-template <int metric_ak> UA_DEVICE void accumulate_float(partial_t& p, float a, float b) {
+UA_DEVICE float fma_real(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+UA_DEVICE double fma_real(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+/// One element pair of an equidimensional metric, `real_ak` = float or double (index_plugins.hpp:1309-1385, 1478-1551).
+template <int metric_ak, typename real_ak>
+UA_DEVICE void accumulate_real(real_ak& x, real_ak& y, real_ak& z, real_ak a, real_ak b) {
     if constexpr (metric_ak == metric_cos_k) {
-        p.fx = __builtin_fmaf(a, b, p.fx);
-        p.fy = __builtin_fmaf(b, b, p.fy);
+        x = fma_real(a, b, x);
+        y = fma_real(b, b, y);
     } else if constexpr (metric_ak == metric_ip_k) {
-        p.fx = __builtin_fmaf(a, b, p.fx);
-    } else {
-        const float t = a - b;
-        p.fx = __builtin_fmaf(t, t, p.fx);
+        x = fma_real(a, b, x);
+    } else if constexpr (metric_ak == metric_l2sq_k) {
+        const real_ak t = a - b;
+        x = fma_real(t, t, x);
+    } else if constexpr (metric_ak == metric_pearson_k) { // metric_pearson_gt 1478-1520; Σa, Σa² are query constants
+        x = fma_real(a, b, x);
+        y = fma_real(b, b, y);
+        z = z + b;
+    } else if constexpr (metric_ak == metric_divergence_k) { // metric_divergence_gt 1526-1551, p = query, q = stored
+        real_ak epsilon, log_p, log_q;
+        if constexpr (sizeof(real_ak) == 4)
+            epsilon = 1.1920928955078125e-7f;
+        else
+            epsilon = 2.220446049250313e-16;
+        const real_ak m = (a + b) / 2 + epsilon;
+        if constexpr (sizeof(real_ak) == 4)
+            log_p = logf((a + epsilon) / m), log_q = logf((b + epsilon) / m);
+        else
+            log_p = log((a + epsilon) / m), log_q = log((b + epsilon) / m);
+        x = x + a * log_p;
+        y = y + b * log_q;
     }
 }
 
-/// LDS bytes the query occupies per 16-byte row chunk: f16 queries are widened to f32 once, at load time.
-template <int scalar_ak> constexpr std::uint32_t query_chunk_bytes() { return scalar_ak == scalar_f16_k ? 32u : 16u; }
+template <int metric_ak> UA_DEVICE void accumulate_float(partial_t& p, float a, float b) {
+    accumulate_real<metric_ak, float>(p.fx, p.fy, p.fz, a, b);
+}
+
+/// metric_haversine_gt (index_plugins.hpp:1636-1657): the pair's (latitude, longitude) in degrees → the term under the
+/// arcsine; `angle_to_radians` of line 203.
+template <typename real_ak>
+UA_DEVICE real_ak haversine_term(real_ak lat_a, real_ak lon_a, real_ak lat_b, real_ak lon_b) {
+    const real_ak pi = (real_ak)3.14159265358979323846, straight = (real_ak)180;
+    const real_ak lat_delta = ((lat_b - lat_a) * pi / straight) / 2, lon_delta = ((lon_b - lon_a) * pi / straight) / 2;
+    const real_ak converted_a = lat_a * pi / straight, converted_b = lat_b * pi / straight;
+    if constexpr (sizeof(real_ak) == 4) {
+        const float s1 = sinf(lat_delta), s2 = sinf(lon_delta);
+        return s1 * s1 + cosf(converted_a) * cosf(converted_b) * (s2 * s2);
+    } else {
+        const double s1 = sin(lat_delta), s2 = sin(lon_delta);
+        return s1 * s1 + cos(converted_a) * cos(converted_b) * (s2 * s2);
+    }
+}
+
+/// LDS bytes the query occupies per 16-byte row chunk: 16-bit float queries are widened to f32 once, at load time.
+template <int scalar_ak> constexpr std::uint32_t query_chunk_bytes() { return narrow_float<scalar_ak>() ? 32u : 16u; }
 
 /// Folds one 16-byte chunk `v` of a stored row against chunk `c` of the query (already in LDS).
 template <int metric_ak, int scalar_ak>
 UA_DEVICE void accumulate_chunk(partial_t& p, const std::uint8_t* query_lds, std::uint32_t c, uint4 v) {
     const std::uint8_t* q = query_lds + (std::size_t)c * query_chunk_bytes<scalar_ak>();
-    if constexpr (scalar_ak == scalar_f32_k) {
+    if constexpr (metric_ak == metric_haversine_k) { // two scalars: the whole vector sits in chunk 0
+        if (c == 0) {
+            if constexpr (scalar_ak == scalar_f32_k) {
+                const float2 a = *reinterpret_cast<const float2*>(q);
+                p.fx = haversine_term<float>(a.x, a.y, __builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y));
+            } else {
+                const double2 a = *reinterpret_cast<const double2*>(q);
+                p.dx = haversine_term<double>(a.x, a.y, __builtin_bit_cast(double, ((std::uint64_t)v.y << 32) | v.x),
+                                              __builtin_bit_cast(double, ((std::uint64_t)v.w << 32) | v.z));
+            }
+        }
+    } else if constexpr (scalar_ak == scalar_f32_k) {
         const float4 a = *reinterpret_cast<const float4*>(q);
         accumulate_float<metric_ak>(p, a.x, __builtin_bit_cast(float, v.x));
         accumulate_float<metric_ak>(p, a.y, __builtin_bit_cast(float, v.y));
         accumulate_float<metric_ak>(p, a.z, __builtin_bit_cast(float, v.z));
         accumulate_float<metric_ak>(p, a.w, __builtin_bit_cast(float, v.w));
-    } else if constexpr (scalar_ak == scalar_f16_k) {
+    } else if constexpr (narrow_float<scalar_ak>()) {
         const float4 a0 = *reinterpret_cast<const float4*>(q);
         const float4 a1 = *reinterpret_cast<const float4*>(q + 16);
-        accumulate_float<metric_ak>(p, a0.x, half_bits_to_float(v.x & 0xFFFFu));
-        accumulate_float<metric_ak>(p, a0.y, half_bits_to_float(v.x >> 16));
-        accumulate_float<metric_ak>(p, a0.z, half_bits_to_float(v.y & 0xFFFFu));
-        accumulate_float<metric_ak>(p, a0.w, half_bits_to_float(v.y >> 16));
-        accumulate_float<metric_ak>(p, a1.x, half_bits_to_float(v.z & 0xFFFFu));
-        accumulate_float<metric_ak>(p, a1.y, half_bits_to_float(v.z >> 16));
-        accumulate_float<metric_ak>(p, a1.z, half_bits_to_float(v.w & 0xFFFFu));
-        accumulate_float<metric_ak>(p, a1.w, half_bits_to_float(v.w >> 16));
+        accumulate_float<metric_ak>(p, a0.x, narrow_bits_to_float<scalar_ak>(v.x & 0xFFFFu));
+        accumulate_float<metric_ak>(p, a0.y, narrow_bits_to_float<scalar_ak>(v.x >> 16));
+        accumulate_float<metric_ak>(p, a0.z, narrow_bits_to_float<scalar_ak>(v.y & 0xFFFFu));
+        accumulate_float<metric_ak>(p, a0.w, narrow_bits_to_float<scalar_ak>(v.y >> 16));
+        accumulate_float<metric_ak>(p, a1.x, narrow_bits_to_float<scalar_ak>(v.z & 0xFFFFu));
+        accumulate_float<metric_ak>(p, a1.y, narrow_bits_to_float<scalar_ak>(v.z >> 16));
+        accumulate_float<metric_ak>(p, a1.z, narrow_bits_to_float<scalar_ak>(v.w & 0xFFFFu));
+        accumulate_float<metric_ak>(p, a1.w, narrow_bits_to_float<scalar_ak>(v.w >> 16));
+    } else if constexpr (scalar_ak == scalar_f64_k) {
+        const double2 a = *reinterpret_cast<const double2*>(q);
+        accumulate_real<metric_ak, double>(p.dx, p.dy, p.dz, a.x,
+                                           __builtin_bit_cast(double, ((std::uint64_t)v.y << 32) | v.x));
+        accumulate_real<metric_ak, double>(p.dx, p.dy, p.dz, a.y,
+                                           __builtin_bit_cast(double, ((std::uint64_t)v.w << 32) | v.z));
     } else if constexpr (scalar_ak == scalar_i8_k) {
         const uint4 a = *reinterpret_cast<const uint4*>(q);
         p.ix = __builtin_amdgcn_sdot4((int)a.x, (int)v.x, p.ix, false);
@@ -457,34 +540,81 @@ UA_DEVICE void accumulate_chunk(partial_t& p, const std::uint8_t* query_lds, std
             p.iy = __builtin_amdgcn_sdot4((int)v.z, (int)v.z, p.iy, false);
             p.iy = __builtin_amdgcn_sdot4((int)v.w, (int)v.w, p.iy, false);
         }
-    } else { // b1x8, hamming
+        if constexpr (metric_ak == metric_pearson_k) { // Σb: a dot product with four ones
+            p.iz = __builtin_amdgcn_sdot4(0x01010101, (int)v.x, p.iz, false);
+            p.iz = __builtin_amdgcn_sdot4(0x01010101, (int)v.y, p.iz, false);
+            p.iz = __builtin_amdgcn_sdot4(0x01010101, (int)v.z, p.iz, false);
+            p.iz = __builtin_amdgcn_sdot4(0x01010101, (int)v.w, p.iz, false);
+        }
+    } else { // b1x8: hamming 1392-1414, tanimoto (= jaccard) 1420-1445, sorensen 1451-1476
         const uint4 a = *reinterpret_cast<const uint4*>(q);
-        p.ix += __popc(a.x ^ v.x) + __popc(a.y ^ v.y) + __popc(a.z ^ v.z) + __popc(a.w ^ v.w);
-    }
-}
-
-/// XOR butterfly over the `lanes_ak` lanes that share a row (offsets lanes/2 … 1).
-template <int scalar_ak, int lanes_ak> UA_DEVICE void reduce_partial(partial_t& p) {
-#pragma unroll
-    for (int offset = lanes_ak / 2; offset >= 1; offset >>= 1) {
-        if constexpr (scalar_ak == scalar_f32_k || scalar_ak == scalar_f16_k) {
-            p.fx += __shfl_xor(p.fx, offset, 64);
-            p.fy += __shfl_xor(p.fy, offset, 64);
+        if constexpr (metric_ak == metric_hamming_k) {
+            p.ix += __popc(a.x ^ v.x) + __popc(a.y ^ v.y) + __popc(a.z ^ v.z) + __popc(a.w ^ v.w);
         } else {
-            p.ix += __shfl_xor(p.ix, offset, 64);
-            p.iy += __shfl_xor(p.iy, offset, 64);
+            p.ix += __popc(a.x & v.x) + __popc(a.y & v.y) + __popc(a.z & v.z) + __popc(a.w & v.w);
+            if constexpr (metric_ak == metric_sorensen_k)
+                p.iy += __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(v.x) + __popc(v.y) +
+                        __popc(v.z) + __popc(v.w);
+            else
+                p.iy += __popc(a.x | v.x) + __popc(a.y | v.y) + __popc(a.z | v.z) + __popc(a.w | v.w);
         }
     }
 }
 
-/// Query-side constants of a distance: Σa² in the same summation layout (float cos) or exact (i8).
+/// XOR butterfly over the `lanes_ak` lanes that share a row (offsets lanes/2 … 1), over the members the pair uses.
+template <int metric_ak, int scalar_ak, int lanes_ak> UA_DEVICE void reduce_partial(partial_t& p) {
+    constexpr bool second = metric_ak == metric_cos_k || metric_ak == metric_pearson_k || metric_ak == metric_divergence_k;
+    constexpr bool third = metric_ak == metric_pearson_k;
+#pragma unroll
+    for (int offset = lanes_ak / 2; offset >= 1; offset >>= 1) {
+        if constexpr (f32_math<scalar_ak>()) {
+            p.fx += __shfl_xor(p.fx, offset, 64);
+            if constexpr (second)
+                p.fy += __shfl_xor(p.fy, offset, 64);
+            if constexpr (third)
+                p.fz += __shfl_xor(p.fz, offset, 64);
+        } else if constexpr (scalar_ak == scalar_f64_k) {
+            p.dx += __shfl_xor(p.dx, offset, 64);
+            if constexpr (second)
+                p.dy += __shfl_xor(p.dy, offset, 64);
+            if constexpr (third)
+                p.dz += __shfl_xor(p.dz, offset, 64);
+        } else {
+            p.ix += __shfl_xor(p.ix, offset, 64);
+            p.iy += __shfl_xor(p.iy, offset, 64);
+            if constexpr (third)
+                p.iz += __shfl_xor(p.iz, offset, 64);
+        }
+    }
+}
+
+/// Query-side constants of a distance, in the same summation layout as the rows: Σa² (cos, pearson) and Σa (pearson);
+/// exact integers for i8 (Σa² also serves l2sq there).
 struct query_norm_t {
-    float f = 0.f;
-    int i = 0;
+    float f = 0.f, g = 0.f;
+    double d = 0.0, e = 0.0;
+    int i = 0, j = 0;
 };
 
-template <int metric_ak, int scalar_ak> UA_DEVICE float finalize_distance(partial_t p, query_norm_t a2) {
-    if constexpr (scalar_ak == scalar_f32_k || scalar_ak == scalar_f16_k) {
+/// metric_pearson_gt's closing arithmetic (index_plugins.hpp:1508-1519) from the five sums.
+template <typename real_ak>
+UA_DEVICE real_ak pearson_distance(std::uint32_t dimensions, real_ak ab, real_ak a2, real_ak b2, real_ak sa, real_ak sb) {
+    if (dimensions <= 1)
+        return 0;
+    const real_ak n = (real_ak)dimensions;
+    const real_ak denominator = (n * a2 - sa * sa) * (n * b2 - sb * sb);
+    if (denominator == 0)
+        return 0;
+    const real_ak correlation = n * ab - sa * sb;
+    if constexpr (sizeof(real_ak) == 4)
+        return 1 - correlation / __builtin_sqrtf(denominator);
+    else
+        return 1 - correlation / __builtin_sqrt(denominator);
+}
+
+template <int metric_ak, int scalar_ak>
+UA_DEVICE float finalize_distance(partial_t p, query_norm_t a2, std::uint32_t dimensions) {
+    if constexpr (f32_math<scalar_ak>()) {
         if constexpr (metric_ak == metric_cos_k) { // metric_cos_gt, index_plugins.hpp:1334-1359
             if (a2.f == 0.f && p.fy == 0.f)
                 return 0.f;
@@ -493,8 +623,32 @@ template <int metric_ak, int scalar_ak> UA_DEVICE float finalize_distance(partia
             return 1.f - p.fx / (__builtin_sqrtf(a2.f) * __builtin_sqrtf(p.fy));
         } else if constexpr (metric_ak == metric_ip_k) { // metric_ip_gt 1309-1326
             return 1.f - p.fx;
+        } else if constexpr (metric_ak == metric_pearson_k) {
+            return pearson_distance<float>(dimensions, p.fx, a2.f, p.fy, a2.g, p.fz);
+        } else if constexpr (metric_ak == metric_divergence_k) {
+            return (p.fx + p.fy) / 2;
+        } else if constexpr (metric_ak == metric_haversine_k) {
+            return 2 * asinf(__builtin_sqrtf(p.fx));
         } else { // metric_l2sq_gt 1365-1385
             return p.fx;
+        }
+    } else if constexpr (scalar_ak == scalar_f64_k) { // the same structs with result_t = f64_t, narrowed at the end (2010-2014)
+        if constexpr (metric_ak == metric_cos_k) {
+            if (a2.d == 0.0 && p.dy == 0.0)
+                return 0.f;
+            if (a2.d == 0.0 || p.dy == 0.0)
+                return 1.f;
+            return (float)(1.0 - p.dx / (__builtin_sqrt(a2.d) * __builtin_sqrt(p.dy)));
+        } else if constexpr (metric_ak == metric_ip_k) {
+            return (float)(1.0 - p.dx);
+        } else if constexpr (metric_ak == metric_pearson_k) {
+            return (float)pearson_distance<double>(dimensions, p.dx, a2.d, p.dy, a2.e, p.dz);
+        } else if constexpr (metric_ak == metric_divergence_k) {
+            return (float)((p.dx + p.dy) / 2);
+        } else if constexpr (metric_ak == metric_haversine_k) {
+            return (float)(2 * asin(__builtin_sqrt(p.dx)));
+        } else {
+            return (float)p.dx;
         }
     } else if constexpr (scalar_ak == scalar_i8_k) {
         if constexpr (metric_ak == metric_cos_k) { // metric_cos_i8_t 1583-1607, incl. `ab == 0 → 0`
@@ -502,11 +656,19 @@ template <int metric_ak, int scalar_ak> UA_DEVICE float finalize_distance(partia
             return p.ix != 0 ? 1.f - (float)p.ix / (a2f * b2f) : 0.f;
         } else if constexpr (metric_ak == metric_ip_k) { // metric_ip_gt<i8_t, f32_t>: exact while |Σ| < 2^24
             return 1.f - (float)p.ix;
+        } else if constexpr (metric_ak == metric_pearson_k) { // metric_pearson_gt<i8_t, f32_t>: its f32 sums of small
+            // integers are exact while they stay below 2^24 (dimensions ≤ 1040), which is where these equal them
+            return pearson_distance<float>(dimensions, (float)p.ix, (float)a2.i, (float)p.iy, (float)a2.j, (float)p.iz);
         } else { // metric_l2sq_i8_t 1613-1630: Σ(a-b)² = Σa² + Σb² - 2Σab, exact in int32
             return (float)(a2.i + p.iy - 2 * p.ix);
         }
-    } else { // metric_hamming_gt<b1x8_t> 1392-1414
-        return (float)p.ix;
+    } else {
+        if constexpr (metric_ak == metric_hamming_k) // metric_hamming_gt<b1x8_t> 1392-1414
+            return (float)p.ix;
+        else if constexpr (metric_ak == metric_sorensen_k) // 1 - 2·|a∧b| / (|a| + |b|), f32 like the reference's result_t
+            return 1 - 2 * (float)p.ix / (float)p.iy;
+        else // tanimoto, jaccard: 1 - |a∧b| / |a∨b|
+            return 1 - (float)p.ix / (float)p.iy;
     }
 }
 
@@ -550,47 +712,82 @@ UA_DEVICE void measure_rows(const snapshot_view_t& ix, const std::uint8_t* query
                     if (it + u < chunks_per_lane)
                         accumulate_chunk<metric_ak, scalar_ak>(p, query_lds, sub + (it + u) * lanes_ak, v[u]);
             }
-            reduce_partial<scalar_ak, lanes_ak>(p);
+            reduce_partial<metric_ak, scalar_ak, lanes_ak>(p);
             if (sub == 0)
-                mem::store(out + ci, finalize_distance<metric_ak, scalar_ak>(p, a2));
+                mem::store(out + ci, finalize_distance<metric_ak, scalar_ak>(p, a2, ix.dimensions));
         }
     }
     wave_sync<global_ak>();
 }
 
-/// Query-side constant of the distance for the query already staged in LDS: Σa² in the row summation layout.
+/// Query-side constants of the distance for the query already staged in LDS: Σa² (and Σa for pearson) in the row
+/// summation layout — lane `sub` owns chunks sub, sub+G, …, one chain per lane, XOR butterfly; every group computes the
+/// same value.
 template <int metric_ak, int scalar_ak, int lanes_ak>
 UA_DEVICE query_norm_t staged_norm(const snapshot_view_t& ix, const std::uint8_t* query_lds) {
     const std::uint32_t lane = lane_id();
     query_norm_t a2;
-    if constexpr ((scalar_ak == scalar_f32_k || scalar_ak == scalar_f16_k) && metric_ak == metric_cos_k) {
-        // Σa² with the row layout: lane `sub` owns chunks sub, sub+G, …; every group computes the same value
+    constexpr bool squares = metric_ak == metric_cos_k || metric_ak == metric_pearson_k;
+    if constexpr (f32_math<scalar_ak>() && squares) {
         const std::uint32_t sub = lane % lanes_ak;
-        float sum = 0.f;
+        float sum = 0.f, plain = 0.f;
         for (std::uint32_t c = sub; c < ix.chunks; c += lanes_ak) {
             const float* a = reinterpret_cast<const float*>(query_lds + (std::size_t)c * query_chunk_bytes<scalar_ak>());
-            constexpr int per_chunk = scalar_ak == scalar_f16_k ? 8 : 4;
+            constexpr int per_chunk = narrow_float<scalar_ak>() ? 8 : 4;
 #pragma unroll
-            for (int e = 0; e < per_chunk; ++e)
+            for (int e = 0; e < per_chunk; ++e) {
                 sum = __builtin_fmaf(a[e], a[e], sum);
+                if constexpr (metric_ak == metric_pearson_k)
+                    plain = plain + a[e];
+            }
         }
 #pragma unroll
-        for (int offset = lanes_ak / 2; offset >= 1; offset >>= 1)
+        for (int offset = lanes_ak / 2; offset >= 1; offset >>= 1) {
             sum += __shfl_xor(sum, offset, 64);
-        a2.f = sum;
+            if constexpr (metric_ak == metric_pearson_k)
+                plain += __shfl_xor(plain, offset, 64);
+        }
+        a2.f = sum, a2.g = plain;
+    } else if constexpr (scalar_ak == scalar_f64_k && squares) {
+        const std::uint32_t sub = lane % lanes_ak;
+        double sum = 0.0, plain = 0.0;
+        for (std::uint32_t c = sub; c < ix.chunks; c += lanes_ak) {
+            const double* a = reinterpret_cast<const double*>(query_lds + (std::size_t)c * 16);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                sum = __builtin_fma(a[e], a[e], sum);
+                if constexpr (metric_ak == metric_pearson_k)
+                    plain = plain + a[e];
+            }
+        }
+#pragma unroll
+        for (int offset = lanes_ak / 2; offset >= 1; offset >>= 1) {
+            sum += __shfl_xor(sum, offset, 64);
+            if constexpr (metric_ak == metric_pearson_k)
+                plain += __shfl_xor(plain, offset, 64);
+        }
+        a2.d = sum, a2.e = plain;
     } else if constexpr (scalar_ak == scalar_i8_k && metric_ak != metric_ip_k) {
-        int sum = 0;
+        int sum = 0, plain = 0;
         for (std::uint32_t c = lane; c < ix.chunks; c += 64) {
             const uint4 a = *reinterpret_cast<const uint4*>(query_lds + (std::size_t)c * 16);
             sum = __builtin_amdgcn_sdot4((int)a.x, (int)a.x, sum, false);
             sum = __builtin_amdgcn_sdot4((int)a.y, (int)a.y, sum, false);
             sum = __builtin_amdgcn_sdot4((int)a.z, (int)a.z, sum, false);
             sum = __builtin_amdgcn_sdot4((int)a.w, (int)a.w, sum, false);
+            if constexpr (metric_ak == metric_pearson_k) {
+                plain = __builtin_amdgcn_sdot4(0x01010101, (int)a.x, plain, false);
+                plain = __builtin_amdgcn_sdot4(0x01010101, (int)a.y, plain, false);
+                plain = __builtin_amdgcn_sdot4(0x01010101, (int)a.z, plain, false);
+                plain = __builtin_amdgcn_sdot4(0x01010101, (int)a.w, plain, false);
+            }
         }
 #pragma unroll
-        for (int offset = 32; offset >= 1; offset >>= 1)
+        for (int offset = 32; offset >= 1; offset >>= 1) {
             sum += __shfl_xor(sum, offset, 64);
-        a2.i = sum;
+            plain += __shfl_xor(plain, offset, 64);
+        }
+        a2.i = sum, a2.j = plain;
     }
     return a2;
 }
@@ -599,13 +796,13 @@ UA_DEVICE query_norm_t staged_norm(const snapshot_view_t& ix, const std::uint8_t
 template <int metric_ak, int scalar_ak, int lanes_ak>
 UA_DEVICE query_norm_t stage_query(const snapshot_view_t& ix, const std::uint8_t* query, std::uint8_t* query_lds) {
     const std::uint32_t lane = lane_id();
-    if constexpr (scalar_ak == scalar_f16_k) {
+    if constexpr (narrow_float<scalar_ak>()) {
         float* dst = reinterpret_cast<float*>(query_lds);
         const std::uint32_t scalars = ix.chunks * 8;
         for (std::uint32_t e = lane; e < scalars; e += 64) {
             float value = 0.f;
             if (e < ix.dimensions)
-                value = half_bits_to_float((std::uint32_t)query[2 * e] | ((std::uint32_t)query[2 * e + 1] << 8));
+                value = narrow_bits_to_float<scalar_ak>((std::uint32_t)query[2 * e] | ((std::uint32_t)query[2 * e + 1] << 8));
             dst[e] = value;
         }
     } else {
@@ -624,12 +821,12 @@ UA_DEVICE query_norm_t stage_row(const snapshot_view_t& ix, std::uint32_t slot, 
     const uint4* row = reinterpret_cast<const uint4*>(ix.vectors + (std::uint64_t)slot * ix.row_stride);
     for (std::uint32_t c = lane_id(); c < ix.chunks; c += 64) {
         const uint4 v = row[c];
-        if constexpr (scalar_ak == scalar_f16_k) {
+        if constexpr (narrow_float<scalar_ak>()) {
             float4* dst = reinterpret_cast<float4*>(query_lds + (std::size_t)c * 32);
-            dst[0] = float4{half_bits_to_float(v.x & 0xFFFFu), half_bits_to_float(v.x >> 16),
-                            half_bits_to_float(v.y & 0xFFFFu), half_bits_to_float(v.y >> 16)};
-            dst[1] = float4{half_bits_to_float(v.z & 0xFFFFu), half_bits_to_float(v.z >> 16),
-                            half_bits_to_float(v.w & 0xFFFFu), half_bits_to_float(v.w >> 16)};
+            dst[0] = float4{narrow_bits_to_float<scalar_ak>(v.x & 0xFFFFu), narrow_bits_to_float<scalar_ak>(v.x >> 16),
+                            narrow_bits_to_float<scalar_ak>(v.y & 0xFFFFu), narrow_bits_to_float<scalar_ak>(v.y >> 16)};
+            dst[1] = float4{narrow_bits_to_float<scalar_ak>(v.z & 0xFFFFu), narrow_bits_to_float<scalar_ak>(v.z >> 16),
+                            narrow_bits_to_float<scalar_ak>(v.w & 0xFFFFu), narrow_bits_to_float<scalar_ak>(v.w >> 16)};
         } else {
             *reinterpret_cast<uint4*>(query_lds + (std::size_t)c * 16) = v;
         }
@@ -664,7 +861,7 @@ inline __host__ __device__ scratch_layout_t scratch_layout(std::uint64_t top_cel
 }
 
 template <int scalar_ak> inline __host__ __device__ std::uint32_t query_lds_bytes(std::uint32_t chunks) {
-    return chunks * (scalar_ak == scalar_f16_k ? 32u : 16u); // a multiple of 16
+    return chunks * ((scalar_ak == scalar_f16_k || scalar_ak == scalar_bf16_k) ? 32u : 16u); // a multiple of 16
 }
 
 /**
@@ -788,6 +985,21 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     wave_sync<global_ak>();
     measure(1);
     float radius = uniform_f32(mem::load(cand_distances));
+    // index_gt::cluster (index.hpp:3089-3125) is the descent alone, down to `beam_level`, plus one more evaluation of the
+    // winner's distance (3115) — the very evaluation the beam starts with: one result per query (`wanted` = 1)
+    if (args.descent_only) {
+        if (lane == 0) {
+            args.keys[q] = args.emit_slots ? (std::uint64_t)closest : ix.keys[closest];
+            args.distances[q] = radius;
+            args.counts[q] = 1;
+            args.visited[q] = cycles;
+            args.computed[q] = computed;
+            args.status[q] = status_done_k;
+            if (args.peaks)
+                args.peaks[2 * (std::uint64_t)q] = 0, args.peaks[2 * (std::uint64_t)q + 1] = 0;
+        }
+        return true;
+    }
     heap_push<global_ak>(next, next_size, -radius, closest);
     visits_set<mode_ak>(visits, visits_mask, closest, lane == 0);
     visits_count = 1;

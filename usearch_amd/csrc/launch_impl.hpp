@@ -48,7 +48,8 @@ template <int metric_ak, int scalar_ak, int lanes_ak>
 hipError_t launch_search_lanes(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
     if (p.mode == scratch_global_k)
         return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_u4_w4_k, scratch_global_k, 0>(p, view, args);
-    if constexpr (lanes_ak == 8) { // rows of ≥ 128 bytes: the unroll depth matters
+    // rows of ≥ 128 bytes: the unroll depth matters; pairs outside the common set only carry the 4-deep build
+    if constexpr (lanes_ak == 8 && all_kernel_builds((metric_kind_t)metric_ak, (scalar_kind_t)scalar_ak)) {
         switch (p.variant) {
         case variant_u8_w3_k: return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u8_w3_k>(p, view, args);
         case variant_u12_w2_k: return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u12_w2_k>(p, view, args);

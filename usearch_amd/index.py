@@ -25,7 +25,18 @@ SCALAR_KINDS = {"f32": 1, "f64": 2, "f16": 3, "i8": 4, "b1": 5, "bf16": 6}
 SCALAR_NAMES = {v: k for k, v in SCALAR_KINDS.items()}
 METRIC_NAMES = {1: "cos", 2: "ip", 3: "l2sq", 4: "haversine", 5: "divergence", 6: "pearson", 7: "jaccard",
                 8: "hamming", 9: "tanimoto", 10: "sorensen"}
-NUMPY_DTYPES = {"f32": np.float32, "f64": np.float64, "f16": np.float16, "i8": np.int8, "b1": np.uint8}
+NUMPY_DTYPES = {"f32": np.float32, "f64": np.float64, "f16": np.float16, "i8": np.int8, "b1": np.uint8,
+                "bf16": np.uint16}  # numpy has no bfloat16: bf16 rows are handed over as their uint16 bit patterns
+
+
+def _infer_dtype(array: np.ndarray) -> str:
+    """Scalar kind of a numpy array when the caller did not name it: `uint8` means bit-packed `b1` rows; `bf16` has no
+    numpy dtype and must always be named (`dtype="bf16"` with a `uint16` array)."""
+    dtype = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64", np.dtype(np.float16): "f16",
+             np.dtype(np.int8): "i8", np.dtype(np.uint8): "b1"}.get(array.dtype)
+    if dtype is None:
+        raise ValueError(f"Unsupported dtype {array.dtype}")
+    return dtype
 
 
 class Tuning(C.Structure):
@@ -69,7 +80,7 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_snapshot_metric_kind", "usearch_amd_snapshot_lanes_per_row", "usearch_amd_search_many",
     "usearch_amd_search_many_device", "usearch_amd_last_peaks", "usearch_amd_distances",
     "usearch_amd_last_distances_ms", "usearch_amd_merge_many", "usearch_amd_merge_many_device",
-    "usearch_amd_exact_search_many", "usearch_amd_exact_search_dataset",
+    "usearch_amd_exact_search_many", "usearch_amd_exact_search_dataset", "usearch_amd_cluster_many",
     "usearch_amd_test_containers", "usearch_amd_cast",
     "usearch_amd_build", "usearch_amd_build_free", "usearch_amd_build_snapshot",
     "usearch_amd_build_serialized_length", "usearch_amd_build_save_buffer", "usearch_amd_build_stats",
@@ -111,6 +122,8 @@ def library() -> C.CDLL:
                                                  C.POINTER(Stats), err_p]
     L.usearch_amd_merge_many_device.argtypes = [C.c_void_p] * 3 + [C.c_size_t] * 3 + [C.c_void_p] * 4 + [err_p]
     L.usearch_amd_merge_many.argtypes = [C.c_void_p] * 3 + [C.c_size_t] * 3 + [C.c_void_p] * 3 + [err_p]
+    L.usearch_amd_cluster_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, err_p]
     L.usearch_amd_exact_search_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), err_p]
     L.usearch_amd_exact_search_dataset.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
@@ -298,10 +311,7 @@ class Index:
         if vectors.ndim != 2:
             raise ValueError("Expects a matrix or a vector")
         if dtype is None:
-            dtype = {np.dtype(np.float32): "f32", np.dtype(np.float64): "f64", np.dtype(np.float16): "f16",
-                     np.dtype(np.int8): "i8", np.dtype(np.uint8): "b1"}.get(vectors.dtype)
-            if dtype is None:
-                raise ValueError(f"Unsupported dtype {vectors.dtype}")
+            dtype = _infer_dtype(vectors)
         expected_columns = (self.ndim + 7) // 8 if dtype == "b1" else self.ndim
         if vectors.shape[1] != expected_columns:
             raise ValueError(f"The number of columns {vectors.shape[1]} must match the index ({expected_columns})")
@@ -364,6 +374,29 @@ class Index:
         library().usearch_amd_last_peaks(self._handle, _pointer(out), queries_count, C.byref(err))
         _raise(err, "usearch_amd_last_peaks")
         return out
+
+    def cluster(self, vectors: np.ndarray, level: int = 1, dtype: Optional[str] = None):
+        """`index_dense_gt::cluster(query, level)` for a batch (index_dense.hpp:788-793 → index.hpp:3089-3125):
+        → (keys[Q], distances[Q], visited[Q], computed[Q]) — per query the member the greedy descent reaches on `level`."""
+        vectors = np.asarray(vectors)
+        if vectors.ndim == 1:
+            vectors = vectors[None, :]
+        if dtype is None:
+            dtype = _infer_dtype(vectors)
+        if vectors.strides[1] != vectors.itemsize:
+            vectors = np.ascontiguousarray(vectors)
+        q = len(vectors)
+        keys = np.zeros(q, dtype=np.uint64)
+        distances = np.zeros(q, dtype=np.float32)
+        visited = np.zeros(q, dtype=np.uint64)
+        computed = np.zeros(q, dtype=np.uint64)
+        err = C.c_char_p()
+        library().usearch_amd_cluster_many(self._handle, _pointer(vectors), SCALAR_KINDS[dtype], q,
+                                           vectors.shape[1] * vectors.itemsize if q <= 1 else vectors.strides[0], level,
+                                           _pointer(keys), _pointer(distances), _pointer(visited), _pointer(computed),
+                                           C.byref(err))
+        _raise(err, "usearch_amd_cluster_many")
+        return keys, distances, visited, computed
 
     def distances(self, queries: np.ndarray, slots: np.ndarray) -> np.ndarray:
         """out[q, j] = metric(queries[q], stored vector of slot slots[q, j]); queries in the storage kind."""
@@ -441,8 +474,7 @@ def build(vectors, metric: str = "cos", dtype: Optional[str] = None, *, keys: Op
     else:
         vectors = np.asarray(vectors)
         if dtype is None:
-            dtype = {np.dtype(np.float32): "f32", np.dtype(np.float16): "f16", np.dtype(np.int8): "i8",
-                     np.dtype(np.uint8): "b1"}[vectors.dtype]
+            dtype = _infer_dtype(vectors)
         if vectors.ndim != 2 or vectors.strides[1] != vectors.itemsize:
             vectors = np.ascontiguousarray(vectors)
         if ndim is None:
@@ -462,8 +494,7 @@ def exact_search(dataset: np.ndarray, queries: np.ndarray, count: int, metric: s
     distances [Q, k]); both matrices in the same scalar kind, rows may be strided."""
     dataset, queries = np.asarray(dataset), np.asarray(queries)
     if dtype is None:
-        dtype = {np.dtype(np.float32): "f32", np.dtype(np.float16): "f16", np.dtype(np.int8): "i8",
-                 np.dtype(np.uint8): "b1"}[dataset.dtype]
+        dtype = _infer_dtype(dataset)
     ndim = dataset.shape[1] * 8 if dtype == "b1" else dataset.shape[1]
     metric_kind = {name: kind for kind, name in METRIC_NAMES.items()}[metric]
     keys = np.zeros((len(queries), count), dtype=np.uint64)
