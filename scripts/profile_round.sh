@@ -19,7 +19,12 @@ EF=$(python -c "import json,sys; print(json.load(open('$OUT/bench.json'))['confi
 QUICK="$* --expansion $EF --recall-queries 0 --no-cpu-baseline --steps 3 --warmup 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python "$REPO/bench.py" $QUICK > "$OUT/stats_bench.json" 2> "$OUT/stats.log"
 find "$OUT/stats" -name "*kernel_stats.csv" | head -1 | while read f; do cp "$f" "$OUT/kernel_stats.csv"; done
+# PROFILE_TRAFFIC_ONLY=1 keeps the two passes roofline.traffic needs (about half the GPU time of the full set)
+GROUPS_LIMIT=${PROFILE_TRAFFIC_ONLY:+2}
+PASS=0
 for counters in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS"; do
+  PASS=$((PASS + 1))
+  if [ -n "${GROUPS_LIMIT:-}" ] && [ "$PASS" -gt "$GROUPS_LIMIT" ]; then break; fi
   name=$(echo $counters | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $counters --output-format csv -d "$OUT/pmc_$name" -- python "$REPO/bench.py" $QUICK > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.log" || echo "pmc $counters failed"
   # keep per-dispatch counter rows of the search kernel only

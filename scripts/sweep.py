@@ -34,6 +34,9 @@ def main():
     p.add_argument("--cache-dir", default="/dev/shm")
     p.add_argument("--gather", action="store_true")
     p.add_argument("--build-threads", type=int, default=0)
+    p.add_argument("--env", nargs="*", default=[""],
+                   help="environment settings to A/B on the same index, one run each: 'NAME=V,NAME2=V2' ('' = none); the "
+                        "engine reads its USEARCH_AMD_* switches at every search call")
     args = p.parse_args()
     metric = "hamming" if args.dtype == "b1" else "l2sq" if args.dtype == "i8" else "cos"
 
@@ -71,6 +74,13 @@ def main():
                   f"{nq * per * index.row_stride / ms / 1e6:.1f} GB/s", flush=True)
     reference_keys = {}
     for ef in args.ef:
+      for setting in args.env:
+        for name in [n for n in os.environ if n.startswith("USEARCH_AMD_")]:
+            del os.environ[name]
+        for pair in filter(None, setting.split(",")):
+            os.environ[pair.split("=")[0]] = pair.split("=")[1]
+        if setting:
+            print(f"--- {setting}", flush=True)
         for mode in args.modes:
             for waves in args.waves:
                 for variant in args.variants:

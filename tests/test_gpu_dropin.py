@@ -205,7 +205,8 @@ def test_c_test_program(lib, count, dimensions, tmp_path):
     their_keys, their_distances, *_ = theirs.search(data[:8], 3, dtype="f32")
     for i in range(8):
         lib.usearch_search(index, ptr(data[i]), SCALAR["f32"], 3, ptr(keys), ptr(distances), C.byref(err))
-        assert np.allclose(distances[:3], their_distances[i], atol=1e-5)
+        # 2-d Pearson is all cancellation (every distance is 0, 1 or 2 up to rounding that the two builds fuse differently)
+        assert np.allclose(distances[:3], their_distances[i], atol=1e-5 if dimensions > 2 else 1e-3)
         if dimensions > 2:  # the Pearson distance of 2-d vectors is 0, 1 or 2: ties everywhere
             assert np.array_equal(keys[:3], their_keys[i])
     lib.usearch_free(index, C.byref(err))
