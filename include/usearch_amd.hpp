@@ -149,6 +149,20 @@ class index_dense_t {
         return result;
     }
 
+    /// `cluster(vector, level)` (index_dense.hpp:788-793): the member the greedy descent reaches on `level` of the hierarchy.
+    struct cluster_result_t {
+        vector_key_t key = 0;
+        distance_t distance = 0;
+        char const* error = nullptr;
+        explicit operator bool() const noexcept { return !error; }
+    };
+    cluster_result_t cluster(float const* q, std::size_t level, std::size_t = 0) const { return cluster_(q, usearch_scalar_f32_k, level); }
+    cluster_result_t cluster(f16_bits_t const* q, std::size_t level, std::size_t = 0) const { return cluster_(q, usearch_scalar_f16_k, level); }
+    cluster_result_t cluster(std::int8_t const* q, std::size_t level, std::size_t = 0) const { return cluster_(q, usearch_scalar_i8_k, level); }
+    cluster_result_t cluster(b1x8_t const* q, std::size_t level, std::size_t = 0) const { return cluster_(q, usearch_scalar_b1_k, level); }
+    cluster_result_t cluster(double const* q, std::size_t level, std::size_t = 0) const { return cluster_(q, usearch_scalar_f64_k, level); }
+    cluster_result_t cluster(bf16_bits_t const* q, std::size_t level, std::size_t = 0) const { return cluster_(q, usearch_scalar_bf16_k, level); }
+
     /// `filtered_search` (index_dense.hpp:774-779): `predicate(key) -> bool`, evaluated on the host once per member.
     template <typename predicate_at>
     search_result_t filtered_search(float const* query, std::size_t wanted, predicate_at&& predicate) const {
@@ -178,6 +192,12 @@ class index_dense_t {
         usearch_add(handle_, key, vector, kind, &result.error);
         return result;
     }
+    cluster_result_t cluster_(void const* query, usearch_scalar_kind_t kind, std::size_t level) const {
+        cluster_result_t result;
+        usearch_cluster_many(handle_, query, kind, 1, 0, level, &result.key, &result.distance, &result.error);
+        return result;
+    }
+
     search_result_t search_(void const* query, usearch_scalar_kind_t kind, std::size_t, std::size_t, std::size_t wanted,
                             bool exact) const {
         search_result_t result;

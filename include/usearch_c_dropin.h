@@ -153,6 +153,14 @@ USEARCH_EXPORT void usearch_search_many(usearch_index_t index, void const* queri
                                         usearch_key_t* keys, size_t keys_stride, usearch_distance_t* distances,
                                         size_t distances_stride, size_t* counts, size_t* visited_members,
                                         size_t* computed_distances, usearch_error_t* error);
+/**
+ *  `index_dense_gt::cluster(query, level)` (index_dense.hpp:788-793 → index_gt::cluster, index.hpp:3089-3125) for a batch:
+ *  per query the member the greedy descent reaches on `level` of the hierarchy and its distance — the C ABI of the reference
+ *  has no entry point for it, its C++ class does. `keys` and `distances` hold one cell per query.
+ */
+USEARCH_EXPORT void usearch_cluster_many(usearch_index_t index, void const* queries, usearch_scalar_kind_t query_kind,
+                                         size_t queries_count, size_t queries_stride, size_t level,
+                                         usearch_key_t* keys, usearch_distance_t* distances, usearch_error_t* error);
 /** Takes (or refreshes) the HBM snapshot now instead of at the next search. */
 USEARCH_EXPORT void usearch_gpu_sync(usearch_index_t index, usearch_error_t* error);
 /** Drops the HBM snapshot (it is re-taken on demand). */

@@ -51,6 +51,10 @@ int main(int argc, char** argv) {
     for (std::size_t i = 0; i < 200; ++i)
         EXPECT(batch.counts[i] == 5 && batch.keys[i * 5] == 1000 + i);
     EXPECT(batch.computed_distances > 0 && batch.visited_members > 0);
+    // cluster(vector, level): level 0 and 1 both end on level 1's winner; far above the top level it is the entry point
+    auto low = index.cluster(data.data(), 0), same = index.cluster(data.data(), 1), top_most = index.cluster(data.data(), 99);
+    EXPECT(low && same && top_most && low.key == same.key && low.distance == same.distance);
+    EXPECT(index.contains(low.key) && index.contains(top_most.key) && top_most.distance >= low.distance);
     // predicate
     auto odd = index.filtered_search(data.data(), 10, [](vector_key_t key) { return key % 2 == 1; });
     EXPECT(odd && odd.size() == 10);

@@ -62,6 +62,8 @@ def lib():
                                           C.c_void_p, err]
     L.usearch_search_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
                                       C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, err]
+    L.usearch_cluster_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                                       C.c_void_p, err]
     L.usearch_get.restype = C.c_size_t
     L.usearch_get.argtypes = [C.c_void_p, C.c_uint64, C.c_size_t, C.c_void_p, C.c_int, err]
     L.usearch_remove.restype = C.c_size_t
@@ -291,6 +293,14 @@ def test_batch_and_buffers_match_the_reference(lib, reference):
     assert np.array_equal(keys, rkeys) and util.same_float_bits(distances, rdistances)
     assert np.array_equal(counts, rcounts)
     assert visited.value == int(np.sum(rvisited)) and computed.value == int(np.sum(rcomputed))
+    # the additive `usearch_cluster_many`: index_dense_gt::cluster(query, level) of the reference, level by level
+    for level in (0, 1, 2, 5):
+        cluster_keys, cluster_distances = np.zeros(200, dtype=np.uint64), np.zeros(200, dtype=np.float32)
+        lib.usearch_cluster_many(index, ptr(queries), SCALAR["i8"], 200, queries.strides[0], level, ptr(cluster_keys),
+                                 ptr(cluster_distances), C.byref(err))
+        ok(err)
+        their_keys, their_distances, *_ = theirs.cluster(queries, level, dtype="i8", threads=1)
+        assert np.array_equal(cluster_keys, their_keys) and util.same_float_bits(cluster_distances, their_distances)
     # save_buffer of an untouched image returns it byte for byte
     length = lib.usearch_serialized_length(index, C.byref(err))
     assert length == image.size

@@ -94,7 +94,7 @@ def test_drop_in_library_exports_the_reference_c_abi():
         assert hasattr(library, f"usearch_{name}"), f"usearch_{name} is missing from the drop-in"
     header = open(os.path.join(ROOT, "include", "usearch_c_dropin.h")).read()
     declared = sorted(set(re.findall(r"USEARCH_EXPORT[^;(]*?\b(usearch_\w+)\s*\(", header)))
-    assert len(declared) == 41
+    assert len(declared) == 42
     for name in declared:
         assert hasattr(library, name), f"{name} is declared in include/usearch_c_dropin.h but not exported"
     reference_header = "/root/reference/c/usearch.h"

@@ -683,6 +683,30 @@ void usearch_search_many(usearch_index_t handle, void const* queries, usearch_sc
                   distances_stride, counts, visited_members, computed_distances, nullptr, error);
 }
 
+void usearch_cluster_many(usearch_index_t handle, void const* queries, usearch_scalar_kind_t query_kind,
+                          size_t queries_count, size_t queries_stride, size_t level, usearch_key_t* keys,
+                          usearch_distance_t* distances, usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    std::lock_guard<std::mutex> lock(index.mutex);
+    const scalar_kind_t kind = scalar_from_c(query_kind);
+    if (kind == scalar_unknown_k)
+        return fail(error, "Unknown scalar kind!");
+    if (!queries_count)
+        return;
+    if (!queries || !keys || !distances)
+        return fail(error, "Cluster search needs the query, key and distance buffers");
+    snapshot_t* device_index = nullptr;
+    if (const char* e = index.ready(&device_index))
+        return fail(error, e);
+    if (!device_index) // index_gt::cluster on an empty index, index.hpp:3102-3103
+        return fail(error, "No clusters to identify");
+    std::vector<std::uint64_t> found(queries_count);
+    if (const char* e = device_index->cluster_host(queries, kind, queries_count, queries_stride, level, found.data(),
+                                                   distances, nullptr, nullptr))
+        return fail(error, e);
+    std::copy(found.begin(), found.end(), keys);
+}
+
 size_t usearch_filtered_search(usearch_index_t handle, void const* query, usearch_scalar_kind_t query_kind, size_t count,
                                int (*filter)(usearch_key_t key, void* filter_state), void* filter_state,
                                usearch_key_t* keys, usearch_distance_t* distances, usearch_error_t* error) {
