@@ -249,18 +249,32 @@ def main() -> None:
         log(f"[bench] exact ground truth for {sample} queries in {time.time() - t0:.1f}s"
             + (" (recall counted by distance: ties)" if by_distance else ""))
         sweep = [args.expansion] if args.expansion else [64, 96, 128, 192, 256, 320, 384, 448, 512, 576, 640, 704, 768, 896, 1024]
-        for ef in sweep:
+
+        def recall_at(ef: int) -> float:
             search_step(ef, False)
             found = keys_dev[:sample].cpu().numpy().astype(np.uint64)
             if by_distance:
                 found_distances = dist_dev[:sample].cpu().numpy()
-                recall = float(np.mean(found_distances <= truth_distances[:, -1:]))
+                value = float(np.mean(found_distances <= truth_distances[:, -1:]))
             else:
-                recall = float(np.mean([len(np.intersect1d(found[i], truth[i])) / args.k for i in range(sample)]))
-            expansion = ef
-            log(f"[bench] ef={ef}: recall@{args.k} = {recall:.4f} on {sample} queries")
+                value = float(np.mean([len(np.intersect1d(found[i], truth[i])) / args.k for i in range(sample)]))
+            log(f"[bench] ef={ef}: recall@{args.k} = {value:.4f} on {sample} queries")
+            return value
+
+        below = 0
+        for ef in sweep:
+            recall, expansion = recall_at(ef), ef
             if recall >= 0.95:
                 break
+            below = ef
+        # the metric is quoted at the SMALLEST expansion that reaches the recall: walk the gap between the last
+        # grid point that missed it and the first that made it in steps of 16
+        if not args.expansion and recall >= 0.95 and below:
+            for ef in range(below + 16, expansion, 16):
+                finer = recall_at(ef)
+                if finer >= 0.95:
+                    recall, expansion = finer, ef
+                    break
     if world > 1:
         chosen = torch.tensor([expansion or 64], device=device)
         dist.broadcast(chosen, 0)
