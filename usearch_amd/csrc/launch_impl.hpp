@@ -64,7 +64,11 @@ hipError_t launch_search_metric(const launch_params_t& p, const snapshot_view_t&
     switch (p.lanes) {
     case 1: return launch_search_lanes<metric_ak, scalar_ak, 1>(p, view, args);
     case 2: return launch_search_lanes<metric_ak, scalar_ak, 2>(p, view, args);
-    case 4: return launch_search_lanes<metric_ak, scalar_ak, 4>(p, view, args);
+    case 4: // never chosen by `row_geometry`, only forced (USEARCH_AMD_LANES): kept for the common pairs' tuning runs
+        if constexpr (all_kernel_builds((metric_kind_t)metric_ak, (scalar_kind_t)scalar_ak))
+            return launch_search_lanes<metric_ak, scalar_ak, 4>(p, view, args);
+        else
+            return hipErrorInvalidValue;
     case 8: return launch_search_lanes<metric_ak, scalar_ak, 8>(p, view, args);
     default: return hipErrorInvalidValue;
     }
@@ -83,7 +87,11 @@ hipError_t launch_distances_metric(const distances_params_t& p, const snapshot_v
     switch (p.lanes) {
     case 1: return launch_distances_one<metric_ak, scalar_ak, 1>(p, view);
     case 2: return launch_distances_one<metric_ak, scalar_ak, 2>(p, view);
-    case 4: return launch_distances_one<metric_ak, scalar_ak, 4>(p, view);
+    case 4: // never chosen by `row_geometry`, only forced (USEARCH_AMD_LANES): kept for the common pairs' tuning runs
+        if constexpr (all_kernel_builds((metric_kind_t)metric_ak, (scalar_kind_t)scalar_ak))
+            return launch_distances_one<metric_ak, scalar_ak, 4>(p, view);
+        else
+            return hipErrorInvalidValue;
     case 8: return launch_distances_one<metric_ak, scalar_ak, 8>(p, view);
     default: return hipErrorInvalidValue;
     }
@@ -103,7 +111,11 @@ hipError_t launch_exact_metric(const exact_params_t& p, const snapshot_view_t& v
     switch (p.lanes) {
     case 1: return launch_exact_one<metric_ak, scalar_ak, 1>(p, view);
     case 2: return launch_exact_one<metric_ak, scalar_ak, 2>(p, view);
-    case 4: return launch_exact_one<metric_ak, scalar_ak, 4>(p, view);
+    case 4: // never chosen by `row_geometry`, only forced (USEARCH_AMD_LANES): kept for the common pairs' tuning runs
+        if constexpr (all_kernel_builds((metric_kind_t)metric_ak, (scalar_kind_t)scalar_ak))
+            return launch_exact_one<metric_ak, scalar_ak, 4>(p, view);
+        else
+            return hipErrorInvalidValue;
     case 8: return launch_exact_one<metric_ak, scalar_ak, 8>(p, view);
     default: return hipErrorInvalidValue;
     }
@@ -127,7 +139,11 @@ hipError_t launch_build_metric(const build_params_t& p, const snapshot_view_t& v
     switch (p.lanes) {
     case 1: return launch_build_one<metric_ak, scalar_ak, 1>(p, view, args);
     case 2: return launch_build_one<metric_ak, scalar_ak, 2>(p, view, args);
-    case 4: return launch_build_one<metric_ak, scalar_ak, 4>(p, view, args);
+    case 4: // never chosen by `row_geometry`, only forced (USEARCH_AMD_LANES): kept for the common pairs' tuning runs
+        if constexpr (all_kernel_builds((metric_kind_t)metric_ak, (scalar_kind_t)scalar_ak))
+            return launch_build_one<metric_ak, scalar_ak, 4>(p, view, args);
+        else
+            return hipErrorInvalidValue;
     case 8: return launch_build_one<metric_ak, scalar_ak, 8>(p, view, args);
     default: return hipErrorInvalidValue;
     }
