@@ -174,9 +174,65 @@ __global__ __launch_bounds__(64) void top_bench_kernel(std::uint32_t count, std:
     }
 }
 
+/**
+ *  Micro-benchmark of the frontier heap: every wave fills a heap of `fill` pseudo-random keys in LDS, then alternates
+ *  `count` pops and pushes (the traversal's steady state) and reports the shader-clock ticks spent in each (diagnostic only).
+ *  `serial_ak` selects the one-level-per-round-trip pop of the reference's shape.
+ */
+template <bool serial_ak>
+__global__ __launch_bounds__(64) void heap_bench_kernel(std::uint32_t fill, std::uint32_t count, unsigned long long* out) {
+    extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
+    cand_t* heap = reinterpret_cast<cand_t*>(lds);
+    std::uint32_t size = 0, state = 4321u + blockIdx.x * 977u;
+    auto next_key = [&]() {
+        state = state * 1664525u + 1013904223u;
+        return uniform_f32(-(float)(state >> 8) * (1.0f / 16777216.0f));
+    };
+    for (std::uint32_t i = 0; i < fill; ++i)
+        heap_push<false>(heap, size, next_key(), i);
+    unsigned long long pop_ticks = 0, push_ticks = 0, checksum = 0;
+    for (std::uint32_t i = 0; i < count; ++i) {
+        const std::uint64_t t0 = __builtin_amdgcn_s_memtime();
+        cand_t popped;
+        if constexpr (serial_ak)
+            popped = heap_pop_serial<false>(heap, size);
+        else
+            popped = heap_pop<false>(heap, size);
+        const std::uint64_t t1 = __builtin_amdgcn_s_memtime();
+        heap_push<false>(heap, size, next_key(), fill + i);
+        const std::uint64_t t2 = __builtin_amdgcn_s_memtime();
+        pop_ticks += t1 - t0, push_ticks += t2 - t1, checksum += popped;
+    }
+    if (lane_id() == 0)
+        out[3 * blockIdx.x] = pop_ticks, out[3 * blockIdx.x + 1] = push_ticks, out[3 * blockIdx.x + 2] = checksum;
+}
+
 } // namespace usearch_amd
 
 extern "C" {
+
+/** Diagnostic: per-wave ticks of `heap_bench_kernel` and a checksum of what was popped (both pops must agree on it). Not in
+ *  the public header. */
+__attribute__((visibility("default"))) void usearch_amd_bench_heap(uint32_t serial, uint32_t fill, uint32_t count,
+                                                                    uint32_t waves, uint64_t* pop_ticks,
+                                                                    uint64_t* push_ticks, uint64_t* checksums,
+                                                                    usearch_amd_error_t* error) {
+    unsigned long long* d_out = nullptr;
+    if (hipMalloc((void**)&d_out, (size_t)waves * 24) != hipSuccess)
+        return fail(error, "hipMalloc failed");
+    const size_t lds = ((size_t)fill + 8) * 8;
+    if (serial)
+        hipLaunchKernelGGL(heap_bench_kernel<true>, dim3(waves), dim3(64), lds, nullptr, fill, count, d_out);
+    else
+        hipLaunchKernelGGL(heap_bench_kernel<false>, dim3(waves), dim3(64), lds, nullptr, fill, count, d_out);
+    std::vector<unsigned long long> host((size_t)waves * 3);
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(host.data(), d_out, host.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        fail(error, "heap bench failed");
+    for (uint32_t w = 0; w < waves; ++w)
+        pop_ticks[w] = host[3 * w], push_ticks[w] = host[3 * w + 1], checksums[w] = host[3 * w + 2];
+    (void)hipFree(d_out);
+}
 
 /** Diagnostic: ticks[wave] and accepted[wave] of `top_bench_kernel` (entries per lane 4, 8 or 16). Not in the public header. */
 __attribute__((visibility("default"))) void usearch_amd_bench_top(uint32_t epl, uint32_t count, uint32_t limit,
