@@ -67,6 +67,25 @@ UA_DEVICE std::uint32_t rank_below(std::uint64_t m, std::uint32_t lane) {
     return popcount64(m & ((1ull << lane) - 1ull)); // lane < 64
 }
 
+/// Lane `i` receives the value of lane `i ^ offset`. Inside a quad (offsets 1 and 2) that is one DPP `quad_perm` move on the
+/// vector ALU; wider exchanges go through the LDS crossbar (`ds_bpermute`). Same value either way: summation order untouched.
+UA_DEVICE std::uint32_t xor_lane_u32(std::uint32_t v, int offset) {
+    if (offset == 1)
+        return (std::uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
+    if (offset == 2)
+        return (std::uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false);
+    return (std::uint32_t)__shfl_xor((int)v, offset, 64);
+}
+UA_DEVICE int xor_lane(int v, int offset) { return (int)xor_lane_u32((std::uint32_t)v, offset); }
+UA_DEVICE float xor_lane(float v, int offset) {
+    return __builtin_bit_cast(float, xor_lane_u32(__builtin_bit_cast(std::uint32_t, v), offset));
+}
+UA_DEVICE double xor_lane(double v, int offset) {
+    const std::uint64_t bits = __builtin_bit_cast(std::uint64_t, v);
+    const std::uint64_t low = xor_lane_u32((std::uint32_t)bits, offset), high = xor_lane_u32((std::uint32_t)(bits >> 32), offset);
+    return __builtin_bit_cast(double, low | (high << 32));
+}
+
 /// {float distance; u32 slot} of index.hpp:2097-2101, packed so that one 8-byte LDS access moves it.
 using cand_t = std::uint64_t;
 UA_DEVICE cand_t make_cand(float d, std::uint32_t slot) {
@@ -638,22 +657,22 @@ template <int metric_ak, int scalar_ak, int lanes_ak> UA_DEVICE void reduce_part
 #pragma unroll
     for (int offset = lanes_ak / 2; offset >= 1; offset >>= 1) {
         if constexpr (f32_math<scalar_ak>()) {
-            p.fx += __shfl_xor(p.fx, offset, 64);
+            p.fx += xor_lane(p.fx, offset);
             if constexpr (second)
-                p.fy += __shfl_xor(p.fy, offset, 64);
+                p.fy += xor_lane(p.fy, offset);
             if constexpr (third)
-                p.fz += __shfl_xor(p.fz, offset, 64);
+                p.fz += xor_lane(p.fz, offset);
         } else if constexpr (scalar_ak == scalar_f64_k) {
-            p.dx += __shfl_xor(p.dx, offset, 64);
+            p.dx += xor_lane(p.dx, offset);
             if constexpr (second)
-                p.dy += __shfl_xor(p.dy, offset, 64);
+                p.dy += xor_lane(p.dy, offset);
             if constexpr (third)
-                p.dz += __shfl_xor(p.dz, offset, 64);
+                p.dz += xor_lane(p.dz, offset);
         } else {
-            p.ix += __shfl_xor(p.ix, offset, 64);
-            p.iy += __shfl_xor(p.iy, offset, 64);
+            p.ix += xor_lane(p.ix, offset);
+            p.iy += xor_lane(p.iy, offset);
             if constexpr (third)
-                p.iz += __shfl_xor(p.iz, offset, 64);
+                p.iz += xor_lane(p.iz, offset);
         }
     }
 }
@@ -813,9 +832,9 @@ UA_DEVICE query_norm_t staged_norm(const snapshot_view_t& ix, const std::uint8_t
         }
 #pragma unroll
         for (int offset = lanes_ak / 2; offset >= 1; offset >>= 1) {
-            sum += __shfl_xor(sum, offset, 64);
+            sum += xor_lane(sum, offset);
             if constexpr (metric_ak == metric_pearson_k)
-                plain += __shfl_xor(plain, offset, 64);
+                plain += xor_lane(plain, offset);
         }
         a2.f = sum, a2.g = plain;
     } else if constexpr (scalar_ak == scalar_f64_k && squares) {
@@ -832,9 +851,9 @@ UA_DEVICE query_norm_t staged_norm(const snapshot_view_t& ix, const std::uint8_t
         }
 #pragma unroll
         for (int offset = lanes_ak / 2; offset >= 1; offset >>= 1) {
-            sum += __shfl_xor(sum, offset, 64);
+            sum += xor_lane(sum, offset);
             if constexpr (metric_ak == metric_pearson_k)
-                plain += __shfl_xor(plain, offset, 64);
+                plain += xor_lane(plain, offset);
         }
         a2.d = sum, a2.e = plain;
     } else if constexpr (scalar_ak == scalar_i8_k && metric_ak != metric_ip_k) {
@@ -854,8 +873,8 @@ UA_DEVICE query_norm_t staged_norm(const snapshot_view_t& ix, const std::uint8_t
         }
 #pragma unroll
         for (int offset = 32; offset >= 1; offset >>= 1) {
-            sum += __shfl_xor(sum, offset, 64);
-            plain += __shfl_xor(plain, offset, 64);
+            sum += xor_lane(sum, offset);
+            plain += xor_lane(plain, offset);
         }
         a2.i = sum, a2.j = plain;
     }
