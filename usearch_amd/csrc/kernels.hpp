@@ -139,25 +139,45 @@ template <bool global_ak> struct scratch_gt {
  *  insert + shift_up (index.hpp:765-770, 808-811: swap while parent < child, strictly). The ancestors of the new leaf
  *  are non-decreasing towards the root, so the ones the new key overtakes form a prefix of the path: every lane reads
  *  one ancestor, a ballot finds the prefix length, the overtaken ancestors move one step down in parallel.
+ *
+ *  In two halves. The first only requests the ancestors and waits for nothing, so register-only work placed between the
+ *  halves (the insert into `top`) runs while the reads are in flight.
  */
-template <bool global_ak>
-UA_DEVICE void heap_push(cand_t* heap, std::uint32_t& size, float key, std::uint32_t slot) {
+struct push_ticket_t {
+    cand_t ancestor;
+    std::uint32_t leaf1; ///< 1-based index of the new leaf
+    bool has;            ///< this lane holds an ancestor
+};
+template <bool global_ak> UA_DEVICE push_ticket_t heap_push_begin(const cand_t* heap, std::uint32_t size) {
     using mem = scratch_gt<global_ak>;
     const std::uint32_t lane = lane_id();
-    const std::uint32_t leaf1 = size + 1;                     // 1-based index of the new leaf
-    const std::uint32_t depth = 31u - (std::uint32_t)__clz((int)leaf1); // number of ancestors
-    const bool has = lane >= 1 && lane <= depth;
-    cand_t ancestor = 0;
-    if (has)
-        ancestor = mem::load(heap + ((leaf1 >> lane) - 1));
-    const std::uint64_t overtaken = ballot(has && cand_distance(ancestor) < key);
+    push_ticket_t ticket;
+    ticket.leaf1 = size + 1;
+    const std::uint32_t depth = 31u - (std::uint32_t)__clz((int)ticket.leaf1); // number of ancestors
+    ticket.has = lane >= 1 && lane <= depth;
+    ticket.ancestor = 0;
+    if (ticket.has)
+        ticket.ancestor = mem::load(heap + ((ticket.leaf1 >> lane) - 1));
+    return ticket;
+}
+/// Second half of a push: how far the key rises, the overtaken ancestors move down, the key lands.
+template <bool global_ak>
+UA_DEVICE void heap_push_finish(cand_t* heap, std::uint32_t& size, const push_ticket_t& ticket, float key, std::uint32_t slot) {
+    using mem = scratch_gt<global_ak>;
+    const std::uint32_t lane = lane_id();
+    const std::uint64_t overtaken = ballot(ticket.has && cand_distance(ticket.ancestor) < key);
     const std::uint32_t rises = popcount64(overtaken);
-    if (has && lane <= rises)
-        mem::store(heap + ((leaf1 >> (lane - 1)) - 1), ancestor);
+    if (ticket.has && lane <= rises)
+        mem::store(heap + ((ticket.leaf1 >> (lane - 1)) - 1), ticket.ancestor);
     if (lane == 0)
-        mem::store(heap + ((leaf1 >> rises) - 1), make_cand(key, slot));
-    size = leaf1;
+        mem::store(heap + ((ticket.leaf1 >> rises) - 1), make_cand(key, slot));
+    size = ticket.leaf1;
     wave_sync<global_ak>();
+}
+template <bool global_ak>
+UA_DEVICE void heap_push(cand_t* heap, std::uint32_t& size, float key, std::uint32_t slot) {
+    const push_ticket_t ticket = heap_push_begin<global_ak>(heap, size);
+    heap_push_finish<global_ak>(heap, size, ticket, key, slot);
 }
 
 /**
@@ -1197,12 +1217,14 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                 ++diagnostic_pushes;
                 const std::uint64_t t0 = __builtin_amdgcn_s_memtime();
 #endif
-                heap_push<global_ak>(next, next_size, -d, successor);
+                // the frontier lives in LDS, `top` in registers: the insert runs while the push's reads are in flight
+                const push_ticket_t ticket = heap_push_begin<global_ak>(next, next_size);
 #ifdef USEARCH_AMD_PHASES
                 const std::uint64_t t1 = __builtin_amdgcn_s_memtime();
 #endif
                 if (allowed(successor))
                     top.insert(d, successor, ef, radius); // radius = top.top() once full
+                heap_push_finish<global_ak>(next, next_size, ticket, -d, successor);
 #ifdef USEARCH_AMD_PHASES
                 const std::uint64_t t2 = __builtin_amdgcn_s_memtime();
                 diagnostic_push_ticks += t1 - t0, diagnostic_insert_ticks += t2 - t1;
