@@ -29,7 +29,9 @@ def test_library_exports_every_declared_symbol():
 
 @pytest.mark.parametrize("source,target", [("f32", "f16"), ("f32", "i8"), ("f32", "b1"), ("f16", "f32"), ("f16", "i8"),
                                            ("i8", "f32"), ("i8", "f16"), ("b1", "f32"), ("b1", "i8"), ("f64", "f16"),
-                                           ("f64", "b1"), ("i8", "b1"), ("f32", "f32")])
+                                           ("f64", "b1"), ("i8", "b1"), ("f32", "f32"), ("f32", "bf16"), ("bf16", "f32"),
+                                           ("bf16", "i8"), ("i8", "bf16"), ("b1", "bf16"), ("bf16", "b1"), ("f64", "bf16"),
+                                           ("bf16", "f16"), ("f32", "f64"), ("i8", "f64"), ("bf16", "bf16")])
 def test_query_casts_match_oracle(source, target):
     import usearch_amd
     rng = np.random.default_rng(3)
@@ -38,6 +40,8 @@ def test_query_casts_match_oracle(source, target):
             vector = rng.integers(0, 256, ndim // 8, dtype=np.uint8)
         elif source == "i8":
             vector = rng.integers(-127, 128, ndim).astype(np.int8)
+        elif source == "bf16":  # brain floats travel as bit patterns: the upper halves of f32 values
+            vector = ((rng.standard_normal(ndim) * 3).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
         else:
             vector = (rng.standard_normal(ndim) * 3).astype({"f32": np.float32, "f16": np.float16, "f64": np.float64}[source])
         ours = usearch_amd.cast(vector, source, target, ndim)

@@ -42,7 +42,8 @@ def test_search_side_by_side(reference, metric, dtype, ndim, n, connectivity, k,
 
 def test_casts_side_by_side(reference):
     """Queries in a foreign scalar kind: the oracle's casts (index_plugins.hpp:1105-1224) must route like the reference's."""
-    for dtype, metric in (("f16", "cos"), ("i8", "cos"), ("b1", "hamming"), ("f32", "l2sq")):
+    for dtype, metric in (("f16", "cos"), ("i8", "cos"), ("b1", "hamming"), ("f32", "l2sq"), ("bf16", "cos"), ("f64", "l2sq"),
+                          ("b1", "tanimoto")):
         image, _, ref_index = util.build_image(1000, 64, metric, dtype, seed=8)
         for query_dtype in ("f32", "f16"):
             if query_dtype == dtype:
