@@ -97,3 +97,16 @@ def test_images_with_64_bit_matrix_dimensions():
                                                              expansion=meta["expansion"])
     assert np.array_equal(keys, data["keys"]) and util.same_float_bits(distances, data["distances"])
     assert np.array_equal(computed, data["computed"])
+
+
+@pytest.mark.parametrize("metric,dtype", [(m, d) for m in ("cos", "l2sq", "divergence", "pearson") for d in ("f32", "f16", "bf16", "i8")
+                                          if (m, d) != ("divergence", "i8")] + [(m, "b1") for m in ("hamming", "tanimoto", "sorensen")])
+def test_distance_to_itself_is_zero_and_to_another_is_not(metric, dtype):
+    """python/scripts/test_distances.py:61-109 (`test_distances_continuous`, `test_distances_sparse`): 1024 dimensions,
+    d(x, x) = 0 and d(x, y) != 0 at 1e-2, for every metric x quantization the reference's Python test sweeps."""
+    ndim = 1024
+    x, y = util.make_vectors(2, ndim, dtype, seed=7, clustered=False, metric=metric)
+    for lanes in (0, 8):
+        assert abs(oraclebind.distance(x, x, metric, dtype, ndim, lanes)) <= 1e-2
+        assert abs(oraclebind.distance(y, y, metric, dtype, ndim, lanes)) <= 1e-2
+        assert abs(oraclebind.distance(x, y, metric, dtype, ndim, lanes)) > 1e-2
