@@ -216,23 +216,27 @@ static double load_f64(const uint8_t* p, uint64_t i) { double d; memcpy(&d, p + 
  * reference lets the compiler reassociate (`omp simd reduction`), so last-bit agreement with one particular build of
  * it is neither promised nor needed.
  * lanes = G:  16-byte chunks dealt round-robin to G lanes, one fused chain per lane in chunk order, XOR butterfly. */
+enum { UO_AB, UO_A2, UO_B2, UO_L2, UO_SA, UO_SB, UO_KP, UO_KQ, UO_SUMS };
+
 #define UO_DEFINE_SUMS(NAME, T, FMA, LOG, EPSILON, LOAD_A, LOAD_B, PER_CHUNK)                                           \
-    typedef struct { T ab, a2, b2, l2, sa, sb, kp, kq; } NAME##_acc_t;                                                  \
+    typedef struct { T sum[UO_SUMS]; } NAME##_acc_t;                                                                    \
     static void NAME##_step(NAME##_acc_t* acc, T a, T b, int with_logs, int fused) {                                    \
+        T* s = acc->sum;                                                                                                \
         T t = a - b;                                                                                                    \
         if (fused) {                                                                                                    \
-            acc->ab = FMA(a, b, acc->ab), acc->a2 = FMA(a, a, acc->a2), acc->b2 = FMA(b, b, acc->b2);                   \
-            acc->l2 = FMA(t, t, acc->l2);                                                                               \
+            s[UO_AB] = FMA(a, b, s[UO_AB]), s[UO_A2] = FMA(a, a, s[UO_A2]), s[UO_B2] = FMA(b, b, s[UO_B2]);             \
+            s[UO_L2] = FMA(t, t, s[UO_L2]);                                                                             \
         } else {                                                                                                        \
-            acc->ab += a * b, acc->a2 += a * a, acc->b2 += b * b, acc->l2 += t * t;                                     \
+            s[UO_AB] += a * b, s[UO_A2] += a * a, s[UO_B2] += b * b, s[UO_L2] += t * t;                                 \
         }                                                                                                               \
-        acc->sa += a, acc->sb += b;                                                                                     \
+        s[UO_SA] += a, s[UO_SB] += b;                                                                                   \
         if (with_logs) {                                                                                                \
             T m = (a + b) / 2 + EPSILON;                                                                                \
-            acc->kp += a * LOG((a + EPSILON) / m);                                                                      \
-            acc->kq += b * LOG((b + EPSILON) / m);                                                                      \
+            s[UO_KP] += a * LOG((a + EPSILON) / m);                                                                     \
+            s[UO_KQ] += b * LOG((b + EPSILON) / m);                                                                     \
         }                                                                                                               \
     }                                                                                                                   \
+    /* XOR butterfly, offsets lanes/2 … 1: every lane ends with the same bit pattern (fp add is commutative). */        \
     static T NAME##_butterfly(T* v, int lanes) {                                                                        \
         T tmp[UO_MAX_LANES];                                                                                            \
         for (int off = lanes / 2; off >= 1; off >>= 1) {                                                                \
@@ -260,24 +264,24 @@ static double load_f64(const uint8_t* p, uint64_t i) { double d; memcpy(&d, p + 
             for (uint64_t i = c * per_chunk; i < (c + 1) * per_chunk && i < dims; ++i)                                  \
                 NAME##_step(&lane[c % (uint64_t)lanes], LOAD_A, LOAD_B, with_logs, 1);                                  \
         T v[UO_MAX_LANES];                                                                                              \
-        T* fields[8] = {&total.ab, &total.a2, &total.b2, &total.l2, &total.sa, &total.sb, &total.kp, &total.kq};        \
-        for (int f = 0; f < 8; ++f) {                                                                                   \
+        for (int f = 0; f < UO_SUMS; ++f) {                                                                             \
             for (int l = 0; l < lanes; ++l)                                                                             \
-                v[l] = *(T*)((uint8_t*)&lane[l] + ((uint8_t*)fields[f] - (uint8_t*)&total));                            \
-            *fields[f] = NAME##_butterfly(v, lanes);                                                                    \
+                v[l] = lane[l].sum[f];                                                                                  \
+            total.sum[f] = NAME##_butterfly(v, lanes);                                                                  \
         }                                                                                                               \
         return total;                                                                                                   \
     }                                                                                                                   \
     /* pearson: metric_pearson_gt 1478-1520 */                                                                          \
-    static T NAME##_pearson(const NAME##_acc_t* s, uint64_t dims) {                                                     \
+    static T NAME##_pearson(const NAME##_acc_t* acc, uint64_t dims) {                                                   \
+        const T* s = acc->sum;                                                                                          \
         if (dims <= 1)                                                                                                  \
             return 0;                                                                                                   \
         T n = (T)dims;                                                                                                  \
-        T denom = (n * s->a2 - s->sa * s->sa) * (n * s->b2 - s->sb * s->sb);                                            \
+        T denom = (n * s[UO_A2] - s[UO_SA] * s[UO_SA]) * (n * s[UO_B2] - s[UO_SB] * s[UO_SB]);                          \
         if (denom == 0)                                                                                                 \
             return 0;                                                                                                   \
-        T corr = n * s->ab - s->sa * s->sb;                                                                             \
-        return 1 - corr / (T)sqrt((double)denom);                                                                       \
+        T corr = n * s[UO_AB] - s[UO_SA] * s[UO_SB];                                                                    \
+        return 1 - corr / (T)sqrt((double)denom); /* sqrt in double then narrowed = the correctly rounded sqrtf */       \
     }
 
 #define UO_FLOAT_PER_CHUNK (UO_CHUNK / (uo_bytes_per_vector(scalar_kind, 8) / 8))
@@ -351,28 +355,28 @@ float uo_distance(uint8_t metric_kind, uint8_t scalar_kind, const void* av, cons
     if (scalar_kind == UO_SCALAR_F64) {
         f64_acc_t s = f64_sums(scalar_kind, a, b, dims, lanes, metric_kind == UO_METRIC_DIVERGENCE);
         switch (metric_kind) {
-        case UO_METRIC_IP: return (float)(1 - s.ab);
+        case UO_METRIC_IP: return (float)(1 - s.sum[UO_AB]);
         case UO_METRIC_COS:
-            if (s.a2 == 0 && s.b2 == 0) return 0.f;
-            if (s.a2 == 0 || s.b2 == 0) return 1.f;
-            return (float)(1 - s.ab / (sqrt(s.a2) * sqrt(s.b2)));
-        case UO_METRIC_L2SQ: return (float)s.l2;
+            if (s.sum[UO_A2] == 0 && s.sum[UO_B2] == 0) return 0.f;
+            if (s.sum[UO_A2] == 0 || s.sum[UO_B2] == 0) return 1.f;
+            return (float)(1 - s.sum[UO_AB] / (sqrt(s.sum[UO_A2]) * sqrt(s.sum[UO_B2])));
+        case UO_METRIC_L2SQ: return (float)s.sum[UO_L2];
         case UO_METRIC_PEARSON: return (float)f64_pearson(&s, dims);
-        case UO_METRIC_DIVERGENCE: return (float)((s.kp + s.kq) / 2);
+        case UO_METRIC_DIVERGENCE: return (float)((s.sum[UO_KP] + s.sum[UO_KQ]) / 2);
         default: return NAN;
         }
     }
     f32_acc_t s = f32_sums(scalar_kind, a, b, dims, lanes, metric_kind == UO_METRIC_DIVERGENCE);
     switch (metric_kind) {
-    case UO_METRIC_IP: return 1.f - s.ab; /* metric_ip_gt 1309-1326 */
+    case UO_METRIC_IP: return 1.f - s.sum[UO_AB]; /* metric_ip_gt 1309-1326 */
     case UO_METRIC_COS: {                 /* metric_cos_gt 1334-1359 */
-        if (s.a2 == 0.f && s.b2 == 0.f) return 0.f;
-        if (s.a2 == 0.f || s.b2 == 0.f) return 1.f;
-        return 1.f - s.ab / (sqrtf(s.a2) * sqrtf(s.b2));
+        if (s.sum[UO_A2] == 0.f && s.sum[UO_B2] == 0.f) return 0.f;
+        if (s.sum[UO_A2] == 0.f || s.sum[UO_B2] == 0.f) return 1.f;
+        return 1.f - s.sum[UO_AB] / (sqrtf(s.sum[UO_A2]) * sqrtf(s.sum[UO_B2]));
     }
-    case UO_METRIC_L2SQ: return s.l2; /* metric_l2sq_gt 1365-1385 */
+    case UO_METRIC_L2SQ: return s.sum[UO_L2]; /* metric_l2sq_gt 1365-1385 */
     case UO_METRIC_PEARSON: return f32_pearson(&s, dims);
-    case UO_METRIC_DIVERGENCE: return (s.kp + s.kq) / 2; /* metric_divergence_gt 1526-1551 */
+    case UO_METRIC_DIVERGENCE: return (s.sum[UO_KP] + s.sum[UO_KQ]) / 2; /* metric_divergence_gt 1526-1551 */
     default: return NAN;
     }
 }
