@@ -516,6 +516,12 @@ static int heap_reserve(heap_t* h, size_t n) {
 /* Sizing statistics of the last uo_search call on this thread (how big `next` and `visits` got): used by the
  * tests / DESIGN.md to size the device scratch, not part of the restated algorithm. */
 static __thread size_t stat_peak_next = 0, stat_visits = 0;
+/* Shape of the last traversal on this thread (design studies for the device kernel, not part of the restated algorithm):
+ * [0] hops on level 0, [1] hops whose node had been pushed during the hop right before (a "newcomer": the next hop was not
+ * the frontier's best at pop time), [2] candidates admitted (pushed), [3] fresh neighbours measured, [4] frontier size at the
+ * end, [5] of those, entries that could still be popped (distance <= radius), [6] sum over hops of the frontier size,
+ * [7] sum over hops of the frontier's live entries (sampled every 16th hop). */
+static __thread double stat_shape[8];
 size_t uo_last_peak_next(void) { return stat_peak_next; }
 size_t uo_last_visits(void) { return stat_visits; }
 
@@ -634,20 +640,35 @@ static void search_to_find_in_base(ctx_t* c, uint32_t start, size_t top_limit) {
         sorted_insert(&c->top, (cand_t){radius, start}, top_limit); /* insert_reserved ≡ insert when empty */
 
     uint32_t nbrs[4096];
+    memset(stat_shape, 0, sizeof(stat_shape));
+    size_t previous_hop_first_push = (size_t)-1, pushes = 0; /* telemetry only: pushes are numbered to tell newcomers */
+    uint32_t* pushed_at = (uint32_t*)calloc((size_t)c->ix->size + 1, sizeof(uint32_t));
     while (c->next.size) {
         cand_t candidate = c->next.e[0];
         if ((-candidate.distance) > radius && c->top.size == top_limit) /* 4210: strict `>` */
             break;
         heap_pop(&c->next);
         c->iteration_cycles++;
+        stat_shape[0] += 1;
+        if (pushed_at && previous_hop_first_push != (size_t)-1 && pushed_at[candidate.slot] > previous_hop_first_push)
+            stat_shape[1] += 1;
+        stat_shape[6] += (double)c->next.size;
+        if (((size_t)stat_shape[0] & 15) == 0)
+            for (size_t i = 0; i < c->next.size; ++i)
+                stat_shape[7] += (-c->next.e[i].distance) <= radius || c->top.size < top_limit;
+        previous_hop_first_push = pushes;
         uint32_t n = uo_neighbors(c->ix, candidate.slot, 0, nbrs, 4096);
         for (uint32_t i = 0; i < n; ++i) {
             uint32_t successor = nbrs[i];
             if (visits_set(&c->visits, successor)) /* 4229 */
                 continue;
             float d = measure(c, successor);
+            stat_shape[3] += 1;
             if (c->top.size < top_limit || d < radius) { /* 4233: strict `<` */
                 heap_insert(&c->next, (cand_t){-d, successor});
+                stat_shape[2] += 1;
+                if (pushed_at)
+                    pushed_at[successor] = (uint32_t)++pushes;
                 if (allow(c, successor)) {
                     sorted_insert(&c->top, (cand_t){d, successor}, top_limit);
                     radius = c->top.e[c->top.size - 1].distance; /* top.top() = last = worst kept (891) */
@@ -655,6 +676,10 @@ static void search_to_find_in_base(ctx_t* c, uint32_t start, size_t top_limit) {
             }
         }
     }
+    stat_shape[4] = (double)c->next.size;
+    for (size_t i = 0; i < c->next.size; ++i)
+        stat_shape[5] += (-c->next.e[i].distance) <= radius;
+    free(pushed_at);
 }
 
 static void search_exact(ctx_t* c, size_t count) {
@@ -782,6 +807,8 @@ void uo_cluster_many(const uo_index_t* ix, const void* queries, uint8_t query_ki
     free(casted);
     ctx_free(&c);
 }
+
+void uo_last_traversal_shape(double* out) { memcpy(out, stat_shape, sizeof(stat_shape)); }
 
 size_t uo_merge_into(uint64_t* keys, float* distances, size_t old_count, size_t max_count, const uint64_t* new_keys,
                      const float* new_distances, size_t new_count) {
