@@ -15,16 +15,23 @@ Default workload = the configuration BASELINE.json's metric is quoted on: 10M x 
 The seeded synthetic vectors are generated in HBM and the index is built ON THE GPU (`usearch_amd.build`, ≈20 s for 10M;
 `--builder reference` lets the reference build it on the host cores instead — minutes per million vectors, so only for
 small `--n`). The reference is handed the very same index (`save_buffer` → `usearch_view_buffer`) for the CPU baseline.
-With N > 1 every rank builds (deterministically, so identically) and holds a replica and searches its own batch (weak
-scaling, no collective on the data path). `--sharded` is the capacity mode: every rank builds and holds its own shard of
-`--n` vectors EACH (per-GPU work fixed as N grows = weak scaling of the index size), the batch is broadcast, every rank
-searches its shard, per-shard top-k are all-gathered over RCCL and merged (usearch_amd/sharded.py).
+`--gpus N` without a launcher re-executes itself under `torch.distributed.run` with N ranks (one per GPU); under a launcher
+(RANK / WORLD_SIZE in the environment) it is one of the ranks. With N > 1 every rank builds (deterministically, so
+identically) and holds a replica and searches its own batch: weak scaling, no collective on the data path, `value` = the
+queries all ranks answered per second. `--sharded` is the capacity mode for indexes beyond one GPU: every rank builds and
+holds its own shard of `--n` vectors EACH, the batch is broadcast, every rank searches its shard, per-shard top-k travel in
+ONE packed RCCL all-gather and are merged (`usearch_amd_sharded_search_many`, usearch_amd/csrc/sharded.hip). Per-GPU work
+is fixed as N grows (weak scaling of the index size): `value` = batch × shards ÷ time, "shard-queries/s" — the 1-GPU point
+is one shard searched by the same batch — and `config.queries_per_second` is the rate against the whole N-shard index
+(DESIGN.md §7).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
 import sys
 import time
 
@@ -118,6 +125,121 @@ def synthetic_vectors_device(count: int, dim: int, dtype: str, seed: int, device
     return out
 
 
+def source_hash() -> str:
+    """Names the product build: sha256 over the kernel / engine sources the library is compiled from. A `roofline.traffic`
+    measured by PMC passes is only attached to a line produced by the same sources (profiles/<round>/traffic.json)."""
+    digest = hashlib.sha256()
+    directory = os.path.join(ROOT, "usearch_amd", "csrc")
+    for name in sorted(os.listdir(directory)):
+        if name.endswith((".hip", ".hpp")):
+            digest.update(name.encode())
+            digest.update(open(os.path.join(directory, name), "rb").read())
+    return digest.hexdigest()[:16]
+
+
+def relaunch_with_ranks(gpus: int) -> None:
+    """`python bench.py --gpus N` on its own: become N ranks, one per GPU, under torch.distributed.run."""
+    with socket.socket() as probe:
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[bench] --gpus {gpus} without a launcher: " + " ".join(command))
+    os.execv(sys.executable, command)
+
+
+def recall_per_query(found: np.ndarray, truth: np.ndarray, k: int) -> np.ndarray:
+    return np.array([len(np.intersect1d(found[i], truth[i])) / k for i in range(len(found))], dtype=np.float64)
+
+
+def interval(values: np.ndarray):
+    """Mean and the half-width of its 95 % confidence interval."""
+    mean = float(np.mean(values))
+    half = 1.96 * float(np.std(values, ddof=1)) / np.sqrt(len(values)) if len(values) > 1 else 0.0
+    return mean, half
+
+
+def stress_rows(args, metric: str, device, local_rank: int, expansion: int) -> dict:
+    """The two secondary datasets SURVEY §8(d) wants next to the headline, on a smaller index (`--stress-n`): i.i.d.
+    Gaussian vectors (no neighbourhood structure at 768-d: the stress case of any graph index) and the reference's own
+    benchmark data, `eval.random_vectors` = uniform[0,1) with in-sample self-recall@1 (python/usearch/eval.py:55-62, 97-139)."""
+    import torch
+
+    import usearch_amd
+    rows = {}
+    row_bytes = int(args.dim * DTYPE_BYTES[args.dtype]) if args.dtype != "b1" else (args.dim + 7) // 8
+
+    def to_storage(x):
+        if args.dtype == "f32":
+            block = x
+        elif args.dtype == "f16":
+            block = x.to(torch.float16)
+        elif args.dtype == "f64":
+            block = x.to(torch.float64)
+        elif args.dtype == "bf16":
+            block = (x.contiguous().view(torch.int32) >> 16).to(torch.int16)
+        elif args.dtype == "i8":
+            block = torch.clamp(torch.round(x * 100.0 if float(x.min()) >= 0 else x * (127.0 / 4.0)), -127, 127).to(torch.int8)
+        else:
+            bits = (x > (0.5 if float(x.min()) >= 0 else 0.0)).to(torch.uint8)
+            if args.dim % 8:
+                bits = torch.nn.functional.pad(bits, (0, 8 - args.dim % 8))
+            weights = (2 ** torch.arange(7, -1, -1, device=device)).to(torch.uint8)
+            block = (bits.view(len(x), -1, 8) * weights).sum(dim=2).to(torch.uint8)
+        return block.contiguous().view(torch.uint8).view(len(x), row_bytes)
+
+    def generate(count: int, seed: int, uniform: bool):
+        generator = torch.Generator(device=device)
+        generator.manual_seed(seed)
+        out = torch.empty((count, row_bytes), dtype=torch.uint8, device=device)
+        for begin in range(0, count, 262144):
+            size = min(262144, count - begin)
+            x = (torch.rand if uniform else torch.randn)((size, args.dim), generator=generator, device=device)
+            out[begin:begin + size] = to_storage(x)
+        return out
+
+    n, q = args.stress_n, min(args.queries, 10_000)
+    for name, uniform in (("iid_gaussian", False), ("uniform_self_recall", True)):
+        t0 = time.time()
+        data = generate(n, 7 + int(uniform), uniform)
+        built = usearch_amd.build(None, metric, args.dtype, connectivity=args.connectivity, expansion_add=args.expansion_add,
+                                  device=local_rank, device_pointer=data.data_ptr(), count=n, stride=data.stride(0),
+                                  ndim=args.dim)
+        index = built.index
+        queries = data[:q].clone() if uniform else generate(q, 99, False)
+        del data
+        keys = torch.zeros((q, args.k), dtype=torch.int64, device=device)
+        distances = torch.zeros((q, args.k), dtype=torch.float32, device=device)
+        counters = [torch.zeros(q, dtype=torch.int64, device=device) for _ in range(3)]
+        stream = torch.cuda.Stream(device)
+
+        def run(ef: int, timed: bool):
+            return index.search_device(queries.data_ptr(), q, queries.stride(0), args.k, ef, keys.data_ptr(),
+                                       distances.data_ptr(), counters[0].data_ptr(), counters[1].data_ptr(),
+                                       counters[2].data_ptr(), stream=stream.cuda_stream, timed=timed)
+        row = {"vectors": n, "queries": q}
+        if uniform:  # the reference's self_recall: every member must find itself first, default expansion
+            run(64, False)
+            row["self_recall_at_1_ef64"] = float((keys[:, 0].cpu().numpy() == np.arange(q)).mean())
+            stats = run(64, True)
+            row["qps_ef64"] = q / (stats.kernel_ms / 1e3)
+        else:
+            sample = min(q, 1000)
+            host = queries[:sample].cpu().numpy().view(NUMPY_STORAGE[args.dtype])
+            truth = index.search(host, args.k, dtype=args.dtype, exact=True).keys
+            for ef in sorted({64, expansion}):
+                stats = run(ef, True)
+                found = keys[:sample].cpu().numpy().astype(np.uint64)
+                row[f"recall_at_{args.k}_ef{ef}"] = float(np.mean(recall_per_query(found, truth, args.k)))
+                row[f"qps_ef{ef}"] = q / (stats.kernel_ms / 1e3)
+        row["seconds"] = round(time.time() - t0, 1)
+        rows[name] = row
+        log(f"[bench] stress row {name}: {row}")
+        del built, index, queries
+        torch.cuda.empty_cache()
+    return rows
+
+
 def main() -> None:
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -130,21 +252,29 @@ def main() -> None:
     parser.add_argument("--queries", type=int, default=10_000)
     parser.add_argument("--k", type=int, default=10)
     parser.add_argument("--expansion", type=int, default=0,
-                        help="0 = smallest of the sweep (64 ... 1024) with recall@k >= 0.95")
+                        help="0 = smallest of the sweep (64 ... 1024) whose recall@k is >= 0.95 with 95 %% confidence")
     parser.add_argument("--connectivity", type=int, default=16)
     parser.add_argument("--expansion-add", type=int, default=128)
-    parser.add_argument("--recall-queries", type=int, default=1000)
+    parser.add_argument("--recall-queries", type=int, default=-1,
+                        help="queries with exact ground truth (-1 = the whole batch; sharded mode: 1000)")
     parser.add_argument("--cpu-seconds", type=float, default=12.0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-stress-rows", action="store_true")
+    parser.add_argument("--stress-n", type=int, default=1_000_000)
     parser.add_argument("--sharded", action="store_true")
+    parser.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
+                        help="sharded mode: native RCCL communicator (default) or torch.distributed collectives")
     parser.add_argument("--builder", default=os.environ.get("BENCH_BUILDER", "gpu"), choices=["gpu", "reference"],
                         help="who links the index: the device builder (default) or the reference on the host cores")
     parser.add_argument("--build-threads", type=int, default=int(os.environ.get("BENCH_BUILD_THREADS", 0)),
                         help="threads the reference uses to build the index (0 = 2 x the cgroup CPU quota)")
     parser.add_argument("--traffic-json", default=os.environ.get("BENCH_TRAFFIC_JSON", ""),
                         help="PMC-derived HBM bytes per launch of this workload (scripts/pmc_traffic.py), copied into "
-                             "roofline.traffic")
+                             "roofline.traffic when it was measured with the same sources")
+    parser.add_argument("--wave-clock", action="store_true", help="record the batch-tail telemetry of the timed steps")
     args = parser.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_with_ranks(args.gpus)
     metric = args.metric or ("hamming" if args.dtype == "b1" else "l2sq" if args.dtype == "i8" else "cos")
     cores = host_cores()
     if not args.build_threads:
@@ -166,7 +296,7 @@ def main() -> None:
 
     # ---- the index. Replicas: every rank builds the same seeded data (the device build is deterministic). Shards: rank r
     #      builds its own `--n` vectors with keys offset by r * n.
-    sharded = args.sharded and world > 1
+    sharded = args.sharded
     data_seed = 42 + (rank if sharded else 0)
     key_base = rank * args.n if sharded else 0
     build_seconds, build_stats, ref_index, image, built = 0.0, None, None, None, None
@@ -207,7 +337,7 @@ def main() -> None:
         log(f"[bench] snapshot: {len(index)} vectors, {index.memory_usage / 1e9:.2f} GB HBM, lanes/row {index.lanes_per_row}, "
             f"row stride {index.row_stride}, max level {index.max_level}")
 
-    # ---- queries: out-of-sample, seeded per rank; resident in HBM before the timed region
+    # ---- queries: out-of-sample, seeded per rank (shards: one batch for all); resident in HBM before the timed region
     queries_dev = synthetic_vectors_device(args.queries, args.dim, args.dtype, 43 if sharded else 43 + 1000 * rank, device)
     queries_host = queries_dev.cpu().numpy().view(NUMPY_STORAGE[args.dtype])
     keys_dev = torch.zeros((args.queries, args.k), dtype=torch.int64, device=device)
@@ -216,70 +346,100 @@ def main() -> None:
     visited_dev = torch.zeros(args.queries, dtype=torch.int64, device=device)
     computed_dev = torch.zeros(args.queries, dtype=torch.int64, device=device)
     stream = torch.cuda.Stream(device)
+    tuning = usearch_amd.Tuning(wave_clock=1) if args.wave_clock else None
 
-    sharded_searcher = None
+    sharded_searcher, exchange_ms = None, []
     if sharded:
         from usearch_amd.sharded import gpu_searcher
-        sharded_searcher = gpu_searcher(index, stream=stream.cuda_stream)
-        merged = {}
+        sharded_searcher = gpu_searcher(index, rank, world, local_rank, stream=stream.cuda_stream, prefer=args.transport)
+        if rank == 0:
+            log(f"[bench] sharded step over the '{sharded_searcher.communicator.kind}' transport, {world} shard(s)")
 
     def search_step(expansion: int, timed: bool):
         if sharded_searcher is not None:
-            # broadcast the batch → local search on this rank's shard → all-gather (RCCL) → merge kernel
-            merged["keys"], merged["distances"], merged["counts"] = sharded_searcher.search(queries_dev, args.k, expansion)
-            visited_dev.copy_(sharded_searcher.local_search.last_visited)
-            computed_dev.copy_(sharded_searcher.local_search.last_computed)
-            return usearch_amd.Stats(passes=1)
+            # ONE native call: broadcast → local search on this rank's shard → packed all-gather (RCCL) → merge kernel
+            *_, stats = sharded_searcher.search(queries_dev, args.k, expansion, broadcast_from=0, timed=timed, tuning=tuning,
+                                                out=(keys_dev, dist_dev, counts_dev, visited_dev, computed_dev))
+            if timed:
+                exchange_ms.append(sharded_searcher.last_step.exchange_ms)
+            return stats
         return index.search_device(queries_dev.data_ptr(), args.queries, queries_dev.stride(0), args.k, expansion,
                                    keys_dev.data_ptr(), dist_dev.data_ptr(), counts_dev.data_ptr(),
                                    visited_dev.data_ptr(), computed_dev.data_ptr(), stream=stream.cuda_stream,
-                                   timed=timed)
+                                   timed=timed, tuning=tuning)
 
     # ---- recall@k against EXACT search (the brute-force kernel, bit-checked against the reference's `exact = true` in
-    #      tests/test_gpu_exact.py) on a sample; pick the smallest ef of the sweep that reaches 0.95
-    recall, expansion = None, args.expansion
-    sample = min(args.recall_queries, args.queries)
-    if rank == 0 and not sharded and sample:
+    #      tests/test_gpu_exact.py). Replicas: on the whole batch. Shards: every rank scans its shard for a sample, the
+    #      per-shard truths are merged on rank 0 (distance ascending). The metric is quoted at the smallest expansion of the
+    #      sweep whose recall is >= 0.95 with 95 % confidence (lower end of the interval).
+    recall, recall_half, expansion = None, None, args.expansion
+    sample = args.queries if args.recall_queries < 0 else min(args.recall_queries, args.queries)
+    if sharded and args.recall_queries < 0:
+        sample = min(1000, args.queries)
+    by_distance = args.dtype in ("b1", "i8")
+    truth, truth_distances = None, None
+    if sample and (rank == 0 or sharded):
         t0 = time.time()
         exact = index.search(queries_host[:sample], args.k, dtype=args.dtype, exact=True)
         truth, truth_distances = exact.keys, exact.distances
-        # integer-valued metrics (Hamming, i8) tie massively: any result at least as close as the exact k-th neighbour is a
-        # correct one, whatever its key (the usual tie-aware recall); float metrics compare keys
-        by_distance = args.dtype in ("b1", "i8")
-        log(f"[bench] exact ground truth for {sample} queries in {time.time() - t0:.1f}s"
-            + (" (recall counted by distance: ties)" if by_distance else ""))
-        sweep = [args.expansion] if args.expansion else [64, 96, 128, 192, 256, 320, 384, 448, 512, 576, 640, 704, 768, 896, 1024]
+        if sharded and world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (truth, truth_distances))
+            all_keys = np.concatenate([g[0] for g in gathered], axis=1)
+            all_distances = np.concatenate([g[1] for g in gathered], axis=1)
+            order = np.argsort(np.nan_to_num(all_distances, nan=np.inf), axis=1, kind="stable")[:, :args.k]
+            truth = np.take_along_axis(all_keys, order, axis=1)
+            truth_distances = np.take_along_axis(all_distances, order, axis=1)
+        if rank == 0:
+            log(f"[bench] exact ground truth for {sample} queries in {time.time() - t0:.1f}s"
+                + (" (recall counted by distance: ties)" if by_distance else ""))
+    sweep = [args.expansion] if args.expansion else [64, 96, 128, 192, 256, 320, 384, 448, 512, 576, 640, 704, 768, 896, 1024]
 
-        def recall_at(ef: int) -> float:
-            search_step(ef, False)
-            found = keys_dev[:sample].cpu().numpy().astype(np.uint64)
-            if by_distance:
-                found_distances = dist_dev[:sample].cpu().numpy()
-                value = float(np.mean(found_distances <= truth_distances[:, -1:]))
-            else:
-                value = float(np.mean([len(np.intersect1d(found[i], truth[i])) / args.k for i in range(sample)]))
-            log(f"[bench] ef={ef}: recall@{args.k} = {value:.4f} on {sample} queries")
-            return value
+    def recall_at(ef: int):
+        """Every rank runs the step (shards: it is a collective); rank 0 scores it."""
+        search_step(ef, False)
+        if rank != 0 or not sample:
+            return None, None
+        found = keys_dev[:sample].cpu().numpy().astype(np.uint64)
+        if by_distance:
+            # integer-valued metrics (Hamming, i8) tie massively: any result at least as close as the exact k-th neighbour is
+            # a correct one, whatever its key (the usual tie-aware recall); float metrics compare keys
+            per_query = np.mean(dist_dev[:sample].cpu().numpy() <= truth_distances[:, -1:], axis=1)
+        else:
+            per_query = recall_per_query(found, truth, args.k)
+        mean, half = interval(per_query)
+        log(f"[bench] ef={ef}: recall@{args.k} = {mean:.4f} +- {half:.4f} on {sample} queries")
+        return mean, half
 
+    def agreed(flag: bool) -> bool:  # rank 0 decides, everybody follows (the sweep is made of collectives when sharded)
+        if world == 1:
+            return flag
+        box = torch.tensor([1 if flag else 0], device=device)
+        dist.broadcast(box, 0)
+        return bool(box.item())
+
+    if sample:
         below = 0
         for ef in sweep:
-            recall, expansion = recall_at(ef), ef
-            if recall >= 0.95:
+            mean, half = recall_at(ef)
+            recall, recall_half, expansion = mean, half, ef
+            if agreed(rank == 0 and mean - half >= 0.95):
                 break
             below = ef
         # the metric is quoted at the SMALLEST expansion that reaches the recall (SURVEY §8d): walk the gap between the last
         # grid point that missed it and the first that made it in steps of 16
-        if not args.expansion and recall >= 0.95 and below:
+        reached = agreed(rank == 0 and recall is not None and recall - recall_half >= 0.95)
+        if not args.expansion and reached and below:
             for ef in range(below + 16, expansion, 16):
-                finer = recall_at(ef)
-                if finer >= 0.95:
-                    recall, expansion = finer, ef
+                mean, half = recall_at(ef)
+                if agreed(rank == 0 and mean - half >= 0.95):
+                    recall, recall_half, expansion = mean, half, ef
                     break
     if world > 1:
         chosen = torch.tensor([expansion or 64], device=device)
         dist.broadcast(chosen, 0)
         expansion = int(chosen.item())
-    expansion = expansion or (256 if sharded else 64)
+    expansion = expansion or 64
 
     # ---- warmup, then EXACTLY `steps` timed steps between barriers
     for _ in range(args.warmup):
@@ -287,12 +447,13 @@ def main() -> None:
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    kernel_ms, passes = [], 0
+    kernel_ms, passes, tails = [], 0, []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stats = search_step(expansion, True)
         kernel_ms.append(stats.kernel_ms)
         passes = max(passes, stats.passes)
+        tails.append(stats.tail_idle)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -310,18 +471,31 @@ def main() -> None:
     step_bytes = float(np.sum(computed * bpv + visited * 4 * m0 + args.k * 8 + bpv))
     kernel_s = float(np.mean(kernel_ms)) / 1e3
     achieved = step_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    # lines touched: what the same accesses cost in whole 128-byte lines (short rows: a 96-byte row is one line, a 16-byte
+    # row still one) — the bound that applies when rows are shorter than a line
+    row_lines = -(-index.row_stride // 128) if index.row_stride >= 128 else 1
+    touched_bytes = float(np.sum(computed * row_lines * 128 + visited * 128 * -(-4 * m0 // 128) + 128 + row_lines * 128))
 
     # ---- the same batch through the HOST-buffer entry point (query upload + result download over PCIe included):
     #      reported for DESIGN.md, never as `value`
-    host_api_qps = None
-    if rank == 0 and world == 1:
+    host_api_qps, single_query_us = None, None
+    if rank == 0 and world == 1 and not sharded:
         index.expansion_search = expansion
         index.search(queries_host, args.k, dtype=args.dtype)
         t1 = time.perf_counter()
         index.search(queries_host, args.k, dtype=args.dtype)
         host_api_qps = args.queries / (time.perf_counter() - t1)
+        # one query at a time, as a `usearch_search` loop would issue them (latency, not throughput)
+        for i in range(8):
+            index.search(queries_host[i], args.k, dtype=args.dtype)
+        t1 = time.perf_counter()
+        for i in range(64):
+            index.search(queries_host[i], args.k, dtype=args.dtype)
+        single_query_us = (time.perf_counter() - t1) / 64 * 1e6
 
-    # ---- the reference on the host cores, same index, same queries, same ef (rank 0, N = 1 only)
+    # ---- the reference on the host cores, same index, same queries, same ef (rank 0, N = 1 only). In sharded mode that is
+    #      the reference's own `Indexes` shape over this one shard: search, then `merge_into` — which for a single shard is
+    #      the search itself.
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import refbind
@@ -341,35 +515,46 @@ def main() -> None:
         rkeys, *_ = ref_index.search(queries_host[:sample_q], args.k, dtype=args.dtype, threads=threads)
         cpu_seconds = time.perf_counter() - t1
         agree = float(np.mean(keys_dev[:sample_q].cpu().numpy().astype(np.uint64) == rkeys))
-        cpu = {"value": sample_q / cpu_seconds, "unit": "queries/s", "cores": threads, "kind": "reference",
+        cpu = {"value": sample_q / cpu_seconds, "unit": "shard-queries/s" if sharded else "queries/s", "cores": threads,
+               "kind": "reference",
                "sample": f"{sample_q} of the step's {args.queries} queries, same index, same ef={expansion}, "
                          f"OpenMP static,32 loop of cpp/bench.cpp:352-377; serial (auto-vectorised) metrics, SimSIMD "
                          f"unavailable offline; {cpu_seconds:.1f}s; label agreement with the GPU {agree:.4f}"}
+        del ref_index, image
+
+    stress = None
+    if rank == 0 and world == 1 and not sharded and not args.no_stress_rows:
+        del built
+        torch.cuda.empty_cache()
+        stress = stress_rows(args, metric, device, local_rank, expansion)
 
     if rank == 0:
         workload = (f"{args.n}x{args.dim} {args.dtype} {metric}, batch {args.queries}, k={args.k}, "
                     f"M={args.connectivity}, ef_construction={args.expansion_add}, ef={expansion}")
         # roofline.traffic: HBM bytes per launch from rocprofv3 PMC passes (separate runs by necessity — scripts/profile_round.sh,
-        # scripts/pmc_traffic.py). Either handed in (--traffic-json), or the committed measurement of this very workload.
+        # scripts/pmc_traffic.py). Attached only when it was measured on this very workload with the very sources this line's
+        # library is built from; anything else stays null.
+        sources = source_hash()
         traffic, traffic_source = None, None
-        if args.traffic_json and os.path.exists(args.traffic_json):
-            traffic, traffic_source = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch"), args.traffic_json
-        else:
-            for directory in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-                candidate = os.path.join(ROOT, "profiles", directory, "bench.json")
-                try:
-                    recorded = json.load(open(candidate))
-                except (OSError, ValueError):
-                    continue
-                if recorded.get("config", {}).get("workload") == workload and recorded.get("roofline", {}).get("traffic"):
-                    traffic, traffic_source = recorded["roofline"]["traffic"], f"profiles/{directory}/traffic.json (PMC passes of the same workload)"
-                    break
-        total_queries = args.queries * args.steps * (1 if sharded else world)
-        total_vectors = args.n * (world if sharded else 1)
+        candidates = [args.traffic_json] if args.traffic_json else []
+        candidates += [os.path.join(ROOT, "profiles", d, "traffic.json") for d in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True)]
+        for candidate in candidates:
+            try:
+                recorded = json.load(open(candidate))
+            except (OSError, ValueError):
+                continue
+            if recorded.get("workload") == workload and recorded.get("sources") == sources and recorded.get("hbm_bytes_per_launch"):
+                traffic = recorded["hbm_bytes_per_launch"]
+                traffic_source = os.path.relpath(candidate, ROOT) + " (PMC passes of this workload, same sources)"
+                break
+        shards = world if sharded else 1
+        replicas = 1 if sharded else world
+        queries_per_second = args.queries * args.steps * replicas / elapsed  # against the whole index
         line = {
-            "metric": f"QPS at recall@{args.k}>=0.95, {args.n}x{args.dim} {args.dtype} {metric}, batch={args.queries}",
-            "value": total_queries / elapsed,
-            "unit": "queries/s",
+            "metric": f"QPS at recall@{args.k}>=0.95, {args.n * shards}x{args.dim} {args.dtype} {metric}, batch={args.queries}"
+                      + (f", {shards} shard(s) of {args.n}" if sharded else ""),
+            "value": queries_per_second * shards,
+            "unit": "shard-queries/s" if sharded else "queries/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -380,17 +565,35 @@ def main() -> None:
             "dtype": args.dtype,
             "data": "synthetic (seeded rank-32 latent + 0.05 noise, out-of-sample queries)",
             "config": {"workload": workload,
-                       "vectors": total_vectors, "dimensions": args.dim, "expansion_search": expansion,
-                       "recall_at_k": recall, "parallelism": ("shards" if sharded else "replicas") + str(world),
+                       "vectors": args.n * shards, "dimensions": args.dim, "expansion_search": expansion,
+                       "recall_at_k": recall, "recall_queries": sample, "recall_ci": [recall - recall_half, recall + recall_half]
+                       if recall is not None else None,
+                       "parallelism": ("shards" if sharded else "replicas") + str(world),
+                       "queries_per_second": queries_per_second,
+                       "scaling_definition": ("weak: every GPU holds one shard of --n vectors and searches the whole batch; value = "
+                                              "batch x shards / time (shard-queries/s), the 1-GPU point is one shard; "
+                                              "queries_per_second is the rate against the whole index") if sharded else
+                                             "weak: every GPU holds a replica and searches its own batch; value = all batches / time",
+                       "exchange": ({"transport": sharded_searcher.communicator.kind,
+                                     "block_bytes": int(sharded_searcher.last_step.block_bytes),
+                                     "gathered_bytes": int(sharded_searcher.last_step.gathered_bytes),
+                                     "exchange_ms": float(np.mean(exchange_ms)) if exchange_ms else None,
+                                     "exchanges_per_step": int(sharded_searcher.last_step.exchanges)} if sharded else None),
                        "index_builder": args.builder, "index_build_seconds": round(build_seconds, 1),
                        "index_build": build_stats, "kernel_passes": passes,
                        "scratch_mode": {1: "lds", 2: "global-hash", 3: "global"}.get(stats.mode, "?"),
+                       "frontier": {1: "heap", 2: "in-top"}.get(stats.frontier, "?"), "kernel_build": stats.variant,
                        "persistent_waves": stats.grid, "lds_bytes_per_wave": stats.lds_bytes,
-                       "host_buffer_api_qps_pcie_inclusive": host_api_qps},
+                       "batch_tail_idle": float(np.mean(tails)) if args.wave_clock else None,
+                       "host_buffer_api_qps_pcie_inclusive": host_api_qps,
+                       "single_query_latency_us_host_api": single_query_us,
+                       "sources": sources, "stress_rows": stress},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "search_kernel", "kernel_ms": kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": step_bytes,
+                         "lines_touched_bytes_per_launch": touched_bytes,
+                         "lines_touched_frac": touched_bytes / kernel_s / 1e9 / HBM_PEAK_GBPS if kernel_s > 0 else None,
                          "distances_per_query": float(np.mean(computed)), "hops_per_query": float(np.mean(visited))},
             "cpu_baseline": cpu,
         }

@@ -46,13 +46,21 @@ enum {
 
 /** Optional knobs of one batched search; zero-initialise for the defaults. */
 typedef struct usearch_amd_tuning_t {
-    uint32_t hash_cap;     /**< visited-set cells per query (power of two); 0 = 48 × expansion */
-    uint32_t next_cap;     /**< frontier capacity per query; 0 = 4 × expansion */
+    uint32_t hash_cap;     /**< visited-set cells per query (power of two); 0 = (30 × expansion + 1600) / 0.75, rounded up */
+    uint32_t next_cap;     /**< frontier heap capacity per query; 0 = 3 × expansion + 256 */
     uint32_t variant;      /**< kernel build: 0 = auto, 1 = 4 row loads in flight per lane (≤128 VGPRs, 16 waves/CU), 2 = 8 loads
-                                (≤168 VGPRs, 12 waves/CU), 3 = 12 loads (≤256 VGPRs, 8 waves/CU) */
+                                (≤168 VGPRs, 12 waves/CU), 3 = 12 loads (≤256 VGPRs, 8 waves/CU); for the in-`top` frontier also
+                                4 = 12 loads under 168 VGPRs, 5 = 8 loads under 128 VGPRs */
     uint32_t mode;         /**< scratch placement: 0 = auto, 1 = visited set in LDS, 2 = visited set in a per-wave global
                                 hash (heaps stay in LDS), 3 = everything in global memory with exact sizes (slow) */
     uint32_t waves_per_cu; /**< persistent waves per compute unit; 0 = as many as LDS and registers admit (≤ 16) */
+    uint32_t frontier;     /**< who holds the traversal's frontier: 0 = auto, 1 = the reference's binary heap (index.hpp:664-835;
+                                its pop order among EQUAL distances), 2 = the not-yet-expanded cells of `top` (no heap at all:
+                                same hops, counters and results whenever the distances meeting in the frontier are distinct;
+                                float-valued pairs, expansion ≤ 1024, no predicate / tombstones — refused otherwise).
+                                Auto = 2 where it applies, else 1. DESIGN.md §3.1 */
+    uint32_t wave_clock;   /**< 1 = record when every persistent wave started and left (fills stats.tail_idle / span_ms) */
+    uint32_t reserved;
 } usearch_amd_tuning_t;
 
 /** What a batched search did, for profiling and tests. */
@@ -61,9 +69,14 @@ typedef struct usearch_amd_stats_t {
     uint32_t retried_lds;    /**< queries rerun with enlarged LDS scratch */
     uint32_t retried_global; /**< queries rerun with global-memory scratch */
     float kernel_ms;         /**< HIP-event duration of the search launches (device entry point with timing only) */
-    uint32_t mode;           /**< scratch placement of the last launch (values of usearch_amd_tuning_t::mode) */
-    uint32_t grid;           /**< persistent waves of the last launch */
-    uint32_t lds_bytes;      /**< LDS bytes per wave of the last launch */
+    uint32_t mode;           /**< scratch placement of the first launch (values of usearch_amd_tuning_t::mode) */
+    uint32_t grid;           /**< persistent waves of the first launch */
+    uint32_t lds_bytes;      /**< LDS bytes per wave of the first launch */
+    uint32_t frontier;       /**< frontier of the first launch (values of usearch_amd_tuning_t::frontier) */
+    uint32_t variant;        /**< kernel build of the first launch (values of usearch_amd_tuning_t::variant) */
+    float tail_idle;         /**< with wave_clock: share of (waves × span) during which waves were not there — batch tail */
+    float span_ms;           /**< with wave_clock: first wave start → last wave exit, device wall clock */
+    uint32_t reserved;
 } usearch_amd_stats_t;
 
 /** Number of visible HIP devices; 0 (and an error) when the runtime finds none. */
@@ -167,6 +180,70 @@ USEARCH_AMD_EXPORT void usearch_amd_exact_search_dataset(void const* dataset, si
                                                          usearch_amd_key_t* keys, size_t keys_stride,
                                                          usearch_amd_distance_t* distances, size_t distances_stride,
                                                          usearch_amd_error_t* error);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ *  Sharded search across the GPUs of one node — one process per GPU, one shard (its own HNSW) per process.
+ *  Replaces the reference's `Indexes` (python/usearch/index.py:1473-1514 → python/lib.cpp:321-402: every sub-index searches
+ *  every query, per-query results folded with `search_result_t::merge_into`, index.hpp:2650-2670).
+ * ---------------------------------------------------------------------------------------------------------------- */
+
+typedef void* usearch_amd_comm_t;
+
+/** Collectives supplied by the caller (MPI, gloo, …) instead of RCCL. Every callback returns NULL or an error message. */
+typedef struct usearch_amd_transport_t {
+    void* context;
+    /** every rank contributes `bytes` bytes at `send` and receives world × `bytes` at `receive`, in rank order */
+    char const* (*all_gather)(void* context, void const* send, void* receive, size_t bytes, void* stream);
+    /** optional: `buffer` of rank `root` to every rank */
+    char const* (*broadcast)(void* context, void* buffer, size_t bytes, int root, void* stream);
+    int buffers_on_host; /**< 0 = callbacks take device pointers and a hipStream_t; 1 = host pointers (stream is NULL) */
+    /** optional stand-in for the device search: when set, the whole step (search, packing, exchange, merge) runs in host
+     *  memory and no HIP call is made — the protocol on machines without a GPU */
+    char const* (*local_search)(void* context, void const* queries, size_t queries_count, size_t queries_stride,
+                                size_t wanted, size_t expansion, usearch_amd_key_t* keys, usearch_amd_distance_t* distances,
+                                uint64_t* counts);
+} usearch_amd_transport_t;
+
+typedef struct usearch_amd_sharded_stats_t {
+    uint64_t block_bytes;    /**< bytes this rank contributes to the all-gather: Q·k·12 + Q·8 + 8 */
+    uint64_t gathered_bytes; /**< bytes it receives (world × block) */
+    float exchange_ms;       /**< all-gather + merge kernel on the stream (HIP events, with `timed`) */
+    uint32_t exchanges;      /**< 1; 2 when some rank's scratch retry ladder ran and the blocks were exchanged again */
+} usearch_amd_sharded_stats_t;
+
+/** 128 bytes that name a new RCCL communicator (`ncclGetUniqueId`): rank 0 makes them, the launcher carries them over. */
+USEARCH_AMD_EXPORT void usearch_amd_comm_unique_id(void* out_128_bytes, usearch_amd_error_t* error);
+/** RCCL communicator over xGMI for this rank's `device` (`ncclCommInitRank`; every rank must call it). */
+USEARCH_AMD_EXPORT usearch_amd_comm_t usearch_amd_comm_init_rccl(void const* unique_id_128_bytes, int rank, int world,
+                                                                 int device, usearch_amd_error_t* error);
+/** Communicator over the caller's collectives. */
+USEARCH_AMD_EXPORT usearch_amd_comm_t usearch_amd_comm_init_custom(usearch_amd_transport_t const* transport, int rank,
+                                                                   int world, int device, usearch_amd_error_t* error);
+USEARCH_AMD_EXPORT void usearch_amd_comm_free(usearch_amd_comm_t comm);
+USEARCH_AMD_EXPORT int usearch_amd_comm_rank(usearch_amd_comm_t comm);
+USEARCH_AMD_EXPORT int usearch_amd_comm_world(usearch_amd_comm_t comm);
+/** `buffer` (device memory) of rank `root` to every rank, on `stream`. */
+USEARCH_AMD_EXPORT void usearch_amd_comm_broadcast(usearch_amd_comm_t comm, void* buffer, size_t bytes, int root,
+                                                   void* stream, usearch_amd_error_t* error);
+
+/**
+ *  ONE STEP of sharded search, on every rank: [broadcast the batch from `broadcast_root`, -1 = every rank already holds
+ *  it] → search `snapshot` (this rank's shard; results go straight into the send block) → ONE all-gather of the packed
+ *  block {distances | keys | counts} → merge kernel with the `merge_into` tie rule, shards taken in rank order. All of it
+ *  on `stream` (NULL = the snapshot's own) with a single wait at the end. Device buffers; queries in the storage kind.
+ *  keys / distances / counts receive the merged result (identical on every rank); visited / computed this rank's own
+ *  traversal counters. With a transport that carries `local_search`, every buffer is host memory and `snapshot` may be
+ *  NULL. Replaces `Indexes.search` (python/lib.cpp:321-402).
+ */
+USEARCH_AMD_EXPORT void usearch_amd_sharded_search_many(usearch_amd_snapshot_t snapshot, usearch_amd_comm_t comm,
+                                                        void* queries, size_t queries_count, size_t queries_stride,
+                                                        size_t wanted, size_t expansion, int broadcast_root,
+                                                        usearch_amd_key_t* keys, usearch_amd_distance_t* distances,
+                                                        uint64_t* counts, uint64_t* visited, uint64_t* computed,
+                                                        void* stream, usearch_amd_tuning_t const* tuning, int timed,
+                                                        usearch_amd_stats_t* stats,
+                                                        usearch_amd_sharded_stats_t* sharded_stats,
+                                                        usearch_amd_error_t* error);
 
 /**
  *  Exchange step of SHARDED search: merges per-shard results `distances/keys[shards][queries][wanted]`,

@@ -76,6 +76,7 @@ def lib() -> C.CDLL:
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.uo_cluster_many.argtypes = [C.POINTER(_Index), C.c_void_p, C.c_uint8, C.c_size_t, C.c_size_t, C.c_size_t,
                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.uo_set_frontier_in_top.argtypes = [C.c_int]
         L.uo_merge_into.restype = C.c_size_t
         L.uo_merge_into.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
                                     C.c_size_t]
@@ -132,8 +133,10 @@ class OracleIndex:
         return int(lib().uo_level(C.byref(self.ix), slot))
 
     def search(self, queries: np.ndarray, k: int, dtype: Optional[str] = None, expansion: int = 64,
-               exact: bool = False, lanes: int = 0):
-        """→ (keys[Q,k], distances[Q,k], counts[Q], visited[Q], computed[Q]) like RefIndex.search."""
+               exact: bool = False, lanes: int = 0, frontier_in_top: bool = False):
+        """→ (keys[Q,k], distances[Q,k], counts[Q], visited[Q], computed[Q]) like RefIndex.search.
+        `frontier_in_top`: the device kernels' heap-less frontier (applied where the engine applies it, `uo_set_frontier_in_top`);
+        the default is the reference's heap."""
         dtype = dtype or self.dtype
         queries = np.ascontiguousarray(queries)
         if queries.ndim == 1:
@@ -145,9 +148,13 @@ class OracleIndex:
         visited = np.zeros(q, dtype=np.uint64)
         computed = np.zeros(q, dtype=np.uint64)
         if q:
-            lib().uo_search_many(C.byref(self.ix), _ptr(queries), SCALAR[dtype], q, queries.strides[0], k, expansion,
-                                 int(exact), lanes, _ptr(keys), _ptr(dists), _ptr(counts), _ptr(visited),
-                                 _ptr(computed))
+            lib().uo_set_frontier_in_top(int(frontier_in_top))
+            try:
+                lib().uo_search_many(C.byref(self.ix), _ptr(queries), SCALAR[dtype], q, queries.strides[0], k, expansion,
+                                     int(exact), lanes, _ptr(keys), _ptr(dists), _ptr(counts), _ptr(visited),
+                                     _ptr(computed))
+            finally:
+                lib().uo_set_frontier_in_top(0)
         return keys, dists, counts, visited, computed
 
     def cluster(self, queries: np.ndarray, level: int, dtype: Optional[str] = None, lanes: int = 0):

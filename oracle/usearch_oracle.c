@@ -593,6 +593,7 @@ typedef struct {
     sorted_t top;
     heap_t next;
     visits_t visits;
+    int has_tombstones; /* any key == free_key_ (only looked up when the in-`top` frontier mode is requested) */
 } ctx_t;
 
 static float measure(ctx_t* c, uint32_t slot) {
@@ -628,8 +629,70 @@ static uint32_t search_for_one(ctx_t* c, uint32_t closest, int begin_level, int 
     return closest;
 }
 
+/* The frontier mode of the device kernels (usearch_amd/csrc/kernels.hpp, frontier_top_k), restated so that the GPU can be
+ * checked bit for bit in it: there is no `next` container; the frontier is the not-yet-expanded part of `top` (bit 31 of a
+ * kept candidate's slot says "expanded"). A candidate enters `next` and `top` together (index.hpp:4233-4240) and what `top`
+ * evicts is farther than the radius for good, so the reference's loop only ever expands members still in `top`: same hops,
+ * same counters, same results whenever the distances that meet in the frontier are distinct (tests/test_oracle_frontier.py
+ * checks this mode against the reference-shaped one and documents the tie cases). Valid only when every member is a result
+ * candidate (no predicate, no tombstones) and slots stay below 2^31 — the caller checks, as the engine does. */
+#define UO_CLOSED 0x80000000u
+static __thread int frontier_in_top_requested = 0;
+void uo_set_frontier_in_top(int enabled) { frontier_in_top_requested = enabled; }
+
+static void search_to_find_in_base_frontier_in_top(ctx_t* c, uint32_t start, size_t top_limit) {
+    visits_clear(&c->visits);
+    c->next.size = 0;
+    c->top.size = 0;
+    float radius = measure(c, start);
+    visits_set(&c->visits, start);
+    sorted_insert(&c->top, (cand_t){radius, start}, top_limit);
+    uint32_t nbrs[4096];
+    memset(stat_shape, 0, sizeof(stat_shape));
+    for (;;) {
+        size_t first_open = 0;
+        while (first_open < c->top.size && (c->top.e[first_open].slot & UO_CLOSED))
+            ++first_open;
+        if (first_open == c->top.size)
+            break;
+        uint32_t expanded = c->top.e[first_open].slot;
+        c->top.e[first_open].slot |= UO_CLOSED;
+        c->iteration_cycles++;
+        stat_shape[0] += 1;
+        uint32_t n = uo_neighbors(c->ix, expanded, 0, nbrs, 4096);
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t successor = nbrs[i];
+            if (visits_set(&c->visits, successor))
+                continue;
+            float d = measure(c, successor);
+            stat_shape[3] += 1;
+            if (c->top.size < top_limit || d < radius) {
+                sorted_insert(&c->top, (cand_t){d, successor}, top_limit);
+                radius = c->top.e[c->top.size - 1].distance;
+                stat_shape[2] += 1;
+            }
+        }
+    }
+    for (size_t i = 0; i < c->top.size; ++i)
+        c->top.e[i].slot &= ~UO_CLOSED;
+}
+
+static int frontier_in_top_applies(const ctx_t* c, size_t top_limit) {
+    /* the engine's rule (usearch_amd/csrc/engine.hip, search_begin): float-valued pair, `top` in registers (expansion
+     * <= 1024), no predicate, no tombstones, slots < 2^31 */
+    if (!frontier_in_top_requested || c->filter || top_limit > 1024 || c->ix->size >= 0x80000000ull)
+        return 0;
+    if (c->ix->scalar_kind == UO_SCALAR_B1 || c->ix->scalar_kind == UO_SCALAR_I8)
+        return 0;
+    return !c->has_tombstones;
+}
+
 static void search_to_find_in_base(ctx_t* c, uint32_t start, size_t top_limit) {
     /* index.hpp:4176-4246 */
+    if (frontier_in_top_applies(c, top_limit)) {
+        search_to_find_in_base_frontier_in_top(c, start, top_limit);
+        return;
+    }
     visits_clear(&c->visits);
     c->next.size = 0;
     c->top.size = 0;
@@ -746,6 +809,9 @@ static int ctx_init(ctx_t* c, const uo_index_t* ix, int lanes, uo_filter_t filte
     memset(c, 0, sizeof(*c));
     c->ix = ix, c->lanes = lanes, c->filter = filter, c->filter_state = state;
     c->visits.bits = (uint8_t*)calloc((size_t)(ix->size / 8 + 1), 1);
+    if (frontier_in_top_requested)
+        for (uint64_t i = 0; i < ix->size && !c->has_tombstones; ++i)
+            c->has_tombstones = uo_key(ix, i) == UINT64_MAX;
     return c->visits.bits != NULL;
 }
 

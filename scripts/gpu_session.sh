@@ -1,0 +1,29 @@
+#!/bin/bash
+# scripts/gpu_session.sh <tag> <step>… — one GPU-box session made of named steps, every step under its own timeout, logs under
+# gpurun_out/<tag>/. Steps: tests | sweep10m | bench | sharded1 | c4small | c5small | profile (see the case arms).
+set -u
+TAG=$1; shift 1
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd "$REPO"
+for step in "$@"; do
+  echo "=== $step $(date +%T)"
+  case $step in
+    tests)    timeout 900 python -m pytest tests -m gpu -x -q > "$OUT/pytest.log" 2>&1; tail -15 "$OUT/pytest.log" ;;
+    sweep10m) timeout 600 python scripts/sweep.py --n 10000000 --ef 592 256 --modes 2 --waves 0 --variants 1 2 3 4 5 \
+                --frontiers 1 2 --steps 3 > "$OUT/sweep10m.log" 2>&1; cat "$OUT/sweep10m.log" ;;
+    sweepwaves) timeout 600 python scripts/sweep.py --n 10000000 --ef 592 --modes 2 --waves 8 12 16 --variants 1 2 3 4 5 \
+                --frontiers 2 --steps 3 > "$OUT/sweepwaves.log" 2>&1; cat "$OUT/sweepwaves.log" ;;
+    bench)    timeout 900 python bench.py --steps 20 --warmup 5 --wave-clock > "$OUT/bench.json" 2> "$OUT/bench.log"; tail -25 "$OUT/bench.log"; cat "$OUT/bench.json" ;;
+    sharded1) timeout 600 python bench.py --sharded --n 2000000 --dim 128 --dtype b1 --queries 100000 --steps 5 --warmup 2 \
+                > "$OUT/sharded1.json" 2> "$OUT/sharded1.log"; tail -12 "$OUT/sharded1.log"; cat "$OUT/sharded1.json" ;;
+    c4small)  timeout 600 python bench.py --n 20000000 --dim 96 --dtype i8 --queries 100000 --no-stress-rows --cpu-seconds 4 \
+                > "$OUT/c4small.json" 2> "$OUT/c4small.log"; tail -8 "$OUT/c4small.log"; cat "$OUT/c4small.json" ;;
+    c5small)  timeout 600 python bench.py --n 20000000 --dim 128 --dtype b1 --queries 100000 --no-stress-rows --cpu-seconds 4 \
+                > "$OUT/c5small.json" 2> "$OUT/c5small.log"; tail -8 "$OUT/c5small.log"; cat "$OUT/c5small.json" ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
+echo "=== done $(date +%T)"

@@ -31,6 +31,8 @@ def main():
     p.add_argument("--modes", type=int, nargs="+", default=[1, 2])
     p.add_argument("--waves", type=int, nargs="+", default=[0])
     p.add_argument("--variants", type=int, nargs="+", default=[0])
+    p.add_argument("--frontiers", type=int, nargs="+", default=[0], help="0 = auto, 1 = reference heap, 2 = open cells of top")
+    p.add_argument("--n-queries-check", type=int, default=0, help="also compare distances / counters across settings")
     p.add_argument("--cache-dir", default="/dev/shm")
     p.add_argument("--gather", action="store_true")
     p.add_argument("--build-threads", type=int, default=0)
@@ -84,26 +86,35 @@ def main():
         for mode in args.modes:
             for waves in args.waves:
                 for variant in args.variants:
-                    tuning = usearch_amd.Tuning(mode=mode, waves_per_cu=waves, variant=variant)
+                  for frontier in args.frontiers:
+                    tuning = usearch_amd.Tuning(mode=mode, waves_per_cu=waves, variant=variant, frontier=frontier, wave_clock=1)
                     ms = []
-                    for step in range(args.steps + 1):
-                        stats = index.search_device(queries.data_ptr(), args.queries, queries.stride(0), args.k, ef,
-                                                    keys.data_ptr(), dists.data_ptr(), counts.data_ptr(),
-                                                    visited.data_ptr(), computed.data_ptr(), timed=True, tuning=tuning)
-                        if step:
-                            ms.append(stats.kernel_ms)
+                    try:
+                        for step in range(args.steps + 1):
+                            stats = index.search_device(queries.data_ptr(), args.queries, queries.stride(0), args.k, ef,
+                                                        keys.data_ptr(), dists.data_ptr(), counts.data_ptr(),
+                                                        visited.data_ptr(), computed.data_ptr(), timed=True, tuning=tuning)
+                            if step:
+                                ms.append(stats.kernel_ms)
+                    except RuntimeError as error:
+                        print(f"ef={ef:4d} mode={mode} waves/cu={waves} variant={variant} frontier={frontier}: {error}", flush=True)
+                        continue
                     c = computed.cpu().numpy().astype(np.float64)
                     v = visited.cpu().numpy().astype(np.float64)
                     step_bytes = float(np.sum(c * bpv + v * 4 * m0 + args.k * 8 + bpv))
                     best = min(ms)
                     k_host = keys.cpu().numpy()
-                    same = reference_keys.setdefault(ef, k_host)
+                    d_host = dists.cpu().numpy().view(np.uint32)
+                    same = reference_keys.setdefault(ef, (k_host, d_host, c, v))
+                    identical = (np.array_equal(same[0], k_host) and np.array_equal(same[1], d_host) and
+                                 np.array_equal(same[2], c) and np.array_equal(same[3], v))
                     peaks = index.last_peaks(args.queries)
                     print(f"ef={ef:4d} mode={stats.mode} waves/cu={waves:2d} grid={stats.grid:5d} lds={stats.lds_bytes:6d} "
-                          f"variant={variant} passes={stats.passes} ms={best:8.3f} (mean {np.mean(ms):8.3f}) "
-                          f"qps={args.queries / best * 1e3:10.0f} GB/s={step_bytes / best / 1e6:8.1f} "
+                          f"variant={stats.variant} frontier={stats.frontier} passes={stats.passes} ms={best:8.3f} "
+                          f"(mean {np.mean(ms):8.3f}) qps={args.queries / best * 1e3:10.0f} GB/s={step_bytes / best / 1e6:8.1f} "
                           f"dist/q={c.mean():.0f} hops/q={v.mean():.0f} peak_next={peaks[:, 0].max()} "
-                          f"visits_max={peaks[:, 1].max()} identical={np.array_equal(same, k_host)}", flush=True)
+                          f"visits_max={peaks[:, 1].max()} tail_idle={stats.tail_idle:.4f} span_ms={stats.span_ms:.3f} "
+                          f"identical(keys,distance bits,counters)={identical}", flush=True)
 
 
 if __name__ == "__main__":

@@ -51,8 +51,11 @@ CONFIGS = [
 
 def check_against_oracle(index, image, queries, k, dtype, expansion, **search_kwargs):
     got = index.search(queries, k, expansion=expansion, dtype=dtype, **search_kwargs)
+    # the oracle restates whichever frontier the engine ran: the reference's heap, or the open cells of `top`
+    # (tests/test_oracle_frontier.py pins the latter to the former wherever no two frontier distances coincide)
     keys, dists, counts, visited, computed = util.oracle_search(image, queries, k, dtype, expansion,
-                                                                lanes=index.lanes_per_row)
+                                                                lanes=index.lanes_per_row,
+                                                                frontier_in_top=got.stats.frontier == 2)
     if not util.layout_exact(index.metric_kind):
         # log / sin / cos / asin come from two different math libraries (ocml on the device, libm in the oracle): the
         # float tolerance of north_star instead of bit equality, labels wherever neighbouring distances are separated
@@ -83,6 +86,18 @@ def test_search_matches_oracle_and_reference(reference, metric, dtype, ndim, n, 
     assert len(index) == n and index.ndim == ndim and index.connectivity == connectivity
     got = check_against_oracle(index, image, queries, k, dtype, expansion)
     assert got.stats.passes == 1, "default scratch sizing should not overflow on these shapes"
+    # float-valued pairs run without a frontier heap by default; the reference-shaped heap stays one switch away and must
+    # give the same answer on these (tie-free) inputs — keys, distance bits, counters
+    float_valued = dtype not in ("b1", "i8")
+    assert got.stats.frontier == (2 if float_valued and max(expansion, k) <= 1024 else 1)
+    if float_valued:
+        from usearch_amd import Tuning
+        heap = check_against_oracle(index, image, queries, k, dtype, expansion, tuning=Tuning(frontier=1))
+        assert heap.stats.frontier == 1
+        if util.layout_exact(metric):
+            assert np.array_equal(heap.keys, got.keys) and util.same_float_bits(heap.distances, got.distances)
+            assert np.array_equal(heap.visited_per_query, got.visited_per_query)
+            assert np.array_equal(heap.computed_per_query, got.computed_per_query)
 
     # the real reference, same image, same queries
     ref_index.expansion_search = expansion
@@ -139,7 +154,8 @@ def test_query_casts_match_reference(reference):
         queries = util.make_vectors(40, ndim, "f32", seed=22)
         got = index.search(queries, 10, dtype="f32")
         keys, dists, counts, visited, computed = util.oracle_search(image, queries, 10, "f32", 64,
-                                                                    lanes=index.lanes_per_row)
+                                                                    lanes=index.lanes_per_row,
+                                                                    frontier_in_top=got.stats.frontier == 2)
         assert np.array_equal(got.keys, keys) and util.same_float_bits(got.distances, dists)
         assert np.array_equal(got.computed_per_query, computed)
         rkeys, rdists, *_ = ref_index.search(queries, 10, dtype="f32", threads=1)
@@ -206,9 +222,38 @@ def test_every_kernel_build_agrees(reference):
     assert index.lanes_per_row == 8
     queries = util.make_vectors(48, 768, "f16", seed=72)
     for expansion in (64, 128, 300, 600):
-        for variant in (1, 2, 3):
+        for variant in (1, 2, 3, 4, 5):  # 4 and 5: the tighter register budgets only the heap-less frontier fits
             got = check_against_oracle(index, image, queries, 10, "f16", expansion, tuning=Tuning(variant=variant))
-            assert got.stats.passes == 1
+            assert got.stats.passes == 1 and got.stats.variant == variant and got.stats.frontier == 2
+        for variant in (1, 2, 3):
+            got = check_against_oracle(index, image, queries, 10, "f16", expansion, tuning=Tuning(variant=variant, frontier=1))
+            assert got.stats.passes == 1 and got.stats.variant == variant and got.stats.frontier == 1
+    with pytest.raises(RuntimeError):  # the tight builds do not exist with the heap
+        index.search(queries, 10, expansion=64, tuning=Tuning(variant=4, frontier=1))
+
+
+def test_exact_float_ties_between_frontier_candidates(reference):
+    """Where the two frontiers may part ways, and only there: members at EXACTLY the same distance from the query (here: every
+    vector stored three times). The heap-less frontier (default for float-valued pairs) is bit-exact against its restatement
+    in the oracle; the reference-shaped heap (`Tuning(frontier=1)`) is bit-exact against the reference-shaped oracle; both
+    return the same DISTANCES for every query (the same members up to which of three identical twins is named), and the
+    traversal counters differ by little. With distinct distances the two are identical (every other test of this file)."""
+    from usearch_amd import Index, Tuning
+    base = util.make_vectors(700, 48, "f32", seed=91)
+    vectors = np.concatenate([base, base, base])
+    from oracle import refbind
+    reference_index = refbind.RefIndex(48, "l2sq", "f32", connectivity=16, expansion_add=128)
+    reference_index.add(np.arange(len(vectors), dtype=np.uint64) + 1000, vectors, threads=1)
+    image = reference_index.save_buffer()
+    index = Index.restore(image)
+    queries = util.make_vectors(120, 48, "f32", seed=92)
+    queries[:30] = base[:30]
+    in_top = check_against_oracle(index, image, queries, 10, "f32", 64)
+    heap = check_against_oracle(index, image, queries, 10, "f32", 64, tuning=Tuning(frontier=1))
+    assert in_top.stats.frontier == 2 and heap.stats.frontier == 1
+    assert util.same_float_bits(in_top.distances, heap.distances), "the same neighbourhoods, whichever twin is named"
+    hops_in_top, hops_heap = in_top.visited_per_query.astype(float), heap.visited_per_query.astype(float)
+    assert abs(hops_in_top.mean() / hops_heap.mean() - 1) < 0.05
 
 
 def test_large_expansion(reference):

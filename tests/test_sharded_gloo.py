@@ -1,44 +1,42 @@
-"""CPU, world_size 2, gloo: the sharded-search protocol of usearch_amd/sharded.py — query broadcast, one all-gather per
-tensor, merge in rank order with the `merge_into` tie rule (index.hpp:2650-2670). The local search and the merge are
-injected (a seeded fake per rank, the oracle's merge_into), so that no GPU is needed; the GPU bindings of the same class
-are covered by tests/test_gpu_merge.py."""
+"""CPU, world_size 2, gloo: the sharded-search step through the SAME native entry point the GPUs use
+(`usearch_amd_sharded_search_many`, usearch_amd/csrc/sharded.hip) — query broadcast, ONE all-gather of the packed block
+{distances | keys | counts | flags}, merge in rank order with the `merge_into` tie rule (index.hpp:2650-2670). Only the
+device search is a stand-in (a seeded fake per rank, handed in through the transport), the collectives are gloo's; packing,
+exchange and merge are the product's own code running in host memory. The expectation is the oracle's `merge_into`.
+The GPU bindings of the same step are covered by tests/test_gpu_merge.py."""
 import os
 import socket
 
 import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 WORLD = 2
-Q, K = 37, 6
+Q, K, STRIDE = 37, 6, 32
 
 
-def fake_shard_results(rank: int, queries: torch.Tensor):
+def fake_shard_results(rank: int, checksum: int):
     """Seeded, tie-heavy, ascending per-query results that depend on the (broadcast) queries."""
-    seed = int(queries.sum().item()) % 1000 + 17 * rank
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(checksum % 1000 + 17 * rank)
     distances = np.sort(rng.integers(0, 5, size=(Q, K)).astype(np.float32), axis=1)
-    keys = (rng.integers(0, 10_000, size=(Q, K)) * WORLD + rank).astype(np.int64)
-    counts = rng.integers(0, K + 1, size=Q).astype(np.int64)
-    return torch.from_numpy(keys), torch.from_numpy(distances), torch.from_numpy(counts)
+    keys = (rng.integers(0, 10_000, size=(Q, K)) * WORLD + rank).astype(np.uint64)
+    counts = rng.integers(0, K + 1, size=Q).astype(np.uint64)
+    return keys, distances, counts
 
 
-def oracle_merge(all_distances, all_keys, all_counts):
+def oracle_merge(parts):
     from oracle import oraclebind
-    shards, q, k = all_distances.shape
-    keys = np.zeros((q, k), dtype=np.uint64)
-    distances = np.zeros((q, k), dtype=np.float32)
-    counts = np.zeros(q, dtype=np.int64)
-    for i in range(q):
+    keys = np.zeros((Q, K), dtype=np.uint64)
+    distances = np.zeros((Q, K), dtype=np.float32)
+    counts = np.zeros(Q, dtype=np.uint64)
+    for i in range(Q):
         merged = 0
-        for shard in range(shards):
-            n = int(all_counts[shard, i])
-            merged = oraclebind.merge_into(keys[i], distances[i], merged, all_keys[shard, i, :n].numpy().astype(np.uint64),
-                                           all_distances[shard, i, :n].numpy(), n)
+        for shard_keys, shard_distances, shard_counts in parts:  # shards in rank order
+            n = int(shard_counts[i])
+            merged = oraclebind.merge_into(keys[i], distances[i], merged, shard_keys[i, :n], shard_distances[i, :n], n)
         counts[i] = merged
-    return torch.from_numpy(keys.astype(np.int64)), torch.from_numpy(distances), torch.from_numpy(counts)
+    return keys, distances, counts
 
 
 def worker(rank: int, port: int, results):
@@ -46,33 +44,50 @@ def worker(rank: int, port: int, results):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     try:
-        from usearch_amd.sharded import ShardedSearcher
+        from usearch_amd.sharded import Communicator
         seen = {}
 
-        def local_search(queries, k, expansion):
-            seen["checksum"] = int(queries.sum().item())
-            return fake_shard_results(rank, queries)
+        def all_gather(send: np.ndarray, receive: np.ndarray):
+            dist.all_gather_into_tensor(torch.from_numpy(receive), torch.from_numpy(send))
 
-        searcher = ShardedSearcher(local_search, oracle_merge)
-        queries = torch.full((Q, 8), 3 if rank == 0 else 99, dtype=torch.int32)  # only rank 0's batch counts
-        keys, distances, counts = searcher.search(queries, K, 64)
-        assert seen["checksum"] == Q * 8 * 3, "the batch was not broadcast from rank 0"
-        # expectation, computed locally from both ranks' deterministic fakes
-        reference_queries = torch.full((Q, 8), 3, dtype=torch.int32)
-        parts = [fake_shard_results(r, reference_queries) for r in range(WORLD)]
-        expected = oracle_merge(torch.stack([p[1] for p in parts]), torch.stack([p[0] for p in parts]),
-                                torch.stack([p[2] for p in parts]))
-        assert torch.equal(counts, expected[2])
+        def broadcast(buffer: np.ndarray, root: int):
+            dist.broadcast(torch.from_numpy(buffer), src=root)
+
+        def local_search(queries: np.ndarray, count: int, wanted: int, expansion: int):
+            assert (count, wanted, expansion) == (Q, K, 64) and queries.shape == (Q, STRIDE)
+            seen["checksum"] = int(queries.astype(np.int64).sum())
+            return fake_shard_results(rank, seen["checksum"])
+
+        communicator = Communicator.on_host(rank, WORLD, all_gather, broadcast, local_search)
+        assert (communicator.rank, communicator.world) == (rank, WORLD)
+        queries = np.full((Q, STRIDE), 3 if rank == 0 else 99, dtype=np.uint8)  # only rank 0's batch counts
+        keys = np.zeros((Q, K), dtype=np.uint64)
+        distances = np.zeros((Q, K), dtype=np.float32)
+        counts = np.zeros(Q, dtype=np.uint64)
+        stats, step = communicator.search_raw(None, queries.ctypes.data, Q, STRIDE, K, 64, 0, keys.ctypes.data,
+                                              distances.ctypes.data, counts.ctypes.data, 0, 0)
+        assert seen["checksum"] == Q * STRIDE * 3, "the batch was not broadcast from rank 0"
+        assert step.block_bytes == ((Q * K * 4 + 7) // 8 * 8) + Q * K * 8 + Q * 8 + 8
+        assert step.gathered_bytes == WORLD * step.block_bytes
+        parts = [fake_shard_results(r, Q * STRIDE * 3) for r in range(WORLD)]
+        expected_keys, expected_distances, expected_counts = oracle_merge(parts)
+        assert np.array_equal(counts, expected_counts)
         for i in range(Q):
             n = int(counts[i])
-            assert torch.equal(keys[i, :n], expected[0][i, :n]) and torch.equal(distances[i, :n], expected[1][i, :n])
             assert n == min(K, int(parts[0][2][i] + parts[1][2][i]))
+            assert np.array_equal(keys[i, :n], expected_keys[i, :n])
+            assert np.array_equal(distances[i, :n], expected_distances[i, :n])
+            assert np.all(keys[i, n:] == 0) and np.all(np.isnan(distances[i, n:]))  # padding of index.hpp:2707-2722
+        # without a broadcast every rank searches what it was handed
+        communicator.search_raw(None, queries.ctypes.data, Q, STRIDE, K, 64, -1, keys.ctypes.data, distances.ctypes.data,
+                                counts.ctypes.data, 0, 0)
+        assert seen["checksum"] == Q * STRIDE * 3  # rank 1's buffer was overwritten by the first step's broadcast
         results[rank] = True
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_protocol_two_ranks_gloo():
+def test_sharded_step_two_ranks_gloo_through_the_c_abi():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -80,3 +95,25 @@ def test_sharded_protocol_two_ranks_gloo():
     results = manager.dict()
     mp.spawn(worker, args=(port, results), nprocs=WORLD, join=True)
     assert dict(results) == {0: True, 1: True}
+
+
+def test_single_rank_step_needs_no_exchange():
+    """world = 1: the same entry point, the merge still pads and counts."""
+    from usearch_amd.sharded import Communicator
+
+    def refuse(*_):
+        raise AssertionError("a single rank has nothing to exchange")
+
+    parts = [fake_shard_results(0, 5)]
+    communicator = Communicator.on_host(0, 1, refuse, None, lambda queries, count, wanted, expansion: parts[0])
+    queries = np.zeros((Q, STRIDE), dtype=np.uint8)
+    keys = np.zeros((Q, K), dtype=np.uint64)
+    distances = np.zeros((Q, K), dtype=np.float32)
+    counts = np.zeros(Q, dtype=np.uint64)
+    communicator.search_raw(None, queries.ctypes.data, Q, STRIDE, K, 64, 0, keys.ctypes.data, distances.ctypes.data,
+                            counts.ctypes.data, 0, 0)
+    expected_keys, expected_distances, expected_counts = oracle_merge(parts)
+    assert np.array_equal(counts, expected_counts)
+    for i in range(Q):
+        n = int(counts[i])
+        assert np.array_equal(keys[i, :n], expected_keys[i, :n]) and np.array_equal(distances[i, :n], expected_distances[i, :n])

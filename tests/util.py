@@ -84,8 +84,11 @@ def same_float_bits(a: np.ndarray, b: np.ndarray) -> bool:
 
 
 def oracle_search(image: np.ndarray, queries: np.ndarray, k: int, dtype: str, expansion: int = 64, lanes: int = 0,
-                  exact: bool = False):
-    return oraclebind.OracleIndex(image).search(queries, k, dtype=dtype, expansion=expansion, lanes=lanes, exact=exact)
+                  exact: bool = False, frontier_in_top: bool = False):
+    """`frontier_in_top`: restate the engine's heap-less frontier (kernels.hpp frontier_top_k) instead of the reference's heap;
+    GPU tests pass what the engine reports it ran (`stats.frontier == 2`)."""
+    return oraclebind.OracleIndex(image).search(queries, k, dtype=dtype, expansion=expansion, lanes=lanes, exact=exact,
+                                                frontier_in_top=frontier_in_top)
 
 
 def with_64_bit_dimensions(image: np.ndarray) -> np.ndarray:

@@ -66,8 +66,8 @@ const char* snapshot_t::allocate_for_build(metric_kind_t metric, scalar_kind_t s
     count_present_ = capacity;
     const std::uint64_t n = capacity;
     const std::uint32_t bpv = (std::uint32_t)bytes_per_vector(scalar, dimensions);
-    std::uint32_t row_stride = 0;
-    row_geometry(bpv, lanes_, row_stride);
+    std::uint32_t row_stride = 0, row_chunks = 0;
+    row_geometry(bpv, lanes_, row_stride, row_chunks);
 
     std::vector<std::uint32_t> upper_ref(n);
     std::uint64_t lists = 0;
@@ -121,7 +121,7 @@ const char* snapshot_t::allocate_for_build(metric_kind_t metric, scalar_kind_t s
     view_.keys = static_cast<const std::uint64_t*>(d_keys_);
     view_.size = 0;
     view_.row_stride = row_stride;
-    view_.chunks = row_stride / 16;
+    view_.chunks = row_chunks;
     view_.bytes_per_vector = bpv;
     view_.dimensions = (std::uint32_t)dimensions;
     view_.m = m;
@@ -131,8 +131,6 @@ const char* snapshot_t::allocate_for_build(metric_kind_t metric, scalar_kind_t s
     UA_HIP(hipGetDeviceProperties(&properties, device));
     compute_units_ = properties.multiProcessorCount > 0 ? properties.multiProcessorCount : 256;
     UA_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    UA_HIP(hipEventCreate(&event_begin_));
-    UA_HIP(hipEventCreate(&event_end_));
     return nullptr;
 }
 
@@ -264,6 +262,7 @@ const char* builder_t::build(metric_kind_t metric, scalar_kind_t scalar, std::si
             extras.query_ids = d_nodes;
             extras.beam_level = level;
             extras.emit_slots = true;
+            extras.reference_frontier = true; // builds stay byte-for-byte reproducible against the reference-shaped oracle
             search_stats_t search_stats;
             if (const char* e = snapshot_.search_device(view.vectors, pass_count, view.row_stride, ef, ef, d_cand_slots,
                                                         d_cand_distances, d_cand_counts, d_visited, d_computed, stream,

@@ -16,6 +16,7 @@
 #include "casts.hpp"
 #include "engine.hpp"
 #include "kernels.hpp"
+#include "sharded.hpp"
 
 using namespace usearch_amd;
 
@@ -85,6 +86,8 @@ search_tuning_t tuning_from_c(usearch_amd_tuning_t const* t) {
         out.variant = t->variant;
         out.mode = t->mode;
         out.waves_per_cu = t->waves_per_cu;
+        out.frontier = t->frontier;
+        out.wave_clock = t->wave_clock;
     }
     return out;
 }
@@ -99,6 +102,11 @@ void stats_to_c(const search_stats_t& s, usearch_amd_stats_t* out) {
     out->mode = s.mode;
     out->grid = s.grid;
     out->lds_bytes = s.lds_bytes;
+    out->frontier = s.frontier;
+    out->variant = s.variant;
+    out->tail_idle = s.tail_idle;
+    out->span_ms = s.span_ms;
+    out->reserved = 0;
 }
 
 void fail(usearch_amd_error_t* error, const char* message) {
@@ -392,6 +400,87 @@ void usearch_amd_exact_search_dataset(void const* dataset, size_t dataset_count,
                                                   queries_stride, wanted, keys, keys_stride, distances,
                                                   distances_stride))
         fail(error, e);
+}
+
+void usearch_amd_comm_unique_id(void* out, usearch_amd_error_t* error) {
+    if (const char* e = comm_t::unique_id(out))
+        fail(error, e);
+}
+
+usearch_amd_comm_t usearch_amd_comm_init_rccl(void const* unique_id, int rank, int world, int device,
+                                              usearch_amd_error_t* error) {
+    comm_t* comm = new (std::nothrow) comm_t();
+    if (!comm) {
+        fail(error, "Out of memory");
+        return nullptr;
+    }
+    if (const char* e = comm->init_rccl(unique_id, rank, world, device)) {
+        delete comm;
+        fail(error, e);
+        return nullptr;
+    }
+    return comm;
+}
+
+usearch_amd_comm_t usearch_amd_comm_init_custom(usearch_amd_transport_t const* transport, int rank, int world, int device,
+                                                usearch_amd_error_t* error) {
+    if (!transport) {
+        fail(error, "No transport");
+        return nullptr;
+    }
+    comm_t* comm = new (std::nothrow) comm_t();
+    if (!comm) {
+        fail(error, "Out of memory");
+        return nullptr;
+    }
+    transport_t inner;
+    inner.context = transport->context;
+    inner.all_gather = transport->all_gather;
+    inner.broadcast = transport->broadcast;
+    inner.buffers_on_host = transport->buffers_on_host;
+    inner.local_search = transport->local_search;
+    if (const char* e = comm->init_custom(inner, rank, world, device)) {
+        delete comm;
+        fail(error, e);
+        return nullptr;
+    }
+    return comm;
+}
+
+void usearch_amd_comm_free(usearch_amd_comm_t comm) { delete static_cast<comm_t*>(comm); }
+int usearch_amd_comm_rank(usearch_amd_comm_t comm) { return comm ? static_cast<comm_t*>(comm)->rank() : 0; }
+int usearch_amd_comm_world(usearch_amd_comm_t comm) { return comm ? static_cast<comm_t*>(comm)->world() : 1; }
+
+void usearch_amd_comm_broadcast(usearch_amd_comm_t comm, void* buffer, size_t bytes, int root, void* stream,
+                                usearch_amd_error_t* error) {
+    if (!comm)
+        return fail(error, "No communicator");
+    if (const char* e = static_cast<comm_t*>(comm)->broadcast(buffer, bytes, root, static_cast<hipStream_t>(stream)))
+        fail(error, e);
+}
+
+void usearch_amd_sharded_search_many(usearch_amd_snapshot_t snapshot, usearch_amd_comm_t comm, void* queries,
+                                     size_t queries_count, size_t queries_stride, size_t wanted, size_t expansion,
+                                     int broadcast_root, usearch_amd_key_t* keys, usearch_amd_distance_t* distances,
+                                     uint64_t* counts, uint64_t* visited, uint64_t* computed, void* stream,
+                                     usearch_amd_tuning_t const* tuning, int timed, usearch_amd_stats_t* stats,
+                                     usearch_amd_sharded_stats_t* sharded_stats, usearch_amd_error_t* error) {
+    if (!comm)
+        return fail(error, "No communicator");
+    search_stats_t s;
+    sharded_stats_t step;
+    if (const char* e = static_cast<comm_t*>(comm)->search(
+            snapshot ? as_snapshot(snapshot) : nullptr, queries, queries_count, queries_stride, wanted, expansion,
+            broadcast_root, keys, distances, counts, visited, computed, static_cast<hipStream_t>(stream),
+            tuning_from_c(tuning), timed != 0, &s, &step))
+        return fail(error, e);
+    stats_to_c(s, stats);
+    if (sharded_stats) {
+        sharded_stats->block_bytes = step.block_bytes;
+        sharded_stats->gathered_bytes = step.gathered_bytes;
+        sharded_stats->exchange_ms = step.exchange_ms;
+        sharded_stats->exchanges = step.exchanges;
+    }
 }
 
 void usearch_amd_merge_many_device(usearch_amd_distance_t const* distances, usearch_amd_key_t const* keys,

@@ -18,7 +18,7 @@
 namespace usearch_amd {
 
 
-void row_geometry(std::size_t bytes, std::uint32_t& lanes, std::uint32_t& row_stride) {
+void row_geometry(std::size_t bytes, std::uint32_t& lanes, std::uint32_t& row_stride, std::uint32_t& chunks) {
     // lanes per row (G): the smallest power of two covering the row's 16-byte chunks, at most 8 (= one 128-byte line per
     // load). USEARCH_AMD_LANES overrides (1, 2, 4, 8): fewer lanes per row = more rows per round trip.
     const std::uint32_t raw_chunks = std::max<std::uint32_t>(1, (std::uint32_t)((bytes + 15) / 16));
@@ -28,7 +28,18 @@ void row_geometry(std::size_t bytes, std::uint32_t& lanes, std::uint32_t& row_st
     const std::size_t forced = env_size("USEARCH_AMD_LANES", 0);
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8)
         lanes = std::min<std::uint32_t>((std::uint32_t)forced, pow2_ceil(raw_chunks));
-    row_stride = (std::uint32_t)((bytes + 16 * lanes - 1) / (16 * lanes) * (16 * lanes));
+    // what the kernels read of a row: whole 16-byte chunks, a multiple of G of them
+    chunks = (std::uint32_t)((bytes + 16 * lanes - 1) / (16 * lanes) * lanes);
+    row_stride = chunks * 16;
+    // where rows start: a row of ≤ 128 bytes never straddles two 128-byte lines when the pitch is a power of two (96-byte
+    // rows at pitch 96 touch 1.5 lines on average: half the fetched bytes wasted); longer rows start on a line boundary
+    // when that costs at most 1/8 of the matrix. USEARCH_AMD_DENSE_ROWS=1 keeps the dense pitch (A/B runs).
+    if (!env_size("USEARCH_AMD_DENSE_ROWS", 0)) {
+        if (row_stride <= 128)
+            row_stride = pow2_ceil(row_stride);
+        else if (row_stride % 128 && (128 - row_stride % 128) * 8 <= row_stride)
+            row_stride += 128 - row_stride % 128;
+    }
 }
 
 /// Re-pitches `rows` host rows of `bytes` bytes (source stride `source_stride`) into device rows of `row_stride` bytes.
@@ -69,27 +80,152 @@ bool kernel_available(metric_kind_t metric, scalar_kind_t scalar) {
 
 snapshot_t::~snapshot_t() { release(); }
 
-void snapshot_t::release() {
-    if (!d_vectors_ && !d_nbr0_ && !d_status_ && !stream_)
-        return;
-    (void)hipSetDevice(device_);
-    for (void* p : {d_vectors_, d_nbr0_, d_upper_ref_, d_upper_, d_keys_, (void*)d_status_, (void*)d_todo_,
-                    (void*)d_queue_, (void*)d_peaks_, (void*)d_scratch_, (void*)d_stage_})
+// ---------------------------------------------------------------------------------------------------------------------
+//  Workspaces: what one in-flight batch owns
+// ---------------------------------------------------------------------------------------------------------------------
+
+const char* workspace_t::create() {
+    UA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    UA_HIP(hipEventCreate(&event_begin));
+    UA_HIP(hipEventCreate(&event_end));
+    UA_HIP(hipMalloc((void**)&d_queue, 256));
+    return nullptr;
+}
+
+const char* workspace_t::reserve(std::size_t queries_wanted, std::size_t scratch_wanted) {
+    if (queries_wanted > queries) {
+        for (void* p : {(void*)d_status, (void*)d_todo, (void*)d_peaks})
+            if (p)
+                (void)hipFree(p);
+        if (h_status)
+            (void)hipHostFree(h_status);
+        d_status = d_todo = d_peaks = h_status = nullptr;
+        queries = 0;
+        const std::size_t room = std::max<std::size_t>(queries_wanted, 64);
+        UA_HIP(hipMalloc((void**)&d_status, room * 4));
+        UA_HIP(hipMalloc((void**)&d_todo, room * 4));
+        UA_HIP(hipMalloc((void**)&d_peaks, room * 8));
+        UA_HIP(hipHostMalloc((void**)&h_status, (room + 16) * 4, hipHostMallocDefault));
+        queries = room;
+    }
+    if (scratch_wanted > scratch_bytes) {
+        if (d_scratch)
+            (void)hipFree(d_scratch);
+        d_scratch = nullptr;
+        scratch_bytes = 0;
+        UA_HIP(hipMalloc((void**)&d_scratch, scratch_wanted));
+        scratch_bytes = scratch_wanted;
+    }
+    return nullptr;
+}
+
+const char* workspace_t::reserve_stage(std::size_t device_bytes, std::size_t host_bytes) {
+    if (device_bytes > stage_bytes) {
+        if (d_stage)
+            (void)hipFree(d_stage);
+        d_stage = nullptr;
+        stage_bytes = 0;
+        const std::size_t room = std::max<std::size_t>(device_bytes, 64 << 10);
+        UA_HIP(hipMalloc((void**)&d_stage, room));
+        stage_bytes = room;
+    }
+    if (host_bytes > host_stage_bytes) {
+        if (h_stage)
+            (void)hipHostFree(h_stage);
+        h_stage = nullptr;
+        host_stage_bytes = 0;
+        const std::size_t room = std::max<std::size_t>(host_bytes, 64 << 10);
+        UA_HIP(hipHostMalloc((void**)&h_stage, room, hipHostMallocDefault));
+        host_stage_bytes = room;
+    }
+    return nullptr;
+}
+
+const char* workspace_t::reserve_wave_clock(std::size_t waves) {
+    if (waves > wave_clock_waves) {
+        if (d_wave_clock)
+            (void)hipFree(d_wave_clock);
+        d_wave_clock = nullptr;
+        wave_clock_waves = 0;
+        UA_HIP(hipMalloc((void**)&d_wave_clock, waves * 16));
+        wave_clock_waves = waves;
+    }
+    return nullptr;
+}
+
+void workspace_t::destroy() {
+    for (void* p : {(void*)d_status, (void*)d_todo, (void*)d_queue, (void*)d_peaks, (void*)d_scratch, (void*)d_stage,
+                    (void*)d_wave_clock})
         if (p)
             (void)hipFree(p);
-    if (h_status_)
-        (void)hipHostFree(h_status_);
-    if (event_begin_)
-        (void)hipEventDestroy(event_begin_);
-    if (event_end_)
-        (void)hipEventDestroy(event_end_);
+    if (h_status)
+        (void)hipHostFree(h_status);
+    if (h_stage)
+        (void)hipHostFree(h_stage);
+    if (event_begin)
+        (void)hipEventDestroy(event_begin);
+    if (event_end)
+        (void)hipEventDestroy(event_end);
+    if (stream)
+        (void)hipStreamDestroy(stream);
+    *this = workspace_t{};
+}
+
+const char* snapshot_t::take(workspace_t*& out) {
+    std::unique_lock<std::mutex> lock(pool_mutex_);
+    for (;;) {
+        if (!idle_.empty()) {
+            out = idle_.back();
+            idle_.pop_back();
+            return nullptr;
+        }
+        if (workspaces_.size() < std::max<std::size_t>(1, max_workspaces_)) {
+            std::unique_ptr<workspace_t> fresh(new workspace_t());
+            UA_HIP(hipSetDevice(device_));
+            if (const char* e = fresh->create()) {
+                fresh->destroy();
+                return e;
+            }
+            out = fresh.get();
+            workspaces_.push_back(std::move(fresh));
+            return nullptr;
+        }
+        pool_ready_.wait(lock);
+    }
+}
+
+void snapshot_t::give_back(workspace_t* workspace) {
+    {
+        std::lock_guard<std::mutex> lock(pool_mutex_);
+        idle_.push_back(workspace);
+        last_used_ = workspace;
+    }
+    pool_ready_.notify_one();
+}
+
+void snapshot_t::set_concurrency(std::size_t workspaces) {
+    std::lock_guard<std::mutex> lock(pool_mutex_);
+    max_workspaces_ = std::max<std::size_t>(1, std::min<std::size_t>(workspaces, 256));
+}
+
+void snapshot_t::release() {
+    if (!d_vectors_ && !d_nbr0_ && workspaces_.empty() && !stream_)
+        return;
+    (void)hipSetDevice(device_);
+    for (void* p : {d_vectors_, d_nbr0_, d_upper_ref_, d_upper_, d_keys_})
+        if (p)
+            (void)hipFree(p);
+    {
+        std::lock_guard<std::mutex> lock(pool_mutex_);
+        for (auto& workspace : workspaces_)
+            workspace->destroy();
+        workspaces_.clear();
+        idle_.clear();
+        last_used_ = nullptr;
+    }
     if (stream_)
         (void)hipStreamDestroy(stream_);
     d_vectors_ = d_nbr0_ = d_upper_ref_ = d_upper_ = d_keys_ = nullptr;
-    d_status_ = d_todo_ = d_queue_ = d_peaks_ = h_status_ = nullptr;
-    d_scratch_ = d_stage_ = nullptr;
-    workspace_queries_ = scratch_bytes_ = stage_bytes_ = 0;
-    event_begin_ = event_end_ = nullptr;
     stream_ = nullptr;
 }
 
@@ -106,8 +242,8 @@ const char* snapshot_t::build(const image_t& image, int device) {
     const std::uint32_t m = (std::uint32_t)image.connectivity, m0 = (std::uint32_t)image.connectivity_base;
     const std::uint32_t bpv = (std::uint32_t)image.cols;
 
-    std::uint32_t row_stride = 0;
-    row_geometry(bpv, lanes_, row_stride);
+    std::uint32_t row_stride = 0, row_chunks = 0;
+    row_geometry(bpv, lanes_, row_stride, row_chunks);
 
     // ---- host pass 1: tape offsets (sequential prefix) and the number of upper-level lists
     std::vector<std::uint64_t> offsets(n + 1);
@@ -223,7 +359,7 @@ const char* snapshot_t::build(const image_t& image, int device) {
     view_.keys = static_cast<const std::uint64_t*>(d_keys_);
     view_.size = n;
     view_.row_stride = row_stride;
-    view_.chunks = row_stride / 16;
+    view_.chunks = row_chunks;
     view_.bytes_per_vector = bpv;
     view_.dimensions = (std::uint32_t)image.dimensions;
     view_.m = m;
@@ -236,54 +372,6 @@ const char* snapshot_t::build(const image_t& image, int device) {
     UA_HIP(hipGetDeviceProperties(&properties, device));
     compute_units_ = properties.multiProcessorCount > 0 ? properties.multiProcessorCount : 256;
     UA_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    UA_HIP(hipEventCreate(&event_begin_));
-    UA_HIP(hipEventCreate(&event_end_));
-    return nullptr;
-}
-
-const char* snapshot_t::ensure_workspace(std::size_t queries, std::size_t scratch_bytes) {
-    if (queries > workspace_queries_) {
-        if (d_status_)
-            (void)hipFree(d_status_);
-        if (d_todo_)
-            (void)hipFree(d_todo_);
-        if (d_peaks_)
-            (void)hipFree(d_peaks_);
-        if (h_status_)
-            (void)hipHostFree(h_status_);
-        d_status_ = d_todo_ = d_peaks_ = h_status_ = nullptr;
-        workspace_queries_ = 0;
-        UA_HIP(hipMalloc((void**)&d_status_, queries * 4));
-        UA_HIP(hipMalloc((void**)&d_todo_, queries * 4));
-        UA_HIP(hipMalloc((void**)&d_peaks_, queries * 8));
-        if (!d_queue_)
-            UA_HIP(hipMalloc((void**)&d_queue_, 256));
-        UA_HIP(hipHostMalloc((void**)&h_status_, queries * 4, hipHostMallocDefault));
-        workspace_queries_ = queries;
-    }
-    if (scratch_bytes > scratch_bytes_) {
-        if (d_scratch_)
-            (void)hipFree(d_scratch_);
-        d_scratch_ = nullptr;
-        scratch_bytes_ = 0;
-        UA_HIP(hipMalloc((void**)&d_scratch_, scratch_bytes));
-        scratch_bytes_ = scratch_bytes;
-    }
-    return nullptr;
-}
-
-const char* snapshot_t::ensure_staging(std::size_t query_bytes, std::size_t count, std::size_t wanted) {
-    // queries | keys | distances | counts | visited | computed, each 256-byte aligned
-    auto pad = [](std::size_t b) { return (b + 255) & ~(std::size_t)255; };
-    const std::size_t need = pad(query_bytes * count) + pad(count * wanted * 8) + pad(count * wanted * 4) + 3 * pad(count * 8);
-    if (need > stage_bytes_) {
-        if (d_stage_)
-            (void)hipFree(d_stage_);
-        d_stage_ = nullptr;
-        stage_bytes_ = 0;
-        UA_HIP(hipMalloc((void**)&d_stage_, need));
-        stage_bytes_ = need;
-    }
     return nullptr;
 }
 
@@ -320,21 +408,30 @@ __global__ void fill_empty_kernel(std::uint64_t* keys, std::uint32_t* distance_b
         counts[i] = 0, visited[i] = 0, computed[i] = 0;
 }
 
-const char* snapshot_t::search_device(const void* queries, std::size_t count, std::size_t stride_bytes,
-                                      std::size_t wanted, std::size_t expansion, std::uint64_t* keys,
-                                      float* distances, std::uint64_t* counts, std::uint64_t* visited,
-                                      std::uint64_t* computed, hipStream_t stream, const search_tuning_t& tuning,
-                                      search_stats_t* stats, bool timed, const search_extras_t* extras) {
-    if (stats)
-        *stats = search_stats_t{};
-    if (!count || !wanted) // index.hpp:3025-3027: nothing wanted, nothing found
+/// The float-valued pairs may keep their frontier as the open cells of a register `top` (kernels.hpp frontier_top_k).
+static bool frontier_in_top_capable(scalar_kind_t scalar) { return scalar != scalar_b1x8_k && scalar != scalar_i8_k; }
+
+const char* snapshot_t::search_begin(search_call_t& call, const void* queries, std::size_t count,
+                                     std::size_t stride_bytes, std::size_t wanted, std::size_t expansion,
+                                     std::uint64_t* keys, float* distances, std::uint64_t* counts, std::uint64_t* visited,
+                                     std::uint64_t* computed, hipStream_t stream, const search_tuning_t& tuning, bool timed,
+                                     const search_extras_t* extras) {
+    call.count = count;
+    call.timed = timed;
+    if (!count || !wanted) { // index.hpp:3025-3027: nothing wanted, nothing found
+        call.done = true;
         return nullptr;
+    }
     if (count >= none_slot_k || wanted >= (1u << 24))
         return "Batch is too large";
-    std::lock_guard<std::mutex> lock(mutex_);
     UA_HIP(hipSetDevice(device_));
+    if (!call.workspace) // a caller that staged buffers in a workspace brings it along
+        if (const char* e = take(call.workspace))
+            return e;
+    workspace_t& ws = *call.workspace;
     if (!stream)
-        stream = stream_;
+        stream = ws.stream;
+    call.stream = stream;
 
     if (view_.size == 0) { // index.hpp:3034-3037
         const std::uint64_t cells = std::max<std::uint64_t>(count * wanted, count);
@@ -342,21 +439,25 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
                            reinterpret_cast<std::uint32_t*>(distances), counts, visited, computed,
                            (std::uint64_t)count, (std::uint64_t)wanted);
         UA_HIP(hipGetLastError());
-        UA_HIP(hipStreamSynchronize(stream));
+        call.done = true;
         return nullptr;
     }
 
     if (!expansion)
         expansion = default_expansion_search_k;
     const std::uint32_t ef = (std::uint32_t)std::max(expansion, wanted); // index.hpp:3052
+    call.ef = ef;
 
     // ---- scratch sizing, from measurements with the reference's own traversal (DESIGN.md "scratch sizing"): the frontier
-    // peaks at 2.4-3.9 × ef and the visited set ends at 18-30 × ef entries; outliers go through the retry ladder below.
+    // peaks at 2.4-3.9 × ef; the visited set ends at 18-30 × ef entries plus what the first hops of a big index cost
+    // whatever the expansion (10M × 768, ef = 64: 3 137 entries = 49 × ef) — hence the constant term. Outliers go through
+    // the retry ladder.
     const std::uint32_t query_lds = view_.chunks * (query_chunk_bytes_of(scalar_));
+    call.query_lds = query_lds;
     const std::uint32_t lds_budget = (std::uint32_t)env_size("USEARCH_AMD_LDS_BUDGET", 160 * 1024);
     std::uint32_t hash_cap = tuning.hash_cap ? tuning.hash_cap : (std::uint32_t)env_size("USEARCH_AMD_HASH_CAP", 0);
     if (!hash_cap)
-        hash_cap = std::max<std::uint32_t>(1024, ef * 48);
+        hash_cap = std::max<std::uint32_t>(1024, (ef * 30 + 1600) / 3 * 4); // entries expected ÷ the 75 % load limit
     hash_cap = pow2_ceil(hash_cap);
     std::uint32_t next_cap = tuning.next_cap ? tuning.next_cap : (std::uint32_t)env_size("USEARCH_AMD_NEXT_CAP", 0);
     if (!next_cap)
@@ -364,28 +465,48 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
     // never larger than the index could possibly need
     hash_cap = std::min<std::uint32_t>(hash_cap, pow2_ceil((std::uint32_t)std::min<std::uint64_t>(view_.size * 2 + 128, 1u << 30)));
     next_cap = (std::uint32_t)std::min<std::uint64_t>(next_cap, view_.size + 64);
+
+    std::uint32_t mode_request = tuning.mode ? tuning.mode : (std::uint32_t)env_size("USEARCH_AMD_MODE", 0);
+    // `top` lives in registers (1 / 4 / 8 / 16 entries per lane) while the expansion allows it
+    const bool top_in_memory = tuning.top_in_memory || env_size("USEARCH_AMD_TOP_IN_MEMORY", 0) != 0;
+    const std::uint32_t entries_per_lane = top_in_memory ? 0u : ef <= 64 ? 1u : ef <= 256 ? 4u : ef <= 512 ? 8u : ef <= 1024 ? 16u : 0u;
+    call.entries_per_lane = entries_per_lane;
+
+    // ---- who holds the frontier (kernels.hpp frontier_mode_t): the open cells of `top` wherever that is exact up to ties —
+    // float-valued pair, `top` in registers, every member a result candidate, slots below 2^31 — else the reference's heap
+    const std::uint32_t frontier_request = tuning.frontier ? tuning.frontier : (std::uint32_t)env_size("USEARCH_AMD_FRONTIER", 0);
+    const bool filtered = view_.has_tombstones || (extras && extras->allow_bits);
+    const bool in_top_possible = frontier_in_top_capable(scalar_) && entries_per_lane && !filtered && mode_request != 3 &&
+                                 view_.size < 0x80000000ull && !(extras && (extras->reference_frontier || extras->descent_only));
+    if (frontier_request == 2 && !in_top_possible)
+        return "The frontier cannot ride in `top` for this search (integer-valued pair, filter, tombstones or expansion > 1024)";
+    const int frontier = (frontier_request == 1 || !in_top_possible) ? frontier_heap_k : frontier_top_k;
+    if (frontier == frontier_top_k)
+        next_cap = 0;
+
     // register/latency trade-off of the kernel (kernels.hpp kernel_variant_t); rows shorter than 8 chunks per lane have
     // nothing to unroll
     const std::uint32_t chunks_per_lane = view_.chunks / lanes_;
     std::uint32_t variant_request = tuning.variant ? tuning.variant : (std::uint32_t)env_size("USEARCH_AMD_VARIANT", 0);
     int variant = variant_u4_w4_k;
-    if (lanes_ == 8 && chunks_per_lane >= 8 && all_kernel_builds(kernel_metric(metric_), scalar_)) {
+    const bool every_build = lanes_ == 8 && all_kernel_builds(kernel_metric(metric_), scalar_);
+    if (every_build && chunks_per_lane >= 8) {
         // measured on 10M x 768 f16 (profiles/): a whole row per round trip (12 loads per lane, 8 waves per CU) beats 8 loads
         // at 12 waves per CU at every expansion — the traversal is latency-bound, fewer round trips per hop win
         variant = chunks_per_lane >= 12 ? variant_u12_w2_k : variant_u8_w3_k;
     }
-    if (variant_request && variant_request - 1 <= (std::uint32_t)variant_u12_w2_k && lanes_ == 8 &&
-        all_kernel_builds(kernel_metric(metric_), scalar_))
-        variant = (int)variant_request - 1;
-    const std::uint32_t top_entries_hint = ef <= 64 ? 1u : ef <= 256 ? 4u : ef <= 512 ? 8u : ef <= 1024 ? 16u : 0u;
-    const std::uint32_t variant_waves_per_cu = 4u * (std::uint32_t)kernel_waves(variant, (int)top_entries_hint);
+    if (variant_request && variant_request - 1 < (std::uint32_t)variant_count_k && every_build) {
+        const int requested = (int)variant_request - 1;
+        const bool tight = requested == variant_u12_w3_k || requested == variant_u8_w4_k;
+        if (tight && frontier != frontier_top_k)
+            return "That kernel build exists for the in-`top` frontier only";
+        variant = requested;
+    }
+    const std::uint32_t variant_waves_per_cu = 4u * (std::uint32_t)kernel_waves(variant, (int)entries_per_lane, frontier);
     const std::uint32_t waves_cap = tuning.waves_per_cu ? tuning.waves_per_cu
                                                         : (std::uint32_t)env_size("USEARCH_AMD_WAVES_PER_CU", 16);
-    std::uint32_t mode_request = tuning.mode ? tuning.mode : (std::uint32_t)env_size("USEARCH_AMD_MODE", 0);
+    call.waves_cap = std::min(waves_cap, variant_waves_per_cu);
 
-    // `top` lives in registers (1 / 4 / 8 / 16 entries per lane) while the expansion allows it
-    const bool top_in_memory = tuning.top_in_memory || env_size("USEARCH_AMD_TOP_IN_MEMORY", 0) != 0;
-    const std::uint32_t entries_per_lane = top_in_memory ? 0u : ef <= 64 ? 1u : ef <= 256 ? 4u : ef <= 512 ? 8u : ef <= 1024 ? 16u : 0u;
     auto lds_bytes_for = [&](int mode, std::uint32_t cap_next, std::uint32_t cap_hash) -> std::uint64_t {
         if (mode == scratch_global_k)
             return query_lds;
@@ -396,14 +517,14 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
     auto waves_for = [&](std::uint64_t lds_bytes) -> std::uint32_t {
         const std::uint64_t granule = (lds_bytes + 1023) / 1024 * 1024; // LDS is allocated in coarse granules
         return (std::uint32_t)std::max<std::uint64_t>(
-            1, std::min<std::uint64_t>(std::min(waves_cap, variant_waves_per_cu), lds_budget / std::max<std::uint64_t>(granule, 1)));
+            1, std::min<std::uint64_t>(call.waves_cap, lds_budget / std::max<std::uint64_t>(granule, 1)));
     };
     // the frontier's default room has 256 cells of slack; when giving up to half of it back lets one more wave share the
     // compute unit's LDS, do (the retry ladder still catches a query that would have needed them)
     const bool default_next_cap = !tuning.next_cap && !env_size("USEARCH_AMD_NEXT_CAP", 0);
-    if (default_next_cap && mode_request != 1 && mode_request != 3) {
+    if (default_next_cap && next_cap && mode_request != 1 && mode_request != 3) {
         const std::uint32_t now = waves_for(lds_bytes_for(scratch_hash_k, next_cap, hash_cap));
-        if (now < std::min(waves_cap, variant_waves_per_cu)) {
+        if (now < call.waves_cap) {
             const std::uint64_t room = lds_budget / (now + 1) / 1024 * 1024;
             const std::uint64_t fixed = lds_bytes_for(scratch_hash_k, 0, hash_cap);
             if (room > fixed) {
@@ -413,14 +534,19 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
             }
         }
     }
-    // auto: keep the visited set in LDS only while that still leaves 8 waves per CU; otherwise move it to the global hash
+    // auto: keep the visited set in LDS only while that does not cost a resident wave; otherwise move it to the global hash
     int mode = mode_request == 1 ? scratch_lds_k : mode_request == 2 ? scratch_hash_k : mode_request == 3 ? scratch_global_k
-               : (waves_for(lds_bytes_for(scratch_lds_k, next_cap, hash_cap)) >= 8 ? scratch_lds_k : scratch_hash_k);
+               : (waves_for(lds_bytes_for(scratch_lds_k, next_cap, hash_cap)) >= std::min<std::uint32_t>(8, call.waves_cap) ? scratch_lds_k
+                                                                                                            : scratch_hash_k);
+    call.mode = mode;
+    call.hash_cap = hash_cap;
+    call.next_cap = next_cap;
 
-    if (const char* e = ensure_workspace(count, 0))
+    if (const char* e = ws.reserve(count, 0))
         return e;
 
-    search_args_t args{};
+    search_args_t& args = call.args;
+    args = search_args_t{};
     args.queries = static_cast<const std::uint8_t*>(queries);
     args.query_stride = stride_bytes;
     args.wanted = (std::uint32_t)wanted;
@@ -430,9 +556,9 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
     args.counts = counts;
     args.visited = visited;
     args.computed = computed;
-    args.status = d_status_;
-    args.queue = d_queue_;
-    args.peaks = d_peaks_;
+    args.status = ws.d_status;
+    args.queue = ws.d_queue;
+    args.peaks = ws.d_peaks;
     if (extras) {
         args.query_ids = extras->query_ids;
         args.beam_level = extras->beam_level;
@@ -441,177 +567,300 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
         args.allow_bits = extras->allow_bits;
     }
 
-    launch_params_t params{};
+    launch_params_t& params = call.params;
+    params = launch_params_t{};
     params.metric = metric_;
     params.lanes = lanes_;
     params.variant = variant;
+    params.frontier = frontier;
     params.stream = stream;
+    call.stats = search_stats_t{};
+    call.stats.frontier = frontier == frontier_top_k ? 2u : 1u;
+    call.stats.variant = (std::uint32_t)variant + 1;
 
     // diagnostic: per-phase shader-clock ticks of the search kernel, printed to stderr (USEARCH_AMD_PHASES=1)
-    const bool want_phases = env_size("USEARCH_AMD_PHASES", 0) != 0;
-    if (want_phases) {
-        args.phases = reinterpret_cast<unsigned long long*>(d_queue_) + 8; // d_queue_ is a 256-byte block
+    call.want_phases = env_size("USEARCH_AMD_PHASES", 0) != 0;
+    if (call.want_phases) {
+        args.phases = reinterpret_cast<unsigned long long*>(ws.d_queue) + 8; // d_queue is a 256-byte block
         UA_HIP(hipMemsetAsync(args.phases, 0, 128, stream));
     }
+    call.want_clock = tuning.wave_clock || env_size("USEARCH_AMD_WAVE_CLOCK", 0) != 0;
 
-    float total_ms = 0.f;
-    auto timed_launch = [&](const launch_params_t& p, const search_args_t& a) -> const char* {
-        UA_HIP(hipMemsetAsync(d_queue_, 0, 4, stream));
-        if (timed)
-            UA_HIP(hipEventRecord(event_begin_, stream));
-        UA_HIP(launch_search(metric_, scalar_, p, view_, a));
-        if (timed) {
-            UA_HIP(hipEventRecord(event_end_, stream));
-            UA_HIP(hipEventSynchronize(event_end_));
+    // ---- first launch: persistent waves, heaps in LDS. Nobody waits here.
+    call.passes = 0;
+    call.total_ms = 0.f;
+    call.have_todo = false;
+    call.todo.clear();
+    ws.last_count = count;
+    return run_ladder(call);
+}
+
+/// One launch of the ladder's current rung over `pending` queries (all of them, or `call.todo`).
+const char* snapshot_t::run_ladder(search_call_t& call) {
+    workspace_t& ws = *call.workspace;
+    search_args_t& args = call.args;
+    launch_params_t& params = call.params;
+    hipStream_t stream = call.stream;
+    const std::uint32_t ef = call.ef;
+    const std::uint32_t lds_budget = (std::uint32_t)env_size("USEARCH_AMD_LDS_BUDGET", 160 * 1024);
+    auto lds_bytes_for = [&](int mode, std::uint32_t cap_next, std::uint32_t cap_hash) -> std::uint64_t {
+        if (mode == scratch_global_k)
+            return call.query_lds;
+        const scratch_layout_t l = scratch_layout(call.entries_per_lane ? 0 : ef, cap_next,
+                                                  mode == scratch_lds_k ? (std::uint64_t)cap_hash * 4 : 0);
+        return call.query_lds + l.total;
+    };
+    auto waves_for = [&](std::uint64_t lds_bytes) -> std::uint32_t {
+        const std::uint64_t granule = (lds_bytes + 1023) / 1024 * 1024;
+        return (std::uint32_t)std::max<std::uint64_t>(
+            1, std::min<std::uint64_t>(call.waves_cap, lds_budget / std::max<std::uint64_t>(granule, 1)));
+    };
+    auto timed_launch = [&]() -> const char* {
+        UA_HIP(hipMemsetAsync(ws.d_queue, 0, 8, stream));
+        if (call.timed)
+            UA_HIP(hipEventRecord(ws.event_begin, stream));
+        UA_HIP(launch_search(metric_, scalar_, params, view_, args));
+        if (call.timed) {
+            UA_HIP(hipEventRecord(ws.event_end, stream));
+            UA_HIP(hipEventSynchronize(ws.event_end));
             float ms = 0.f;
-            UA_HIP(hipEventElapsedTime(&ms, event_begin_, event_end_));
-            total_ms += ms;
+            UA_HIP(hipEventElapsedTime(&ms, ws.event_begin, ws.event_end));
+            call.total_ms += ms;
         }
         return nullptr;
     };
-    /// Collects the indices of overflowed queries (among `previous`, or all) and uploads them as the next todo list.
-    auto collect_overflow = [&](const std::vector<std::uint32_t>* previous, std::vector<std::uint32_t>& todo) -> const char* {
-        UA_HIP(hipMemcpyAsync(h_status_, d_status_, count * 4, hipMemcpyDeviceToHost, stream));
-        UA_HIP(hipStreamSynchronize(stream));
-        todo.clear();
-        if (previous) {
-            for (std::uint32_t q : *previous)
-                if (h_status_[q] == status_overflow_k)
-                    todo.push_back(q);
-        } else {
-            for (std::uint32_t q = 0; q < count; ++q)
-                if (h_status_[q] == status_overflow_k)
-                    todo.push_back(q);
-        }
-        if (!todo.empty())
-            UA_HIP(hipMemcpyAsync(d_todo_, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, stream));
-        return nullptr;
-    };
 
-    std::vector<std::uint32_t> todo, todo_next;
-    std::uint32_t passes = 0;
-    bool have_todo = false;
-
-    // ---- pass 1 (+2): persistent waves, heaps in LDS; the second attempt moves the visited set to the global hash and
-    //      gives both structures 4× the room
-    if (mode != scratch_global_k) {
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            if (lds_bytes_for(mode, next_cap, hash_cap) > lds_budget) {
-                if (mode == scratch_lds_k)
-                    mode = scratch_hash_k;
-                while (next_cap > 64 && lds_bytes_for(mode, next_cap, hash_cap) > lds_budget)
-                    next_cap /= 2;
-                if (lds_bytes_for(mode, next_cap, hash_cap) > lds_budget)
-                    break; // `top` alone does not fit LDS: straight to the global fallback
-            }
-            const std::uint64_t lds_bytes = lds_bytes_for(mode, next_cap, hash_cap);
-            const std::uint32_t pending = have_todo ? (std::uint32_t)todo.size() : (std::uint32_t)count;
-            const std::uint32_t grid = (std::uint32_t)std::min<std::uint64_t>(pending, (std::uint64_t)waves_for(lds_bytes) * compute_units_);
-            const std::uint64_t slab = mode == scratch_hash_k ? (std::uint64_t)hash_cap * 4 : 0;
-            if (const char* e = ensure_workspace(count, slab * grid))
-                return e;
-            args.hash_cap = hash_cap;
-            args.next_cap = next_cap;
-            args.todo = have_todo ? d_todo_ : nullptr;
-            args.count = pending;
-            args.scratch = d_scratch_;
-            args.scratch_stride = slab;
-            params.mode = mode;
-            params.entries_per_lane = entries_per_lane;
-            params.grid = grid;
-            params.lds_bytes = (std::uint32_t)lds_bytes;
-            if (stats && attempt == 1)
-                stats->retried_lds = pending;
-            if (const char* e = timed_launch(params, args))
-                return e;
-            ++passes;
-            if (const char* e = collect_overflow(have_todo ? &todo : nullptr, todo_next))
-                return e;
-            todo.swap(todo_next);
-            have_todo = true;
-            if (todo.empty() || attempt == 1)
-                break;
-            mode = scratch_hash_k;
-            hash_cap = std::min<std::uint32_t>(hash_cap * 4, pow2_ceil((std::uint32_t)std::min<std::uint64_t>(view_.size * 2 + 128, 1u << 30)));
-            next_cap = (std::uint32_t)std::min<std::uint64_t>((std::uint64_t)next_cap * 4, view_.size + 64);
-            while (next_cap > 64 && lds_bytes_for(mode, next_cap, hash_cap) > lds_budget)
-                next_cap = next_cap * 3 / 4;
+    const std::uint32_t pending = call.have_todo ? (std::uint32_t)call.todo.size() : (std::uint32_t)call.count;
+    if (call.mode != scratch_global_k) {
+        if (lds_bytes_for(call.mode, call.next_cap, call.hash_cap) > lds_budget) {
+            if (call.mode == scratch_lds_k)
+                call.mode = scratch_hash_k;
+            while (call.next_cap > 64 && lds_bytes_for(call.mode, call.next_cap, call.hash_cap) > lds_budget)
+                call.next_cap /= 2;
+            if (lds_bytes_for(call.mode, call.next_cap, call.hash_cap) > lds_budget)
+                call.mode = scratch_global_k; // `top` alone does not fit LDS: straight to the global fallback
         }
     }
-
-    // ---- pass 3: global-memory scratch — exact sizes (one bit per slot, one frontier cell per slot), cannot overflow
-    if (mode == scratch_global_k || (have_todo && !todo.empty())) {
-        if (!have_todo) {
-            todo.resize(count);
-            for (std::uint32_t q = 0; q < count; ++q)
-                todo[q] = q;
-        }
-        if (stats)
-            stats->retried_global = (std::uint32_t)todo.size();
-        const std::uint64_t bitmap_bytes = ((view_.size + 31) / 32) * 4;
-        const std::uint32_t frontier = (std::uint32_t)std::min<std::uint64_t>(view_.size + 64, 0xFFFFFFF0u);
-        const scratch_layout_t layout = scratch_layout(ef, frontier, bitmap_bytes);
-        const std::size_t slab = (layout.total + 255) & ~(std::size_t)255;
-        const std::size_t budget = env_size("USEARCH_AMD_GLOBAL_SCRATCH_BYTES", (std::size_t)2 << 30);
-        const std::size_t waves = std::max<std::size_t>(1, std::min<std::size_t>(todo.size(), budget / slab));
-        if (const char* e = ensure_workspace(count, waves * slab))
+    if (call.mode != scratch_global_k) {
+        const std::uint64_t lds_bytes = lds_bytes_for(call.mode, call.next_cap, call.hash_cap);
+        const std::uint32_t grid = (std::uint32_t)std::min<std::uint64_t>(pending, (std::uint64_t)waves_for(lds_bytes) * compute_units_);
+        const std::uint64_t slab = call.mode == scratch_hash_k ? (std::uint64_t)call.hash_cap * 4 : 0;
+        if (const char* e = ws.reserve(call.count, slab * grid))
             return e;
-        for (std::size_t begin = 0; begin < todo.size(); begin += waves) {
-            const std::size_t chunk = std::min(waves, todo.size() - begin);
-            UA_HIP(hipMemcpyAsync(d_todo_, todo.data() + begin, chunk * 4, hipMemcpyHostToDevice, stream));
-            // only the bitmaps need zeroing
-            UA_HIP(hipMemset2DAsync(d_scratch_ + layout.visits, slab, 0, bitmap_bytes, chunk, stream));
-            args.hash_cap = 0;
-            args.next_cap = frontier;
-            args.todo = d_todo_;
-            args.count = (std::uint32_t)chunk;
-            args.scratch = d_scratch_;
-            args.scratch_stride = slab;
-            params.mode = scratch_global_k;
-            params.entries_per_lane = 0;
-            params.grid = (std::uint32_t)chunk;
-            params.lds_bytes = query_lds;
-            if (const char* e = timed_launch(params, args))
+        args.status = ws.d_status, args.peaks = ws.d_peaks;
+        args.hash_cap = call.hash_cap;
+        args.next_cap = call.next_cap;
+        args.todo = call.have_todo ? ws.d_todo : nullptr;
+        args.count = pending;
+        args.scratch = ws.d_scratch;
+        args.scratch_stride = slab;
+        args.wave_clock = nullptr;
+        if (call.want_clock && call.passes == 0) {
+            if (const char* e = ws.reserve_wave_clock(grid))
                 return e;
-            ++passes;
-            UA_HIP(hipStreamSynchronize(stream));
+            args.wave_clock = ws.d_wave_clock;
         }
-        UA_HIP(hipMemcpyAsync(h_status_, d_status_, count * 4, hipMemcpyDeviceToHost, stream));
-        UA_HIP(hipStreamSynchronize(stream));
-        for (std::uint32_t q : todo)
-            if (h_status_[q] != status_done_k)
-                return "Search scratch overflow in the global-memory pass";
+        params.mode = call.mode;
+        params.entries_per_lane = call.entries_per_lane;
+        params.grid = grid;
+        params.lds_bytes = (std::uint32_t)lds_bytes;
+        if (const char* e = timed_launch())
+            return e;
+        ++call.passes;
+        return nullptr;
     }
-    if (want_phases) {
+
+    // ---- last rung: global-memory scratch — exact sizes (one bit per slot, one frontier cell per slot), cannot overflow;
+    //      the reference's heap (a frontier in `top` needs `top` in registers)
+    if (!call.have_todo) {
+        call.todo.resize(call.count);
+        for (std::uint32_t q = 0; q < call.count; ++q)
+            call.todo[q] = q;
+        call.have_todo = true;
+    }
+    call.stats.retried_global = (std::uint32_t)call.todo.size();
+    const std::uint64_t bitmap_bytes = ((view_.size + 31) / 32) * 4;
+    const std::uint32_t frontier_cells = (std::uint32_t)std::min<std::uint64_t>(view_.size + 64, 0xFFFFFFF0u);
+    const scratch_layout_t layout = scratch_layout(ef, frontier_cells, bitmap_bytes);
+    const std::size_t slab = (layout.total + 255) & ~(std::size_t)255;
+    const std::size_t budget = env_size("USEARCH_AMD_GLOBAL_SCRATCH_BYTES", (std::size_t)2 << 30);
+    const std::size_t waves = std::max<std::size_t>(1, std::min<std::size_t>(call.todo.size(), budget / slab));
+    if (const char* e = ws.reserve(call.count, waves * slab))
+        return e;
+    for (std::size_t begin = 0; begin < call.todo.size(); begin += waves) {
+        const std::size_t chunk = std::min(waves, call.todo.size() - begin);
+        UA_HIP(hipMemcpyAsync(ws.d_todo, call.todo.data() + begin, chunk * 4, hipMemcpyHostToDevice, stream));
+        // only the bitmaps need zeroing
+        UA_HIP(hipMemset2DAsync(ws.d_scratch + layout.visits, slab, 0, bitmap_bytes, chunk, stream));
+        args.status = ws.d_status, args.peaks = ws.d_peaks;
+        args.hash_cap = 0;
+        args.next_cap = frontier_cells;
+        args.todo = ws.d_todo;
+        args.count = (std::uint32_t)chunk;
+        args.scratch = ws.d_scratch;
+        args.scratch_stride = slab;
+        args.wave_clock = nullptr;
+        params.mode = scratch_global_k;
+        params.entries_per_lane = 0;
+        params.frontier = frontier_heap_k;
+        params.grid = (std::uint32_t)chunk;
+        params.lds_bytes = call.query_lds;
+        if (const char* e = timed_launch())
+            return e;
+        ++call.passes;
+        UA_HIP(hipStreamSynchronize(stream)); // the todo block is reused by the next chunk
+    }
+    return nullptr;
+}
+
+const char* snapshot_t::search_finish(search_call_t& call, search_stats_t* stats) {
+    if (stats)
+        *stats = search_stats_t{};
+    if (!call.workspace)
+        return nullptr; // nothing was wanted
+    struct hand_back_t { // on every path out of here the workspace returns to the pool, unless the caller keeps it
+        snapshot_t& owner;
+        search_call_t& call;
+        ~hand_back_t() {
+            if (!call.keep_workspace)
+                owner.give_back(call.workspace);
+            call.workspace = nullptr;
+        }
+    } hand_back{*this, call};
+    workspace_t& ws = *call.workspace;
+    hipStream_t stream = call.stream;
+    UA_HIP(hipSetDevice(device_));
+    if (call.done) {
+        UA_HIP(hipStreamSynchronize(stream));
+        return nullptr;
+    }
+
+    const std::uint32_t first_grid = call.params.grid, first_lds = call.params.lds_bytes;
+    const int first_mode = call.params.mode;
+    // ---- the ladder: did any query outgrow its scratch? One 8-byte read-back answers that; the per-query status is only
+    //      fetched when the answer is yes. Second rung: visited set in the global hash, 4× the room for both structures.
+    //      Third rung: global-memory scratch of exact size.
+    for (int rung = 0;; ++rung) {
+        UA_HIP(hipMemcpyAsync(ws.h_status, ws.d_queue, 8, hipMemcpyDeviceToHost, stream));
+        UA_HIP(hipStreamSynchronize(stream));
+        if (call.params.mode == scratch_global_k) {
+            if (ws.h_status[1])
+                return "Search scratch overflow in the global-memory pass";
+            break;
+        }
+        if (!ws.h_status[1])
+            break;
+        UA_HIP(hipMemcpyAsync(ws.h_status + 16, ws.d_status, call.count * 4, hipMemcpyDeviceToHost, stream));
+        UA_HIP(hipStreamSynchronize(stream));
+        std::vector<std::uint32_t> again;
+        if (call.have_todo) {
+            for (std::uint32_t q : call.todo)
+                if (ws.h_status[16 + q] == status_overflow_k)
+                    again.push_back(q);
+        } else {
+            for (std::uint32_t q = 0; q < call.count; ++q)
+                if (ws.h_status[16 + q] == status_overflow_k)
+                    again.push_back(q);
+        }
+        call.todo.swap(again);
+        call.have_todo = true;
+        call.reran = true;
+        if (call.todo.empty())
+            break;
+        if (rung == 0) {
+            call.stats.retried_lds = (std::uint32_t)call.todo.size();
+            call.mode = scratch_hash_k;
+            call.hash_cap = std::min<std::uint32_t>(call.hash_cap * 4, pow2_ceil((std::uint32_t)std::min<std::uint64_t>(view_.size * 2 + 128, 1u << 30)));
+            if (call.next_cap) {
+                const std::uint32_t lds_budget = (std::uint32_t)env_size("USEARCH_AMD_LDS_BUDGET", 160 * 1024);
+                call.next_cap = (std::uint32_t)std::min<std::uint64_t>((std::uint64_t)call.next_cap * 4, view_.size + 64);
+                while (call.next_cap > 64 &&
+                       call.query_lds + scratch_layout(call.entries_per_lane ? 0 : call.ef, call.next_cap, 0).total > lds_budget)
+                    call.next_cap = call.next_cap * 3 / 4;
+            }
+        } else {
+            call.mode = scratch_global_k;
+        }
+        if (call.mode != scratch_global_k)
+            UA_HIP(hipMemcpyAsync(ws.d_todo, call.todo.data(), call.todo.size() * 4, hipMemcpyHostToDevice, stream));
+        if (const char* e = run_ladder(call))
+            return e;
+    }
+
+    if (call.want_phases) {
         unsigned long long ticks[16] = {0};
-        UA_HIP(hipMemcpy(ticks, args.phases, 128, hipMemcpyDeviceToHost));
+        UA_HIP(hipMemcpy(ticks, call.args.phases, 128, hipMemcpyDeviceToHost));
         double total = 0;
         for (int i = 0; i < 6; ++i)
             total += (double)ticks[i];
         std::fprintf(stderr, "[usearch_amd] phases ef=%u grid=%u: setup %.1f%% pop+list %.1f%% visited %.1f%% distances %.1f%% "
                              "commit %.1f%% [heap push %.1f%% top insert %.1f%%, %llu candidates rechecked] dump %.1f%% (%.3g ticks); "
                              "frontier pushes %llu, lists ready ahead %llu\n",
-                     ef, params.grid, 100 * ticks[0] / total, 100 * ticks[1] / total, 100 * ticks[2] / total,
+                     call.ef, first_grid, 100 * ticks[0] / total, 100 * ticks[1] / total, 100 * ticks[2] / total,
                      100 * ticks[3] / total, 100 * ticks[4] / total, 100 * ticks[8] / total, 100 * ticks[9] / total, ticks[10],
                      100 * ticks[5] / total, total, ticks[6], ticks[7]);
     }
-    if (stats) {
-        stats->passes = passes;
-        stats->kernel_ms = total_ms;
-        stats->mode = (std::uint32_t)mode + 1;
-        stats->grid = params.grid;
-        stats->lds_bytes = params.lds_bytes;
+    if (call.want_clock && ws.d_wave_clock && first_grid) {
+        // batch tail: between the first wave's start and the last wave's exit, how much wave-time was spent gone?
+        std::vector<unsigned long long> clock((std::size_t)first_grid * 2);
+        UA_HIP(hipMemcpy(clock.data(), ws.d_wave_clock, clock.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long first = ~0ull, last = 0;
+        for (std::uint32_t w = 0; w < first_grid; ++w)
+            first = std::min(first, clock[2 * w]), last = std::max(last, clock[2 * w + 1]);
+        double gone = 0;
+        for (std::uint32_t w = 0; w < first_grid; ++w)
+            gone += (double)(clock[2 * w] - first) + (double)(last - clock[2 * w + 1]);
+        const double span = (double)(last - first);
+        call.stats.tail_idle = span > 0 ? (float)(gone / (span * first_grid)) : 0.f;
+        call.stats.span_ms = (float)(span / 1e5); // 100 MHz
+        if (env_size("USEARCH_AMD_WAVE_CLOCK", 0) > 1) { // histogram of exit times, in tenths of the span
+            unsigned long long bins[10] = {0};
+            for (std::uint32_t w = 0; w < first_grid; ++w)
+                ++bins[std::min<std::size_t>(9, (std::size_t)(10.0 * (double)(clock[2 * w + 1] - first) / std::max(span, 1.0)))];
+            std::fprintf(stderr, "[usearch_amd] wave exits by tenth of the %.3f ms span (grid %u):", call.stats.span_ms, first_grid);
+            for (unsigned long long b : bins)
+                std::fprintf(stderr, " %llu", b);
+            std::fprintf(stderr, "; idle share %.4f\n", call.stats.tail_idle);
+        }
     }
-    last_count_ = count;
+    call.stats.passes = call.passes;
+    call.stats.kernel_ms = call.total_ms;
+    call.stats.mode = (std::uint32_t)first_mode + 1;
+    call.stats.grid = first_grid;
+    call.stats.lds_bytes = first_lds;
+    if (stats)
+        *stats = call.stats;
     return nullptr;
 }
 
+const char* snapshot_t::search_device(const void* queries, std::size_t count, std::size_t stride_bytes,
+                                      std::size_t wanted, std::size_t expansion, std::uint64_t* keys,
+                                      float* distances, std::uint64_t* counts, std::uint64_t* visited,
+                                      std::uint64_t* computed, hipStream_t stream, const search_tuning_t& tuning,
+                                      search_stats_t* stats, bool timed, const search_extras_t* extras) {
+    if (stats)
+        *stats = search_stats_t{};
+    search_call_t call;
+    const char* error = search_begin(call, queries, count, stride_bytes, wanted, expansion, keys, distances, counts, visited,
+                                     computed, stream, tuning, timed, extras);
+    if (error) {
+        if (call.workspace)
+            give_back(call.workspace);
+        return error;
+    }
+    return search_finish(call, stats);
+}
+
 const char* snapshot_t::last_peaks(std::uint32_t* out, std::size_t queries) {
-    std::lock_guard<std::mutex> lock(mutex_);
-    if (!d_peaks_ || queries > last_count_)
+    workspace_t* ws = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(pool_mutex_);
+        ws = last_used_;
+    }
+    if (!ws || !ws->d_peaks || queries > ws->last_count)
         return "No telemetry for that many queries";
     UA_HIP(hipSetDevice(device_));
-    UA_HIP(hipMemcpy(out, d_peaks_, queries * 8, hipMemcpyDeviceToHost));
+    UA_HIP(hipMemcpy(out, ws->d_peaks, queries * 8, hipMemcpyDeviceToHost));
     return nullptr;
 }
 
@@ -627,73 +876,106 @@ const char* snapshot_t::search_host(const void* queries, scalar_kind_t query_kin
         return nullptr;
     const std::size_t bpv = view_.bytes_per_vector ? view_.bytes_per_vector : bytes_per_vector(scalar_, view_.dimensions);
     const std::size_t dims = view_.dimensions;
+    if (query_kind != scalar_ && bytes_per_vector(query_kind, dims) == 0)
+        return "Unsupported query scalar kind";
+    const std::size_t source_bytes = query_kind != scalar_ ? bytes_per_vector(query_kind, dims) : bpv;
+    if (count > 1 && stride_bytes < source_bytes)
+        return "Query stride is smaller than one query";
 
-    // cast (or gather strided rows) into a dense host block in the storage kind — index_dense.hpp:2058-2064
-    std::vector<std::uint8_t> dense;
-    const std::uint8_t* source = static_cast<const std::uint8_t*>(queries);
-    if (query_kind != scalar_) {
-        const std::size_t query_bytes = bytes_per_vector(query_kind, dims);
-        if (query_bytes == 0)
-            return "Unsupported query scalar kind";
-        if (count > 1 && stride_bytes < query_bytes)
-            return "Query stride is smaller than one query";
-        dense.assign(count * bpv, 0);
-        parallel_ranges(count, [&](std::uint64_t begin, std::uint64_t end) {
-            for (std::uint64_t q = begin; q < end; ++q)
-                cast_vector(query_kind, scalar_, source + q * stride_bytes, dims, dense.data() + q * bpv);
-        });
-        source = dense.data();
-    } else if (count > 1 && stride_bytes != bpv) {
-        if (stride_bytes < bpv)
-            return "Query stride is smaller than one query";
-        dense.resize(count * bpv);
-        parallel_ranges(count, [&](std::uint64_t begin, std::uint64_t end) {
-            for (std::uint64_t q = begin; q < end; ++q)
-                std::memcpy(dense.data() + q * bpv, source + q * stride_bytes, bpv);
-        });
-        source = dense.data();
-    }
-
-    std::lock_guard<std::mutex> host_lock(host_mutex_); // the staging block below is shared
-    UA_HIP(hipSetDevice(device_));
-    if (const char* e = ensure_staging(bpv, count, wanted))
-        return e;
+    // One block on the device — queries | keys | distances | counts | visited | computed | predicate bits — mirrored by one
+    // pinned block on the host: one upload, one launch, one download, one wait per call.
     auto pad = [](std::size_t b) { return (b + 255) & ~(std::size_t)255; };
-    std::uint8_t* d_queries = d_stage_;
-    std::uint64_t* d_keys = reinterpret_cast<std::uint64_t*>(d_queries + pad(bpv * count));
-    float* d_distances = reinterpret_cast<float*>(reinterpret_cast<std::uint8_t*>(d_keys) + pad(count * wanted * 8));
-    std::uint64_t* d_counts = reinterpret_cast<std::uint64_t*>(reinterpret_cast<std::uint8_t*>(d_distances) + pad(count * wanted * 4));
-    std::uint64_t* d_visited = reinterpret_cast<std::uint64_t*>(reinterpret_cast<std::uint8_t*>(d_counts) + pad(count * 8));
-    std::uint64_t* d_computed = reinterpret_cast<std::uint64_t*>(reinterpret_cast<std::uint8_t*>(d_visited) + pad(count * 8));
-
-    UA_HIP(hipMemcpy(d_queries, source, bpv * count, hipMemcpyHostToDevice));
-    search_extras_t extras = more ? *more : search_extras_t{};
-    std::uint32_t* d_allow = nullptr;
-    if (allow_bits_host && view_.size) {
-        const std::size_t words = (view_.size + 31) / 32;
-        UA_HIP(hipMalloc((void**)&d_allow, words * 4));
-        if (hipMemcpy(d_allow, allow_bits_host, words * 4, hipMemcpyHostToDevice) != hipSuccess) {
-            (void)hipFree(d_allow);
-            return "Failed to upload the predicate bitmap";
-        }
-        extras.allow_bits = d_allow;
+    const std::size_t allow_words = allow_bits_host && view_.size ? (view_.size + 31) / 32 : 0;
+    const std::size_t o_keys = pad(bpv * count), o_distances = o_keys + pad(count * wanted * 8),
+                      o_counts = o_distances + pad(count * wanted * 4), o_visited = o_counts + pad(count * 8),
+                      o_computed = o_visited + pad(count * 8), o_allow = o_computed + pad(count * 8),
+                      total = o_allow + pad(allow_words * 4);
+    UA_HIP(hipSetDevice(device_));
+    search_call_t call;
+    // the lease is taken here (not inside search_begin) because the staging blocks live in the workspace
+    if (const char* e = take(call.workspace))
+        return e;
+    workspace_t& ws = *call.workspace;
+    if (const char* e = ws.reserve_stage(total, o_allow)) {
+        give_back(call.workspace);
+        return e;
     }
-    const char* search_error = search_device(d_queries, count, bpv, wanted, expansion, d_keys, d_distances, d_counts,
-                                             d_visited, d_computed, nullptr, tuning, stats, false, &extras);
-    if (d_allow)
-        (void)hipFree(d_allow);
-    if (search_error)
-        return search_error;
+
+    // cast (or gather strided rows) straight into the pinned block, in the storage kind — index_dense.hpp:2058-2064
+    const std::uint8_t* source = static_cast<const std::uint8_t*>(queries);
+    auto fill = [&](std::uint64_t begin, std::uint64_t end) {
+        for (std::uint64_t q = begin; q < end; ++q) {
+            std::uint8_t* row = ws.h_stage + q * bpv;
+            if (query_kind == scalar_ || !cast_vector(query_kind, scalar_, source + q * stride_bytes, dims, row))
+                std::memcpy(row, source + q * stride_bytes, bpv);
+        }
+    };
+    if (count >= 256)
+        parallel_ranges(count, fill);
+    else
+        fill(0, count);
+
+    hipStream_t stream = ws.stream;
+    UA_HIP(hipMemcpyAsync(ws.d_stage, ws.h_stage, bpv * count, hipMemcpyHostToDevice, stream));
+    search_extras_t extras = more ? *more : search_extras_t{};
+    if (allow_words) {
+        UA_HIP(hipMemcpyAsync(ws.d_stage + o_allow, allow_bits_host, allow_words * 4, hipMemcpyHostToDevice, stream));
+        extras.allow_bits = reinterpret_cast<const std::uint32_t*>(ws.d_stage + o_allow);
+    }
+    std::uint64_t* d_keys = reinterpret_cast<std::uint64_t*>(ws.d_stage + o_keys);
+    float* d_distances = reinterpret_cast<float*>(ws.d_stage + o_distances);
+    std::uint64_t* d_counts = reinterpret_cast<std::uint64_t*>(ws.d_stage + o_counts);
+    std::uint64_t* d_visited = reinterpret_cast<std::uint64_t*>(ws.d_stage + o_visited);
+    std::uint64_t* d_computed = reinterpret_cast<std::uint64_t*>(ws.d_stage + o_computed);
+
+    // `call` already holds the workspace: search_begin uses it instead of leasing another one
+    if (const char* e = search_begin(call, ws.d_stage, count, bpv, wanted, expansion, d_keys, d_distances, d_counts, d_visited,
+                                     d_computed, stream, tuning, false, &extras)) {
+        give_back(call.workspace);
+        return e;
+    }
+    // results ride home behind the first launch; if a rung of the ladder re-runs queries they are fetched again
+    auto download = [&]() -> const char* {
+        UA_HIP(hipMemcpyAsync(ws.h_stage + o_keys, ws.d_stage + o_keys, o_allow - o_keys, hipMemcpyDeviceToHost, stream));
+        return nullptr;
+    };
+    if (const char* e = download())
+        return e;
+    workspace_t* leased = call.workspace;
+    {
+        // keep the workspace across search_finish (which gives it back): the pinned block is still to be read. Finish
+        // works on a call without a workspace of its own only when nothing was launched, so take the lease over here.
+        search_stats_t local;
+        // search_finish returns the workspace to the pool; copying out of the pinned block must happen before that, so the
+        // finish is split: wait + ladder first (workspace retained), hand-back last.
+        call.keep_workspace = true;
+        if (const char* e = search_finish(call, &local)) {
+            give_back(leased);
+            return e;
+        }
+        if (stats)
+            *stats = local;
+        if (call.reran) {
+            const char* e = download();
+            if (!e && hipStreamSynchronize(stream) != hipSuccess)
+                e = "Failed to fetch the results";
+            if (e) {
+                give_back(leased);
+                return e;
+            }
+        }
+    }
     if (keys)
-        UA_HIP(hipMemcpy(keys, d_keys, count * wanted * 8, hipMemcpyDeviceToHost));
+        std::memcpy(keys, ws.h_stage + o_keys, count * wanted * 8);
     if (distances)
-        UA_HIP(hipMemcpy(distances, d_distances, count * wanted * 4, hipMemcpyDeviceToHost));
+        std::memcpy(distances, ws.h_stage + o_distances, count * wanted * 4);
     if (counts)
-        UA_HIP(hipMemcpy(counts, d_counts, count * 8, hipMemcpyDeviceToHost));
+        std::memcpy(counts, ws.h_stage + o_counts, count * 8);
     if (visited)
-        UA_HIP(hipMemcpy(visited, d_visited, count * 8, hipMemcpyDeviceToHost));
+        std::memcpy(visited, ws.h_stage + o_visited, count * 8);
     if (computed)
-        UA_HIP(hipMemcpy(computed, d_computed, count * 8, hipMemcpyDeviceToHost));
+        std::memcpy(computed, ws.h_stage + o_computed, count * 8);
+    give_back(leased);
     return nullptr;
 }
 
@@ -802,10 +1084,15 @@ const char* exact_search_device(metric_kind_t metric, scalar_kind_t scalar, std:
 const char* snapshot_t::exact_device(const void* queries, std::size_t count, std::size_t stride_bytes,
                                      std::size_t wanted, std::uint64_t* keys, float* distances, std::uint64_t* counts,
                                      hipStream_t stream, float* kernel_ms) {
-    std::lock_guard<std::mutex> lock(mutex_);
     UA_HIP(hipSetDevice(device_));
+    lease_t lease(*this);
+    if (!stream) {
+        if (const char* e = lease.take())
+            return e;
+        stream = lease.workspace->stream;
+    }
     return exact_search_device(metric_, scalar_, lanes_, view_, queries, count, stride_bytes, wanted, true, keys,
-                               distances, counts, stream ? stream : stream_, kernel_ms);
+                               distances, counts, stream, kernel_ms);
 }
 
 const char* snapshot_t::exact_host(const void* queries, scalar_kind_t query_kind, std::size_t count,
@@ -823,17 +1110,21 @@ const char* snapshot_t::exact_host(const void* queries, scalar_kind_t query_kind
             if (!cast_vector(query_kind, scalar_, source + q * stride_bytes, dims, dense.data() + q * bpv))
                 std::memcpy(dense.data() + q * bpv, source + q * stride_bytes, bpv);
     });
-    std::lock_guard<std::mutex> host_lock(host_mutex_);
     UA_HIP(hipSetDevice(device_));
-    if (const char* e = ensure_staging(bpv, count, wanted))
+    lease_t lease(*this);
+    if (const char* e = lease.take())
         return e;
+    workspace_t& ws = *lease.workspace;
     auto pad = [](std::size_t b) { return (b + 255) & ~(std::size_t)255; };
-    std::uint8_t* d_queries = d_stage_;
+    if (const char* e = ws.reserve_stage(pad(bpv * count) + pad(count * wanted * 8) + pad(count * wanted * 4) + pad(count * 8), 0))
+        return e;
+    std::uint8_t* d_queries = ws.d_stage;
     std::uint64_t* d_keys = reinterpret_cast<std::uint64_t*>(d_queries + pad(bpv * count));
     float* d_distances = reinterpret_cast<float*>(reinterpret_cast<std::uint8_t*>(d_keys) + pad(count * wanted * 8));
     std::uint64_t* d_counts = reinterpret_cast<std::uint64_t*>(reinterpret_cast<std::uint8_t*>(d_distances) + pad(count * wanted * 4));
     UA_HIP(hipMemcpy(d_queries, dense.data(), bpv * count, hipMemcpyHostToDevice));
-    if (const char* e = exact_device(d_queries, count, bpv, wanted, d_keys, d_distances, d_counts, nullptr, kernel_ms))
+    if (const char* e = exact_search_device(metric_, scalar_, lanes_, view_, d_queries, count, bpv, wanted, true, d_keys,
+                                            d_distances, d_counts, ws.stream, kernel_ms))
         return e;
     if (keys)
         UA_HIP(hipMemcpy(keys, d_keys, count * wanted * 8, hipMemcpyDeviceToHost));
@@ -858,8 +1149,8 @@ const char* exact_search_dataset_host(metric_kind_t metric, scalar_kind_t scalar
     const std::size_t bpv = bytes_per_vector(scalar, dimensions);
     if (dataset_stride < bpv || queries_stride < bpv)
         return "Stride is smaller than one vector";
-    std::uint32_t lanes = 1, row_stride = 16;
-    row_geometry(bpv, lanes, row_stride);
+    std::uint32_t lanes = 1, row_stride = 16, row_chunks = 1;
+    row_geometry(bpv, lanes, row_stride, row_chunks);
     std::uint8_t *d_rows = nullptr, *d_queries = nullptr;
     std::uint64_t *d_keys = nullptr, *d_counts = nullptr;
     float* d_distances = nullptr;
@@ -885,7 +1176,7 @@ const char* exact_search_dataset_host(metric_kind_t metric, scalar_kind_t scalar
         view.vectors = d_rows;
         view.size = dataset_count;
         view.row_stride = row_stride;
-        view.chunks = row_stride / 16;
+        view.chunks = row_chunks;
         view.bytes_per_vector = (std::uint32_t)bpv;
         view.dimensions = (std::uint32_t)dimensions;
         error = exact_search_device(metric, scalar, lanes, view, d_queries, queries_count, bpv, wanted, false, d_keys,
@@ -915,8 +1206,12 @@ const char* snapshot_t::distances_host(const void* queries, std::size_t count, s
                                        const std::uint32_t* slots, std::size_t slots_per_query, float* out) {
     if (!count || !slots_per_query)
         return nullptr;
-    std::lock_guard<std::mutex> lock(mutex_);
     UA_HIP(hipSetDevice(device_));
+    lease_t lease(*this);
+    if (const char* e = lease.take())
+        return e;
+    hipStream_t stream_ = lease.workspace->stream;
+    hipEvent_t event_begin_ = lease.workspace->event_begin, event_end_ = lease.workspace->event_end;
     const std::size_t bpv = view_.bytes_per_vector;
     std::uint8_t* d_queries = nullptr;
     std::uint32_t* d_slots = nullptr;

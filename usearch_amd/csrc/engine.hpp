@@ -9,7 +9,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdint>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -26,6 +28,9 @@ struct search_tuning_t {
     std::uint32_t mode = 0;         ///< 0 = auto, 1 = visited set in LDS, 2 = visited set in a global hash, 3 = all-global fallback
     std::uint32_t waves_per_cu = 0; ///< persistent waves per compute unit (0 = as many as LDS / registers admit)
     std::uint32_t top_in_memory = 0; ///< 1 = keep `top` in scratch memory even when it would fit registers
+    std::uint32_t frontier = 0;     ///< 0 = auto, 1 = the reference's heap (its pop order among equal distances), 2 = the open
+                                    ///< cells of `top` (kernels.hpp frontier_top_k; refused where it does not apply)
+    std::uint32_t wave_clock = 0;   ///< 1 = record every persistent wave's start / exit time (batch-tail telemetry)
 };
 
 struct search_stats_t {
@@ -36,6 +41,11 @@ struct search_stats_t {
     std::uint32_t mode = 0;              ///< scratch mode of the last launch (1 = LDS, 2 = global hash, 3 = all global)
     std::uint32_t grid = 0;              ///< persistent waves of the last launch
     std::uint32_t lds_bytes = 0;         ///< LDS per wave of the last launch
+    std::uint32_t frontier = 0;          ///< 1 = heap, 2 = open cells of `top` (first launch)
+    std::uint32_t variant = 0;           ///< 1 + kernel_variant_t of the first launch
+    float tail_idle = 0.f;               ///< with `wave_clock`: share of wave-time between the first start and the last exit
+                                         ///< that waves spent gone (the drain phase of the batch), first launch
+    float span_ms = 0.f;                 ///< with `wave_clock`: first start → last exit on the device's 100-MHz clock
 };
 
 /// What index construction asks of the search on top of a plain query batch (see search_args_t).
@@ -45,6 +55,51 @@ struct search_extras_t {
     bool emit_slots = false;                  ///< slots instead of keys in the `keys` output
     bool descent_only = false;                ///< `cluster`: the greedy descent to `beam_level` alone, one result per query
     const std::uint32_t* allow_bits = nullptr; ///< device: one bit per slot, 0 = rejected by the caller's predicate
+    bool reference_frontier = false;          ///< keep the reference's heap whatever the pair (index construction does)
+};
+
+/// Per-scalar-kind launchers, one translation unit each (compile time): defined in search_<kind>.hip.
+struct launch_params_t {
+    metric_kind_t metric;
+    std::uint32_t lanes;
+    int variant; ///< kernel_variant_t of kernels.hpp
+    int mode;    ///< scratch_mode_t of kernels.hpp
+    std::uint32_t entries_per_lane; ///< `top` in registers: 1, 4, 8 or 16 entries per lane; 0 = in scratch memory
+    int frontier;                   ///< frontier_mode_t of kernels.hpp
+    std::uint32_t grid;
+    std::uint32_t lds_bytes;
+    hipStream_t stream;
+};
+
+/**
+ *  Everything ONE in-flight batch needs besides the immutable snapshot: a stream, the ticket counter, per-query status,
+ *  scratch slabs, and the device + pinned-host staging of the host-buffer entry points. A snapshot keeps a small pool of
+ *  these, so that concurrent callers (the reference leases one `context_t` per thread, index_dense.hpp:1984-2000) run
+ *  side by side instead of queueing on one mutex.
+ */
+struct workspace_t {
+    hipStream_t stream = nullptr;
+    hipEvent_t event_begin = nullptr, event_end = nullptr;
+    std::uint32_t* d_status = nullptr;
+    std::uint32_t* d_todo = nullptr;
+    std::uint32_t* d_queue = nullptr; ///< 256-byte block: [0] ticket counter, [1] overflowed queries, [16…] phase clock
+    std::uint32_t* d_peaks = nullptr;
+    std::uint32_t* h_status = nullptr; ///< pinned: [0..1] copy of the queue block's counters, then per-query status
+    std::size_t queries = 0;
+    std::uint8_t* d_scratch = nullptr;
+    std::size_t scratch_bytes = 0;
+    unsigned long long* d_wave_clock = nullptr;
+    std::size_t wave_clock_waves = 0;
+    std::uint8_t* d_stage = nullptr; ///< host-buffer API: queries | keys | distances | counts | visited | computed [| allow bits]
+    std::uint8_t* h_stage = nullptr; ///< pinned mirror of the result part
+    std::size_t stage_bytes = 0, host_stage_bytes = 0;
+    std::size_t last_count = 0;
+
+    const char* create();
+    const char* reserve(std::size_t queries_wanted, std::size_t scratch_wanted);
+    const char* reserve_stage(std::size_t device_bytes, std::size_t host_bytes);
+    const char* reserve_wave_clock(std::size_t waves);
+    void destroy();
 };
 
 class snapshot_t {
@@ -69,13 +124,42 @@ class snapshot_t {
 
     /**
      *  Batched search, all pointers device-resident, queries already in the storage scalar kind.
-     *  Enqueues on `stream` and waits for it (the retry ladder needs the per-query status).
+     *  Enqueues on `stream` (the leased workspace's own when null) and waits for it: the retry ladder needs to know
+     *  whether any query outgrew its scratch (one 8-byte read-back).
      */
     const char* search_device(const void* queries, std::size_t count, std::size_t stride_bytes, std::size_t wanted,
                               std::size_t expansion, std::uint64_t* keys, float* distances, std::uint64_t* counts,
                               std::uint64_t* visited, std::uint64_t* computed, hipStream_t stream,
                               const search_tuning_t& tuning, search_stats_t* stats, bool timed,
                               const search_extras_t* extras = nullptr);
+
+    /**
+     *  The same search in two halves, for callers that append their own work to the stream before anybody waits (the
+     *  sharded step: search → all-gather → merge, one stream, one wait): `search_begin` sizes the scratch, leases a
+     *  workspace and launches; `search_finish` waits, and re-runs what outgrew its scratch (`reran` tells the caller that
+     *  outputs changed after its appended work read them). A call object is used once.
+     */
+    struct search_call_t {
+        workspace_t* workspace = nullptr;
+        hipStream_t stream = nullptr;
+        search_args_t args{};
+        launch_params_t params{};
+        std::size_t count = 0;
+        std::uint32_t ef = 0, hash_cap = 0, next_cap = 0, query_lds = 0, entries_per_lane = 0, waves_cap = 0;
+        int mode = 0;
+        bool timed = false, want_phases = false, want_clock = false, done = false, reran = false;
+        bool keep_workspace = false; ///< search_finish leaves the workspace with the caller (who gives it back)
+        float total_ms = 0.f;
+        std::uint32_t passes = 0;
+        search_stats_t stats{};
+        std::vector<std::uint32_t> todo;
+        bool have_todo = false;
+    };
+    const char* search_begin(search_call_t& call, const void* queries, std::size_t count, std::size_t stride_bytes,
+                             std::size_t wanted, std::size_t expansion, std::uint64_t* keys, float* distances,
+                             std::uint64_t* counts, std::uint64_t* visited, std::uint64_t* computed, hipStream_t stream,
+                             const search_tuning_t& tuning, bool timed, const search_extras_t* extras = nullptr);
+    const char* search_finish(search_call_t& call, search_stats_t* stats);
 
     /**
      *  Construction support (build.hip): allocates the HBM arrays of an index of `capacity` nodes whose levels are
@@ -95,6 +179,10 @@ class snapshot_t {
     std::uint32_t* mutable_upper() { return static_cast<std::uint32_t*>(d_upper_); }
     hipStream_t stream() const { return stream_; }
     int compute_units() const { return compute_units_; }
+
+    /// How many batches may be in flight at once (`usearch_change_threads_search`): the size of the workspace pool.
+    void set_concurrency(std::size_t workspaces);
+    std::size_t concurrency() const { return max_workspaces_; }
 
     /// Same with host buffers and a query scalar kind that may differ from the storage kind (cast first).
     const char* search_host(const void* queries, scalar_kind_t query_kind, std::size_t count, std::size_t stride_bytes,
@@ -126,9 +214,22 @@ class snapshot_t {
     const char* distances_host(const void* queries, std::size_t count, std::size_t stride_bytes,
                                const std::uint32_t* slots, std::size_t slots_per_query, float* out);
 
+    /// Leases a workspace (waits while `concurrency()` of them are out); `give_back` returns it. RAII: `lease_t`.
+    const char* take(workspace_t*& out);
+    void give_back(workspace_t* workspace);
+    struct lease_t {
+        snapshot_t& owner;
+        workspace_t* workspace = nullptr;
+        explicit lease_t(snapshot_t& s) : owner(s) {}
+        ~lease_t() {
+            if (workspace)
+                owner.give_back(workspace);
+        }
+        const char* take() { return owner.take(workspace); }
+    };
+
   private:
-    const char* ensure_workspace(std::size_t queries, std::size_t scratch_bytes);
-    const char* ensure_staging(std::size_t query_bytes, std::size_t count, std::size_t wanted);
+    const char* run_ladder(search_call_t& call);
     void release();
 
     snapshot_view_t view_{};
@@ -145,36 +246,18 @@ class snapshot_t {
     void* d_upper_ = nullptr;
     void* d_keys_ = nullptr;
 
-    std::mutex mutex_;      ///< one batch at a time per snapshot: the workspace below is shared
-    std::mutex host_mutex_; ///< serialises `search_host` callers around the staging block
-    std::uint32_t* d_status_ = nullptr;
-    std::uint32_t* d_todo_ = nullptr;
-    std::uint32_t* d_queue_ = nullptr;
-    std::uint32_t* d_peaks_ = nullptr;
     int compute_units_ = 256;
     float last_distances_ms_ = 0.f;
-    std::uint32_t* h_status_ = nullptr; ///< pinned
-    std::size_t workspace_queries_ = 0, last_count_ = 0;
-    std::uint8_t* d_scratch_ = nullptr;
-    std::size_t scratch_bytes_ = 0;
-    // staging for search_host
-    std::uint8_t* d_stage_ = nullptr;
-    std::size_t stage_bytes_ = 0;
-    hipStream_t stream_ = nullptr;
-    hipEvent_t event_begin_ = nullptr, event_end_ = nullptr;
+    hipStream_t stream_ = nullptr; ///< the snapshot's own stream: construction and one-off kernels
+
+    std::mutex pool_mutex_; ///< guards the pool below, never held while a batch runs
+    std::condition_variable pool_ready_;
+    std::vector<std::unique_ptr<workspace_t>> workspaces_;
+    std::vector<workspace_t*> idle_;
+    workspace_t* last_used_ = nullptr;
+    std::size_t max_workspaces_ = 16;
 };
 
-/// Per-scalar-kind launchers, one translation unit each (compile time): defined in search_<kind>.hip.
-struct launch_params_t {
-    metric_kind_t metric;
-    std::uint32_t lanes;
-    int variant; ///< kernel_variant_t of kernels.hpp
-    int mode;    ///< scratch_mode_t of kernels.hpp
-    std::uint32_t entries_per_lane; ///< `top` in registers: 1, 4 or 8 entries per lane; 0 = in scratch memory
-    std::uint32_t grid;
-    std::uint32_t lds_bytes;
-    hipStream_t stream;
-};
 #define USEARCH_AMD_DECLARE_LAUNCHERS(name)                                                                            \
     hipError_t launch_search_##name(const launch_params_t&, const snapshot_view_t&, const search_args_t&);            \
     hipError_t launch_distances_##name(const struct distances_params_t&, const snapshot_view_t&);                     \
@@ -268,8 +351,9 @@ const char* exact_search_dataset_host(metric_kind_t metric, scalar_kind_t scalar
                                       std::size_t wanted, std::uint64_t* keys, std::size_t keys_stride,
                                       float* distances, std::size_t distances_stride);
 
-/// Lanes per stored row and padded row stride for rows of `bytes` bytes (the summation layout of DESIGN.md §3.3).
-void row_geometry(std::size_t bytes, std::uint32_t& lanes, std::uint32_t& row_stride);
+/// Lanes per stored row, the row pitch and the 16-byte chunks the kernels read of a row of `bytes` bytes (the summation layout
+/// of DESIGN.md §3.3; the pitch may exceed chunks × 16 so that short rows never straddle a 128-byte line).
+void row_geometry(std::size_t bytes, std::uint32_t& lanes, std::uint32_t& row_stride, std::uint32_t& chunks);
 
 /// Exchange step of sharded search (merge.hip): [shards][queries][wanted] per-shard results → [queries][wanted], device
 /// pointers, `merge_into` tie rule with shards merged in index order. Returns after the stream has drained.
@@ -277,6 +361,14 @@ const char* merge_shards_device(const float* distances, const std::uint64_t* key
                                 std::size_t shards, std::size_t queries, std::size_t wanted, float* out_distances,
                                 std::uint64_t* out_keys, std::uint64_t* out_counts, hipStream_t stream,
                                 bool later_position_first = true);
+
+/// The same merge without the wait, shards `*_stride` ELEMENTS apart (a packed all-gather block keeps the three arrays of one
+/// shard together, so the strides differ from the dense [shards][queries][wanted] case).
+const char* merge_shards_enqueue(const float* distances, const std::uint64_t* keys, const std::uint64_t* counts,
+                                 std::uint64_t distances_stride, std::uint64_t keys_stride, std::uint64_t counts_stride,
+                                 std::size_t shards, std::size_t queries, std::size_t wanted, float* out_distances,
+                                 std::uint64_t* out_keys, std::uint64_t* out_counts, hipStream_t stream,
+                                 bool later_position_first = true);
 
 /// Is there a HIP kernel for this (metric, scalar) pair?
 bool kernel_available(metric_kind_t metric, scalar_kind_t scalar);

@@ -350,8 +350,12 @@ UA_DEVICE float lane_below_f32(float v) {
  *    epl_ak == 0  in scratch memory (LDS, or the global slab of the fallback mode): any expansion.
  *  Same observable behaviour as sorted_buffer_gt (index.hpp:845-956) either way.
  */
-template <int epl_ak, bool global_ak> struct top_gt {
+template <int epl_ak, bool global_ak, bool flags_ak = false> struct top_gt {
     static constexpr int regs_k = epl_ak > 0 ? epl_ak : 1;
+    static_assert(!flags_ak || epl_ak > 0, "the frontier flags ride in the register layout only");
+    /// flags_ak: bit 31 of a cell's slot word says "closed" — the member was already expanded (or the cell is padding); the
+    /// open cells ARE the traversal's frontier (see `search_one`, frontier_top_k). Slots are < 2^31 in that mode.
+    static constexpr std::uint32_t closed_bit_k = 0x80000000u;
     // plain arrays that are only ever indexed by compile-time constants (every loop over them is fully unrolled): SROA turns
     // each cell into its own SSA value
     float d[regs_k];
@@ -421,6 +425,41 @@ template <int epl_ak, bool global_ak> struct top_gt {
         }
     }
 
+    /**
+     *  The closest member that has not been expanded yet: the first open cell of the ascending array. Every lane finds its own
+     *  first open cell with straight-line selects, one ballot names the lowest lane that has one.
+     *  Returns false when every kept member has been expanded — the traversal is over.
+     */
+    UA_DEVICE bool first_open(float& distance, std::uint32_t& slot, std::uint32_t& owner_lane, std::uint32_t& owner_cell) const {
+        static_assert(flags_ak, "frontier flags are not compiled into this layout");
+        std::uint32_t my_cell = (std::uint32_t)regs_k, my_slot = 0;
+        float my_distance = 0.f;
+#pragma unroll
+        for (int i = regs_k - 1; i >= 0; --i) {
+            const bool open = (s[i] & closed_bit_k) == 0;
+            my_cell = open ? (std::uint32_t)i : my_cell;
+            my_slot = open ? s[i] : my_slot;
+            my_distance = open ? d[i] : my_distance;
+        }
+        const std::uint64_t owners = ballot(my_cell < (std::uint32_t)regs_k);
+        if (!owners)
+            return false;
+        owner_lane = (std::uint32_t)__ffsll((long long)owners) - 1;
+        distance = read_lane_f32(my_distance, owner_lane);
+        slot = read_lane_u32(my_slot, owner_lane);
+        owner_cell = read_lane_u32(my_cell, owner_lane);
+        return true;
+    }
+
+    /// Marks cell `owner_cell` of lane `owner_lane` as expanded.
+    UA_DEVICE void close(std::uint32_t owner_lane, std::uint32_t owner_cell) {
+        static_assert(flags_ak, "frontier flags are not compiled into this layout");
+        const bool mine = lane_id() == owner_lane;
+#pragma unroll
+        for (int i = 0; i < regs_k; ++i)
+            s[i] |= (mine && owner_cell == (std::uint32_t)i) ? closed_bit_k : 0u;
+    }
+
     /// top.top() — the worst kept distance (index.hpp:891). Requires size > 0. (Scratch-memory layout only.)
     UA_DEVICE float worst() const {
         return uniform_f32(cand_distance(scratch_gt<global_ak>::load(cells + (size - 1))));
@@ -448,7 +487,7 @@ template <int epl_ak, bool global_ak> struct top_gt {
             for (int i = 0; i < epl_ak; ++i) {
                 const std::uint32_t g = lane_id() * epl_ak + i;
                 const float distance = d[i];
-                const std::uint32_t slot = s[i];
+                const std::uint32_t slot = flags_ak ? (s[i] & ~closed_bit_k) : s[i];
                 if (g < wanted) {
                     keys[g] = g < found ? (args.emit_slots ? (std::uint64_t)slot : ix.keys[slot]) : 0;
                     bits[g] = g < found ? __builtin_bit_cast(std::uint32_t, distance) : signaling_nan_bits_k;
@@ -475,6 +514,26 @@ enum scratch_mode_t : int {
     scratch_hash_k = 1,   ///< top, next in LDS; visits = open-addressing hash in a per-wave global slab (L2/MALL resident)
     scratch_global_k = 2, ///< everything in a per-wave global slab, visits = one bit per slot: cannot overflow (fallback)
 };
+
+/**
+ *  What holds the traversal's frontier (`next` of index.hpp:4176-4246).
+ *
+ *  frontier_heap_k  the reference's container: a binary max-heap on the negated distance (index.hpp:664-835) in scratch
+ *                   memory, never pruned. Pop order among EQUAL distances is the reference's. At expansion ≈ 600 it holds
+ *                   ≈ 1 100 entries (peaks at 3-4 × expansion) of which 25 % can still be popped.
+ *  frontier_top_k   no container at all. A candidate enters `next` and `top` in the same breath (index.hpp:4233-4240), and an
+ *                   entry that `top` has evicted is farther than the radius for good (the radius never grows), so the loop
+ *                   `pop the closest of next; stop when it is farther than the radius` only ever expands members that are
+ *                   still in `top`: the frontier IS the not-yet-expanded part of `top`. One flag bit per `top` cell replaces
+ *                   the 16-KB heap, "pop" is a handful of register selects and a ballot. Same hops in the same order, same
+ *                   counters, same results as the heap whenever the distances that meet in the frontier are distinct; two
+ *                   members at exactly the same distance may be expanded in the other order than the reference's heap would
+ *                   (and a member evicted from a full `top` at exactly the radius is not expanded, where the reference's strict
+ *                   `>` of index.hpp:4210 still would). Requires every member to be a result candidate (no predicate, no
+ *                   tombstones: a rejected member is traversed without entering `top`) and slots < 2^31. The engine uses it
+ *                   for the float-valued pairs; the integer-valued ones (b1, i8), where ties are the norm, keep the heap.
+ */
+enum frontier_mode_t : int { frontier_heap_k = 0, frontier_top_k = 1 };
 
 /// Returns true for lanes whose `slot` was NOT in the set before (and now is). Inactive lanes return false.
 template <int mode_ak>
@@ -977,15 +1036,17 @@ template <int scalar_ak> inline __host__ __device__ std::uint32_t query_lds_byte
  *  One query, start to finish. `heaps` = top/next/candidate arrays (LDS, or the slab in `scratch_global_k`), `visits` = the
  *  visited set (LDS hash, slab hash or slab bitmap). Returns false on scratch overflow (nothing written but `status`).
  */
-template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, int mode_ak, int epl_ak>
+template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, int mode_ak, int epl_ak, int frontier_ak>
 UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, std::uint32_t q,
                           std::uint8_t* query_lds, std::uint8_t* heaps, std::uint32_t* visits) {
     constexpr bool global_ak = mode_ak == scratch_global_k;
+    constexpr bool in_top_ak = frontier_ak == frontier_top_k;
+    static_assert(!in_top_ak || (epl_ak > 0 && !global_ak), "the frontier rides in the register layout of `top`");
     using mem = scratch_gt<global_ak>;
     const std::uint32_t lane = lane_id();
     const std::uint32_t ef = args.ef, wanted = args.wanted;
-    const scratch_layout_t layout = scratch_layout(epl_ak ? 0 : ef, args.next_cap, 0);
-    top_gt<epl_ak, global_ak> top;
+    const scratch_layout_t layout = scratch_layout(epl_ak ? 0 : ef, in_top_ak ? 0 : args.next_cap, 0);
+    top_gt<epl_ak, global_ak, in_top_ak> top;
     top.reset(reinterpret_cast<cand_t*>(heaps + layout.top));
     cand_t* next = reinterpret_cast<cand_t*>(heaps + layout.next);
     std::uint32_t* cand_slots = reinterpret_cast<std::uint32_t*>(heaps + layout.cand_slots);
@@ -1109,10 +1170,11 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
         }
         return true;
     }
-    heap_push<global_ak>(next, next_size, -radius, closest);
+    if constexpr (!in_top_ak)
+        heap_push<global_ak>(next, next_size, -radius, closest);
     visits_set<mode_ak>(visits, visits_mask, closest, lane == 0);
     visits_count = 1;
-    if (allowed(closest)) {
+    if (in_top_ak || allowed(closest)) {
         float first_radius = radius;
         top.insert(radius, closest, ef, first_radius);
     }
@@ -1124,13 +1186,25 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     };
     std::uint32_t ahead_slot = none_slot_k, ahead_cell = none_slot_k; // list tile requested ahead of its hop
     tick(0);
-    while (next_size) {
-        const cand_t candidate = mem::load(next);
-        const float candidate_distance = -uniform_f32(cand_distance(candidate));
-        if (candidate_distance > radius && top.size == ef) // index.hpp:4210, strict `>`
-            break;
+    for (;;) {
+        std::uint32_t expanded;
+        if constexpr (in_top_ak) {
+            // the closest member not expanded yet; every kept member is within the radius, so index.hpp:4210 never fires
+            float open_distance;
+            std::uint32_t owner_lane, owner_cell;
+            if (!top.first_open(open_distance, expanded, owner_lane, owner_cell))
+                break;
+            top.close(owner_lane, owner_cell);
+        } else {
+            if (!next_size)
+                break;
+            const cand_t candidate = mem::load(next);
+            const float candidate_distance = -uniform_f32(cand_distance(candidate));
+            if (candidate_distance > radius && top.size == ef) // index.hpp:4210, strict `>`
+                break;
+            expanded = uniform_u32(cand_slot(candidate));
+        }
         ++cycles;
-        const std::uint32_t expanded = uniform_u32(cand_slot(candidate));
         const std::uint32_t* list = list_of(expanded);
         const bool list_ready = expanded == ahead_slot; // its first tile was requested one hop ago
 #ifdef USEARCH_AMD_PHASES
@@ -1146,15 +1220,22 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
         // arrives behind this hop's vector traffic instead of in front of the next hop's.
         bool popped = false;
         auto pop_now = [&]() {
-            heap_pop<global_ak>(next, next_size);
             popped = true;
             ahead_slot = none_slot_k;
-            if (next_size) {
-                ahead_slot = uniform_u32(cand_slot(mem::load(next)));
-                ahead_cell = lane < cells ? list_of(ahead_slot)[lane] : none_slot_k;
+            if constexpr (in_top_ak) { // the member was closed above; the next open one is the likeliest next hop
+                float ahead_distance;
+                std::uint32_t ahead_lane, ahead_index;
+                if (top.first_open(ahead_distance, ahead_slot, ahead_lane, ahead_index))
+                    ahead_cell = lane < cells ? list_of(ahead_slot)[lane] : none_slot_k;
+            } else {
+                heap_pop<global_ak>(next, next_size);
+                if (next_size) {
+                    ahead_slot = uniform_u32(cand_slot(mem::load(next)));
+                    ahead_cell = lane < cells ? list_of(ahead_slot)[lane] : none_slot_k;
+                }
             }
         };
-        if (!list_ready || cells > 64 || mode_ak == scratch_global_k)
+        if (in_top_ak || !list_ready || cells > 64 || mode_ak == scratch_global_k)
             pop_now();
         for (std::uint32_t tile = 0; tile < cells; tile += 64) {
             const std::uint32_t cell = tile + lane;
@@ -1165,7 +1246,7 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
             if (!present_count)
                 break;
             if (visits_count + present_count > visits_limit ||
-                next_size - (popped ? 0u : 1u) + present_count > args.next_cap) {
+                (!in_top_ak && next_size - (popped ? 0u : 1u) + present_count > args.next_cap)) {
                 overflow = true;
                 break;
             }
@@ -1218,13 +1299,16 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                 const std::uint64_t t0 = __builtin_amdgcn_s_memtime();
 #endif
                 // the frontier lives in LDS, `top` in registers: the insert runs while the push's reads are in flight
-                const push_ticket_t ticket = heap_push_begin<global_ak>(next, next_size);
+                push_ticket_t ticket;
+                if constexpr (!in_top_ak)
+                    ticket = heap_push_begin<global_ak>(next, next_size);
 #ifdef USEARCH_AMD_PHASES
                 const std::uint64_t t1 = __builtin_amdgcn_s_memtime();
 #endif
-                if (allowed(successor))
-                    top.insert(d, successor, ef, radius); // radius = top.top() once full
-                heap_push_finish<global_ak>(next, next_size, ticket, -d, successor);
+                if (in_top_ak || allowed(successor))
+                    top.insert(d, successor, ef, radius); // radius = top.top() once full; the new cell is open
+                if constexpr (!in_top_ak)
+                    heap_push_finish<global_ak>(next, next_size, ticket, -d, successor);
 #ifdef USEARCH_AMD_PHASES
                 const std::uint64_t t2 = __builtin_amdgcn_s_memtime();
                 diagnostic_push_ticks += t1 - t0, diagnostic_insert_ticks += t2 - t1;
@@ -1242,8 +1326,10 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
 
     // ---- results: shrink to `wanted`, dump_to with padding (index.hpp:3067-3073, 2707-2722)
     if (overflow) {
-        if (lane == 0)
+        if (lane == 0) {
             args.status[q] = status_overflow_k;
+            atomicAdd(args.queue + 1, 1u); // the host reads this one counter before it looks at any status
+        }
         return false;
     }
     const std::uint32_t found = top.size < wanted ? top.size : wanted;
@@ -1287,27 +1373,41 @@ enum kernel_variant_t : int {
     variant_u4_w4_k = 0,  ///< 4 loads in flight per lane
     variant_u8_w3_k = 1,  ///< 8 loads in flight (8 loads under 128 VGPRs spills: measured 2× slower)
     variant_u12_w2_k = 2, ///< 12 loads in flight (a whole 768-d f16 row per lane group)
+    variant_u12_w3_k = 3, ///< 12 loads in flight under the 168-VGPR budget (frontier_top_k builds only)
+    variant_u8_w4_k = 4,  ///< 8 loads in flight under the 128-VGPR budget (frontier_top_k builds only)
+    variant_count_k = 5,
 };
-constexpr int variant_unroll(int v) { return v == variant_u4_w4_k ? 4 : v == variant_u12_w2_k ? 12 : 8; }
+constexpr int variant_unroll(int v) {
+    return v == variant_u4_w4_k ? 4 : (v == variant_u12_w2_k || v == variant_u12_w3_k) ? 12 : 8;
+}
 /// Waves per SIMD the register budget of an instantiation is cut for (512 VGPRs per SIMD lane: 128 → 4, 168 → 3, 256 → 2);
 /// from the allocations the compiler reports for the widest rows (cos, G = 8) with `top` in `epl` register rows.
-constexpr int kernel_waves(int variant, int epl) {
+constexpr int kernel_waves(int variant, int epl, int frontier = 0) {
+    if (variant == variant_u12_w3_k)
+        return 3;
+    if (variant == variant_u8_w4_k)
+        return 4;
+    if (frontier) // without the heap's bookkeeping the 4-deep build fits 128 registers with any `top`
+        return variant == variant_u4_w4_k ? 4 : variant == variant_u8_w3_k ? 3 : 2;
     return variant == variant_u4_w4_k ? (epl >= 8 ? 3 : 4) : variant == variant_u8_w3_k ? (epl >= 16 ? 2 : 3) : 2;
 }
 
-template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak>
-__global__ __launch_bounds__(64, kernel_waves(variant_ak, epl_ak)) void search_kernel(const snapshot_view_t ix,
-                                                                               const search_args_t args) {
+template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak, int frontier_ak>
+__global__ __launch_bounds__(64, kernel_waves(variant_ak, epl_ak, frontier_ak)) void search_kernel(const snapshot_view_t ix,
+                                                                                            const search_args_t args) {
     constexpr int unroll_ak = variant_unroll(variant_ak);
     extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
     std::uint8_t* query_lds = lds;
     const std::uint32_t query_bytes = query_lds_bytes<scalar_ak>(ix.chunks);
     std::uint8_t* slab = args.scratch + (std::uint64_t)blockIdx.x * args.scratch_stride;
-    const scratch_layout_t layout = scratch_layout(epl_ak ? 0 : args.ef, args.next_cap, 0);
+    const scratch_layout_t layout = scratch_layout(epl_ak ? 0 : args.ef, frontier_ak == frontier_top_k ? 0 : args.next_cap, 0);
+    // batch-tail telemetry: when every wave of the launch started and left (100 MHz wall clock, comparable across the chip)
+    if (args.wave_clock && lane_id() == 0)
+        args.wave_clock[2 * (std::uint64_t)blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 
     if constexpr (mode_ak == scratch_global_k) {
         const std::uint32_t q = args.todo ? args.todo[blockIdx.x] : blockIdx.x;
-        search_one<metric_ak, scalar_ak, lanes_ak, unroll_ak, mode_ak, epl_ak>(
+        search_one<metric_ak, scalar_ak, lanes_ak, unroll_ak, mode_ak, epl_ak, frontier_ak>(
             ix, args, q, query_lds, slab, reinterpret_cast<std::uint32_t*>(slab + layout.visits));
     } else {
         std::uint8_t* heaps = lds + query_bytes;
@@ -1321,10 +1421,13 @@ __global__ __launch_bounds__(64, kernel_waves(variant_ak, epl_ak)) void search_k
             if (ticket >= args.count)
                 break;
             const std::uint32_t q = args.todo ? args.todo[ticket] : ticket;
-            search_one<metric_ak, scalar_ak, lanes_ak, unroll_ak, mode_ak, epl_ak>(ix, args, q, query_lds, heaps, visits);
+            search_one<metric_ak, scalar_ak, lanes_ak, unroll_ak, mode_ak, epl_ak, frontier_ak>(ix, args, q, query_lds, heaps,
+                                                                                               visits);
             wave_sync<false>();
         }
     }
+    if (args.wave_clock && lane_id() == 0)
+        args.wave_clock[2 * (std::uint64_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 /**

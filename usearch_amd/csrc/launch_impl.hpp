@@ -9,9 +9,9 @@
 
 namespace usearch_amd {
 
-template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak>
+template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak, int frontier_ak = frontier_heap_k>
 hipError_t launch_search_one(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
-    auto kernel = search_kernel<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, epl_ak>;
+    auto kernel = search_kernel<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, epl_ak, frontier_ak>;
     if (p.lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
@@ -22,15 +22,33 @@ hipError_t launch_search_one(const launch_params_t& p, const snapshot_view_t& vi
     return hipGetLastError();
 }
 
+/// The frontier as the open cells of a register `top` (kernels.hpp frontier_top_k): float-valued pairs only — the
+/// integer-valued ones (b1, i8) tie all the time and keep the reference's heap and its pop order.
+template <int scalar_ak> constexpr bool frontier_in_top_pair() { return scalar_ak != scalar_b1x8_k && scalar_ak != scalar_i8_k; }
+
+template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak>
+hipError_t launch_search_frontier(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
+    if constexpr (epl_ak > 0 && frontier_in_top_pair<scalar_ak>()) {
+        if (p.frontier == frontier_top_k)
+            return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, epl_ak, frontier_top_k>(p, view, args);
+    }
+    if (p.frontier != frontier_heap_k)
+        return hipErrorInvalidValue;
+    if constexpr (variant_ak == variant_u12_w3_k || variant_ak == variant_u8_w4_k)
+        return hipErrorInvalidValue;
+    else
+        return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, epl_ak, frontier_heap_k>(p, view, args);
+}
+
 /// `top` in registers with 1 / 4 / 8 / 16 entries per lane (expansion ≤ 64 / 256 / 512 / 1024), or in scratch memory (0).
 template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak>
 hipError_t launch_search_epl(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
     switch (p.entries_per_lane) {
-    case 0: return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 0>(p, view, args);
-    case 1: return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 1>(p, view, args);
-    case 4: return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 4>(p, view, args);
-    case 8: return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 8>(p, view, args);
-    case 16: return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 16>(p, view, args);
+    case 0: return launch_search_frontier<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 0>(p, view, args);
+    case 1: return launch_search_frontier<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 1>(p, view, args);
+    case 4: return launch_search_frontier<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 4>(p, view, args);
+    case 8: return launch_search_frontier<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 8>(p, view, args);
+    case 16: return launch_search_frontier<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 16>(p, view, args);
     default: return hipErrorInvalidValue;
     }
 }
@@ -53,6 +71,16 @@ hipError_t launch_search_lanes(const launch_params_t& p, const snapshot_view_t& 
         switch (p.variant) {
         case variant_u8_w3_k: return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u8_w3_k>(p, view, args);
         case variant_u12_w2_k: return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u12_w2_k>(p, view, args);
+        case variant_u12_w3_k: // tighter register budgets: only the heap-less builds fit them
+        case variant_u8_w4_k:
+            if constexpr (frontier_in_top_pair<scalar_ak>()) {
+                if (p.frontier != frontier_top_k || !p.entries_per_lane)
+                    return hipErrorInvalidValue;
+                if (p.variant == variant_u12_w3_k)
+                    return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u12_w3_k>(p, view, args);
+                return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u8_w4_k>(p, view, args);
+            }
+            return hipErrorInvalidValue;
         default: break;
         }
     }

@@ -42,13 +42,15 @@ def _infer_dtype(array: np.ndarray) -> str:
 class Tuning(C.Structure):
     """`usearch_amd_tuning_t`."""
     _fields_ = [("hash_cap", C.c_uint32), ("next_cap", C.c_uint32), ("variant", C.c_uint32), ("mode", C.c_uint32),
-                ("waves_per_cu", C.c_uint32)]
+                ("waves_per_cu", C.c_uint32), ("frontier", C.c_uint32), ("wave_clock", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Stats(C.Structure):
     """`usearch_amd_stats_t`."""
     _fields_ = [("passes", C.c_uint32), ("retried_lds", C.c_uint32), ("retried_global", C.c_uint32),
-                ("kernel_ms", C.c_float), ("mode", C.c_uint32), ("grid", C.c_uint32), ("lds_bytes", C.c_uint32)]
+                ("kernel_ms", C.c_float), ("mode", C.c_uint32), ("grid", C.c_uint32), ("lds_bytes", C.c_uint32),
+                ("frontier", C.c_uint32), ("variant", C.c_uint32), ("tail_idle", C.c_float), ("span_ms", C.c_float),
+                ("reserved", C.c_uint32)]
 
 
 class BuildConfig(C.Structure):
@@ -84,6 +86,9 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_test_containers", "usearch_amd_cast",
     "usearch_amd_build", "usearch_amd_build_free", "usearch_amd_build_snapshot",
     "usearch_amd_build_serialized_length", "usearch_amd_build_save_buffer", "usearch_amd_build_stats",
+    # sharded search across GPUs (usearch_amd/sharded.py binds these)
+    "usearch_amd_comm_unique_id", "usearch_amd_comm_init_rccl", "usearch_amd_comm_init_custom", "usearch_amd_comm_free",
+    "usearch_amd_comm_rank", "usearch_amd_comm_world", "usearch_amd_comm_broadcast", "usearch_amd_sharded_search_many",
 ]
 
 

@@ -1,83 +1,287 @@
 """Sharded search across the GPUs of one node: one process per GPU, one HNSW per shard, one exchange step.
 
 What the reference does on the CPU with `Indexes` (python/usearch/index.py:1473-1514 → python/lib.cpp:321-402: every shard
-searches every query, per-query results are folded with `search_result_t::merge_into`, index.hpp:2650-2670) becomes:
+searches every query, per-query results are folded with `search_result_t::merge_into`, index.hpp:2650-2670) is ONE native
+call here, `usearch_amd_sharded_search_many` (usearch_amd/csrc/sharded.hip): on every rank, on one stream, with one wait,
 
-    broadcast the batch (rank 0 → all)  →  local `usearch_amd_search_many_device` on this rank's shard
-    →  all-gather of (distances f32, keys u64, counts u64)[Q][k] over RCCL  →  `usearch_amd_merge_many_device`
+    [broadcast the batch]  →  search this rank's shard, results written straight into the send block
+    →  ONE all-gather of the packed block {distances | keys | counts}  →  merge kernel (rank order, `merge_into` tie rule).
 
-with shards merged in RANK ORDER (the reference's order is whatever its dynamic executor produces; ties between shards
-are therefore only defined here). Message per rank = Q·k·12 bytes (+ Q·8), e.g. 100 k queries × k = 10 → 12.8 MB, gathered
-96-102 MB on 8 GPUs: latency-, not bandwidth-bound on xGMI, hence ONE collective per batch per tensor, no bucketing.
+This module is the thin host mirror: it creates the communicator (RCCL over xGMI; the 128-byte unique id travels through
+whatever process group the launcher set up) and forwards device pointers. `torch.distributed` is plumbing — rendezvous
+and, when RCCL cannot be initialised natively, a fallback transport whose collectives are handed to the SAME native step as
+callbacks. A third transport runs the step in host memory with a caller-supplied stand-in for the device search, which is
+how the protocol is covered on machines without a GPU (tests/test_sharded_gloo.py).
 
-The class is transport-agnostic on purpose: `local_search` and `merge` are injected callables so that the protocol is
-covered on CPU with the `gloo` backend (tests/test_sharded_gloo.py) while production binds them to the GPU engine.
+Message per rank = Q·k·12 + Q·8 + 8 bytes, e.g. 100 k queries × k = 10 → 12.8 MB, gathered 102 MB on 8 GPUs: latency-, not
+bandwidth-bound on xGMI, hence ONE collective per batch, no bucketing.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+import ctypes as C
+from typing import Callable, Optional
 
-import torch
-import torch.distributed as dist
+import numpy as np
 
-SearchFn = Callable[[torch.Tensor, int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]
-MergeFn = Callable[[torch.Tensor, torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]
+from . import index as binding
+
+# the callbacks return `char const*`: NULL, or the address of a message that stays alive (see `_message`)
+ALL_GATHER_T = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+BROADCAST_T = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+LOCAL_SEARCH_T = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                             C.c_void_p, C.c_void_p, C.c_void_p)
+_messages = []
+
+
+def _message(error: Exception) -> int:
+    """An error string the native side may read after the callback has returned."""
+    buffer = C.create_string_buffer(f"{type(error).__name__}: {error}".encode()[:240])
+    _messages.append(buffer)
+    del _messages[:-16]
+    return C.addressof(buffer)
+
+
+class Transport(C.Structure):
+    """`usearch_amd_transport_t`."""
+    _fields_ = [("context", C.c_void_p), ("all_gather", ALL_GATHER_T), ("broadcast", BROADCAST_T),
+                ("buffers_on_host", C.c_int), ("local_search", LOCAL_SEARCH_T)]
+
+
+class ShardedStats(C.Structure):
+    """`usearch_amd_sharded_stats_t`."""
+    _fields_ = [("block_bytes", C.c_uint64), ("gathered_bytes", C.c_uint64), ("exchange_ms", C.c_float),
+                ("exchanges", C.c_uint32)]
+
+
+def _bind(library: C.CDLL) -> C.CDLL:
+    if getattr(library, "_sharded_bound", False):
+        return library
+    err_p = C.POINTER(C.c_char_p)
+    library.usearch_amd_comm_unique_id.argtypes = [C.c_void_p, err_p]
+    library.usearch_amd_comm_init_rccl.restype = C.c_void_p
+    library.usearch_amd_comm_init_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, err_p]
+    library.usearch_amd_comm_init_custom.restype = C.c_void_p
+    library.usearch_amd_comm_init_custom.argtypes = [C.POINTER(Transport), C.c_int, C.c_int, C.c_int, err_p]
+    library.usearch_amd_comm_free.argtypes = [C.c_void_p]
+    library.usearch_amd_comm_rank.argtypes = [C.c_void_p]
+    library.usearch_amd_comm_world.argtypes = [C.c_void_p]
+    library.usearch_amd_comm_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, err_p]
+    library.usearch_amd_sharded_search_many.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(binding.Tuning), C.c_int,
+        C.POINTER(binding.Stats), C.POINTER(ShardedStats), err_p]
+    library._sharded_bound = True
+    return library
+
+
+def _raise(err: C.c_char_p, where: str) -> None:
+    if err.value:
+        raise RuntimeError(f"{where}: {err.value.decode()}")
+
+
+class Communicator:
+    """Owns a `usearch_amd_comm_t`. Build one with `Communicator.rccl(...)`, `.over_torch(...)` or `.on_host(...)`."""
+
+    def __init__(self, handle: int, kind: str, keep=()):
+        self._handle = handle
+        self.kind = kind
+        self._keep = keep  # ctypes callbacks and their structure must outlive the native object
+
+    def __del__(self):
+        try:
+            if self._handle:
+                _bind(binding.library()).usearch_amd_comm_free(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    @property
+    def rank(self) -> int:
+        return int(_bind(binding.library()).usearch_amd_comm_rank(self._handle))
+
+    @property
+    def world(self) -> int:
+        return int(_bind(binding.library()).usearch_amd_comm_world(self._handle))
+
+    # ---- RCCL over xGMI, natively: the production transport
+    @classmethod
+    def rccl(cls, rank: int, world: int, device: int, share_id: Callable[[Optional[bytes]], bytes]) -> "Communicator":
+        """`share_id(bytes on rank 0 / None elsewhere) -> the 128 bytes on every rank`: the launcher's side channel."""
+        library = _bind(binding.library())
+        err = C.c_char_p()
+        unique, failure = None, None
+        if rank == 0:
+            block = (C.c_uint8 * 128)()
+            library.usearch_amd_comm_unique_id(block, C.byref(err))
+            if err.value:  # tell the other ranks instead of leaving them in the side channel
+                failure = err.value.decode()
+            else:
+                unique = bytes(block)
+        unique = share_id(unique)
+        if not unique or len(unique) != 128:
+            raise RuntimeError(f"usearch_amd_comm_unique_id: {failure or 'rank 0 could not create the RCCL unique id'}")
+        err = C.c_char_p()
+        block = (C.c_uint8 * 128).from_buffer_copy(unique)
+        handle = library.usearch_amd_comm_init_rccl(block, rank, world, device, C.byref(err))
+        _raise(err, "usearch_amd_comm_init_rccl")
+        return cls(handle, "rccl-native")
+
+    # ---- the caller's collectives on DEVICE buffers (torch.distributed with the nccl = RCCL backend): fallback
+    @classmethod
+    def over_torch(cls, rank: int, world: int, device: int, group=None) -> "Communicator":
+        import torch
+        import torch.distributed as dist
+
+        def as_tensor(pointer: int, nbytes: int):
+            # a uint8 view of raw device memory; torch only carries it to the collective
+            holder = {"data": (pointer, False), "shape": (nbytes,), "typestr": "|u1", "version": 3}
+
+            class Raw:
+                __cuda_array_interface__ = holder
+            return torch.as_tensor(Raw(), device=torch.device("cuda", device))
+
+        def all_gather(_context, send, receive, nbytes, stream):
+            try:
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream or 0, device=torch.device("cuda", device))):
+                    dist.all_gather_into_tensor(as_tensor(receive, nbytes * world), as_tensor(send, nbytes), group=group)
+                return None
+            except Exception as error:  # surfaced through the C ABI as an error string
+                return _message(error)
+
+        def broadcast(_context, buffer, nbytes, root, stream):
+            try:
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream or 0, device=torch.device("cuda", device))):
+                    dist.broadcast(as_tensor(buffer, nbytes), src=root, group=group)
+                return None
+            except Exception as error:
+                return _message(error)
+
+        callbacks = (ALL_GATHER_T(all_gather), BROADCAST_T(broadcast))
+        transport = Transport(None, callbacks[0], callbacks[1], 0, LOCAL_SEARCH_T())
+        err = C.c_char_p()
+        handle = _bind(binding.library()).usearch_amd_comm_init_custom(C.byref(transport), rank, world, device, C.byref(err))
+        _raise(err, "usearch_amd_comm_init_custom")
+        return cls(handle, "torch-distributed", keep=(callbacks, transport))
+
+    # ---- everything in host memory, the device search replaced by `local_search`: the protocol without a GPU
+    @classmethod
+    def on_host(cls, rank: int, world: int, all_gather: Callable[[np.ndarray, np.ndarray], None],
+                broadcast: Optional[Callable[[np.ndarray, int], None]],
+                local_search: Callable[[np.ndarray, int, int, int], tuple]) -> "Communicator":
+        """`all_gather(send u8[n], receive u8[world·n])`, `broadcast(buffer u8[n], root)`,
+        `local_search(queries u8[Q, stride], count, wanted, expansion) -> (keys u64[Q,k], distances f32[Q,k], counts u64[Q])`."""
+
+        def view(pointer: int, nbytes: int) -> np.ndarray:
+            return np.ctypeslib.as_array(C.cast(pointer, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+        def gather_callback(_context, send, receive, nbytes, _stream):
+            try:
+                all_gather(view(send, nbytes), view(receive, nbytes * world))
+                return None
+            except Exception as error:
+                return _message(error)
+
+        def broadcast_callback(_context, buffer, nbytes, root, _stream):
+            try:
+                broadcast(view(buffer, nbytes), root)
+                return None
+            except Exception as error:
+                return _message(error)
+
+        def search_callback(_context, queries, count, stride, wanted, expansion, keys, distances, counts):
+            try:
+                found = local_search(view(queries, count * stride).reshape(count, stride), count, wanted, expansion)
+                view(keys, count * wanted * 8)[:] = np.ascontiguousarray(found[0], dtype=np.uint64).view(np.uint8).ravel()
+                view(distances, count * wanted * 4)[:] = np.ascontiguousarray(found[1], dtype=np.float32).view(np.uint8).ravel()
+                view(counts, count * 8)[:] = np.ascontiguousarray(found[2], dtype=np.uint64).view(np.uint8).ravel()
+                return None
+            except Exception as error:
+                return _message(error)
+
+        callbacks = (ALL_GATHER_T(gather_callback), BROADCAST_T(broadcast_callback) if broadcast else BROADCAST_T(),
+                     LOCAL_SEARCH_T(search_callback))
+        transport = Transport(None, callbacks[0], callbacks[1], 1, callbacks[2])
+        err = C.c_char_p()
+        handle = _bind(binding.library()).usearch_amd_comm_init_custom(C.byref(transport), rank, world, 0, C.byref(err))
+        _raise(err, "usearch_amd_comm_init_custom")
+        return cls(handle, "host", keep=(callbacks, transport))
+
+    def broadcast_device(self, pointer: int, nbytes: int, root: int, stream: int = 0) -> None:
+        err = C.c_char_p()
+        _bind(binding.library()).usearch_amd_comm_broadcast(self._handle, C.c_void_p(pointer), nbytes, root,
+                                                            C.c_void_p(stream), C.byref(err))
+        _raise(err, "usearch_amd_comm_broadcast")
+
+    # ---- the step
+    def search_raw(self, snapshot_handle, queries_ptr: int, count: int, stride: int, wanted: int, expansion: int,
+                   broadcast_root: int, keys_ptr: int, distances_ptr: int, counts_ptr: int, visited_ptr: int,
+                   computed_ptr: int, stream: int = 0, timed: bool = False,
+                   tuning: Optional[binding.Tuning] = None):
+        """`usearch_amd_sharded_search_many` on raw addresses (device memory, or host memory for `on_host`)."""
+        stats, step, err = binding.Stats(), ShardedStats(), C.c_char_p()
+        _bind(binding.library()).usearch_amd_sharded_search_many(
+            snapshot_handle, self._handle, C.c_void_p(queries_ptr), count, stride, wanted, expansion, broadcast_root,
+            C.c_void_p(keys_ptr), C.c_void_p(distances_ptr), C.c_void_p(counts_ptr), C.c_void_p(visited_ptr),
+            C.c_void_p(computed_ptr), C.c_void_p(stream), C.byref(tuning) if tuning is not None else None, int(timed),
+            C.byref(stats), C.byref(step), C.byref(err))
+        _raise(err, "usearch_amd_sharded_search_many")
+        return stats, step
 
 
 class ShardedSearcher:
-    """`local_search(queries, k, expansion) -> (keys i64[Q,k], distances f32[Q,k], counts i64[Q])` on this rank's shard;
-    `merge(distances[P,Q,k], keys[P,Q,k], counts[P,Q]) -> (keys[Q,k], distances[Q,k], counts[Q])`."""
+    """This rank's shard (`usearch_amd.Index`) + a communicator. `search` runs one step on torch CUDA tensors."""
 
-    def __init__(self, local_search: SearchFn, merge: MergeFn, group: Optional[dist.ProcessGroup] = None):
-        self.local_search = local_search
-        self.merge = merge
-        self.group = group
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+    def __init__(self, index, communicator: Communicator, stream: int = 0):
+        self.index = index
+        self.communicator = communicator
+        self.stream = stream
+        self.last_visited = None
+        self.last_computed = None
+        self.last_step = None
 
-    def search(self, queries: torch.Tensor, k: int, expansion: int = 0, broadcast_from: Optional[int] = 0):
-        """Every rank passes a tensor of the batch's shape; with `broadcast_from` set, that rank's content wins."""
-        if self.world > 1 and broadcast_from is not None:
-            dist.broadcast(queries, src=broadcast_from, group=self.group)
-        keys, distances, counts = self.local_search(queries, k, expansion)
-        if self.world == 1:
-            return keys, distances, counts
-        def gather(tensor: torch.Tensor) -> torch.Tensor:
-            flat = tensor.contiguous().view(-1)  # flat in, flat out: the one form every backend agrees on
-            out = torch.empty(self.world * flat.numel(), dtype=flat.dtype, device=flat.device)
-            dist.all_gather_into_tensor(out, flat, group=self.group)
-            return out.view((self.world,) + tuple(tensor.shape))
-
-        all_distances, all_keys, all_counts = gather(distances), gather(keys), gather(counts)
-        return self.merge(all_distances, all_keys, all_counts)
-
-
-def gpu_searcher(index, group: Optional[dist.ProcessGroup] = None, stream: int = 0) -> ShardedSearcher:
-    """Binds the protocol to the MI355X engine: `index` is this rank's `usearch_amd.Index` (its shard)."""
-    from . import index as binding
-
-    def local_search(queries: torch.Tensor, k: int, expansion: int):
+    def search(self, queries, k: int, expansion: int = 0, broadcast_from: Optional[int] = 0, timed: bool = False,
+               tuning: Optional[binding.Tuning] = None, out=None):
+        """`queries`: uint8 CUDA tensor [Q, bytes] in the storage kind (every rank passes one; with `broadcast_from` set that
+        rank's content wins). → (keys i64[Q,k], distances f32[Q,k], counts i64[Q]) merged over all shards, + engine stats.
+        `out` = (keys, distances, counts, visited, computed) tensors to fill instead of fresh ones."""
+        import torch
         q = queries.shape[0]
-        keys = torch.empty((q, k), dtype=torch.int64, device=queries.device)
-        distances = torch.empty((q, k), dtype=torch.float32, device=queries.device)
-        counts = torch.empty(q, dtype=torch.int64, device=queries.device)
-        visited = torch.empty(q, dtype=torch.int64, device=queries.device)
-        computed = torch.empty(q, dtype=torch.int64, device=queries.device)
-        torch.cuda.current_stream(queries.device).synchronize()
-        index.search_device(queries.data_ptr(), q, queries.stride(0) * queries.element_size(), k, expansion,
-                            keys.data_ptr(), distances.data_ptr(), counts.data_ptr(), visited.data_ptr(),
-                            computed.data_ptr(), stream=stream)
-        local_search.last_visited, local_search.last_computed = visited, computed
-        return keys, distances, counts
+        if out is None:
+            out = (torch.empty((q, k), dtype=torch.int64, device=queries.device),
+                   torch.empty((q, k), dtype=torch.float32, device=queries.device),
+                   torch.empty(q, dtype=torch.int64, device=queries.device),
+                   torch.empty(q, dtype=torch.int64, device=queries.device),
+                   torch.empty(q, dtype=torch.int64, device=queries.device))
+            torch.cuda.current_stream(queries.device).synchronize()  # they exist before our stream touches them
+        keys, distances, counts, visited, computed = out
+        stats, step = self.communicator.search_raw(
+            self.index._handle, queries.data_ptr(), q, queries.stride(0) * queries.element_size(), k, expansion,
+            -1 if broadcast_from is None else broadcast_from, keys.data_ptr(), distances.data_ptr(), counts.data_ptr(),
+            visited.data_ptr(), computed.data_ptr(), self.stream, timed, tuning)
+        self.last_visited, self.last_computed, self.last_step = visited, computed, step
+        return keys, distances, counts, stats
 
-    def merge(all_distances: torch.Tensor, all_keys: torch.Tensor, all_counts: torch.Tensor):
-        shards, q, k = all_distances.shape
-        keys = torch.empty((q, k), dtype=torch.int64, device=all_keys.device)
-        distances = torch.empty((q, k), dtype=torch.float32, device=all_keys.device)
-        counts = torch.empty(q, dtype=torch.int64, device=all_keys.device)
-        torch.cuda.current_stream(all_keys.device).synchronize()
-        binding.merge_many_device(all_distances.data_ptr(), all_keys.data_ptr(), all_counts.data_ptr(), shards, q, k,
-                                  distances.data_ptr(), keys.data_ptr(), counts.data_ptr(), stream)
-        return keys, distances, counts
 
-    return ShardedSearcher(local_search, merge, group)
+def gpu_searcher(index, rank: int, world: int, device: int, stream: int = 0, group=None,
+                 prefer: str = "rccl") -> ShardedSearcher:
+    """Production binding: native RCCL when it initialises, else the torch.distributed transport — say which in the logs
+    (`ShardedSearcher.communicator.kind`). The unique id travels over the launcher's process group."""
+    import torch.distributed as dist
+
+    def share_id(unique: Optional[bytes]) -> bytes:
+        if world == 1:
+            return unique
+        box = [unique]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return box[0]
+
+    communicator = None
+    if prefer == "rccl":
+        try:
+            communicator = Communicator.rccl(rank, world, device, share_id)
+        except RuntimeError as error:
+            import sys
+            print(f"[usearch_amd] native RCCL unavailable on rank {rank} ({error}); using torch.distributed", file=sys.stderr)
+    if communicator is None:
+        communicator = Communicator.over_torch(rank, world, device, group)
+    return ShardedSearcher(index, communicator, stream)
