@@ -514,7 +514,20 @@ def main() -> None:
         t1 = time.perf_counter()
         rkeys, *_ = ref_index.search(queries_host[:sample_q], args.k, dtype=args.dtype, threads=threads)
         cpu_seconds = time.perf_counter() - t1
-        agree = float(np.mean(keys_dev[:sample_q].cpu().numpy().astype(np.uint64) == rkeys))
+        found_keys = keys_dev[:sample_q].cpu().numpy().astype(np.uint64)
+        if sharded:  # `Indexes` folds every shard's result with merge_into, the first one into an empty buffer: equal distances
+            from oracle import oraclebind  # come out in reverse order (index.hpp:2650-2670); apply it to the reference's rows
+            folded = min(sample_q, 2000)
+            rkeys_all, rdists_all, rcounts_all, *_ = ref_index.search(queries_host[:folded], args.k, dtype=args.dtype, threads=threads)
+            merged_keys = np.zeros_like(rkeys_all)
+            for i in range(folded):
+                row_keys, row_distances = np.zeros(args.k, dtype=np.uint64), np.zeros(args.k, dtype=np.float32)
+                n = int(rcounts_all[i])
+                oraclebind.merge_into(row_keys, row_distances, 0, rkeys_all[i, :n], rdists_all[i, :n], n)
+                merged_keys[i] = row_keys
+            agree = float(np.mean(found_keys[:folded] == merged_keys))
+        else:
+            agree = float(np.mean(found_keys == rkeys))
         cpu = {"value": sample_q / cpu_seconds, "unit": "shard-queries/s" if sharded else "queries/s", "cores": threads,
                "kind": "reference",
                "sample": f"{sample_q} of the step's {args.queries} queries, same index, same ef={expansion}, "

@@ -14,6 +14,8 @@ for step in "$@"; do
     tests)    timeout 900 python -m pytest tests -m gpu -x -q > "$OUT/pytest.log" 2>&1; tail -15 "$OUT/pytest.log" ;;
     sweep10m) timeout 600 python scripts/sweep.py --n 10000000 --ef 592 256 --modes 2 --waves 0 --variants 1 2 3 4 5 \
                 --frontiers 1 2 --steps 3 > "$OUT/sweep10m.log" 2>&1; cat "$OUT/sweep10m.log" ;;
+    sweepv)   timeout 600 python scripts/sweep.py --n 10000000 --ef 608 --queries 10000 100000 --modes 2 --waves 0 --variants 3 1 2 4 \
+                --frontiers 1 2 --steps 3 > "$OUT/sweepv.log" 2>&1; cat "$OUT/sweepv.log" ;;
     sweepwaves) timeout 600 python scripts/sweep.py --n 10000000 --ef 592 --modes 2 --waves 8 12 16 --variants 1 2 3 4 5 \
                 --frontiers 2 --steps 3 > "$OUT/sweepwaves.log" 2>&1; cat "$OUT/sweepwaves.log" ;;
     bench)    timeout 900 python bench.py --steps 20 --warmup 5 --wave-clock > "$OUT/bench.json" 2> "$OUT/bench.log"; tail -25 "$OUT/bench.log"; cat "$OUT/bench.json" ;;

@@ -314,6 +314,8 @@ const char* builder_t::build(metric_kind_t metric, scalar_kind_t scalar, std::si
     for (std::uint64_t key : keys_)
         tombstones |= key == free_key_k;
     snapshot_.set_tombstones(tombstones);
+    if (const char* e = snapshot_.finalize_layout()) // the graph is final: rows of ≤ 16 bytes move next to the lists
+        return e;
     unsigned long long counters[4] = {0, 0, 0, 0};
     UA_HIP(hipMemcpy(counters, d_counters, sizeof(counters), hipMemcpyDeviceToHost));
     stats_.select_distances = counters[0];

@@ -81,6 +81,10 @@ constexpr std::size_t default_expansion_search_k = 64;         ///< index.hpp:30
  *    upper_ref [size] u32                 index of the node's level-1 list inside `upper`, none_slot_k for level-0 nodes
  *    upper     [lists][m] u32             lists of levels 1..L of one node are consecutive; same cell convention
  *    keys      [size] u64                 node_t::key (index.hpp:2116-2137)
+ *    nbr0_rows [size][m0][16] bytes       optional, rows of ≤ 16 bytes (b1 × 128 …): the stored rows of a node's level-0
+ *                                         neighbours next to each other, in list order — the per-hop gather of up to M0
+ *                                         scattered 16-byte rows becomes one contiguous 16·M0-byte read (docs/format.md:7-28
+ *                                         keeps a node's neighbours together for the same reason)
  */
 struct snapshot_view_t {
     const std::uint8_t* vectors;
@@ -88,6 +92,8 @@ struct snapshot_view_t {
     const std::uint32_t* upper_ref;
     const std::uint32_t* upper;
     const std::uint64_t* keys;
+    const std::uint8_t* nbr0_rows; ///< optional [size][m0][16]: cell j = a copy of the stored row of nbr0[i][j] (rows of ≤ 16
+                                   ///< bytes only: the neighbours' vectors travel with the list, one contiguous block per hop)
     std::uint64_t size;
     std::uint32_t row_stride; ///< bytes, multiple of 16*G
     std::uint32_t chunks;     ///< row_stride / 16

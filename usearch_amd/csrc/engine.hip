@@ -212,7 +212,7 @@ void snapshot_t::release() {
     if (!d_vectors_ && !d_nbr0_ && workspaces_.empty() && !stream_)
         return;
     (void)hipSetDevice(device_);
-    for (void* p : {d_vectors_, d_nbr0_, d_upper_ref_, d_upper_, d_keys_})
+    for (void* p : {d_vectors_, d_nbr0_, d_upper_ref_, d_upper_, d_keys_, d_nbr0_rows_})
         if (p)
             (void)hipFree(p);
     {
@@ -225,8 +225,44 @@ void snapshot_t::release() {
     }
     if (stream_)
         (void)hipStreamDestroy(stream_);
-    d_vectors_ = d_nbr0_ = d_upper_ref_ = d_upper_ = d_keys_ = nullptr;
+    d_vectors_ = d_nbr0_ = d_upper_ref_ = d_upper_ = d_keys_ = d_nbr0_rows_ = nullptr;
+    view_.nbr0_rows = nullptr;
     stream_ = nullptr;
+}
+
+/// out[i][j] = the stored row of nbr0[i][j], one 16-byte chunk per cell (empty cells are left alone: never read).
+__global__ void inline_rows_kernel(const std::uint8_t* vectors, const std::uint32_t* nbr0, uint4* out, std::uint64_t cells,
+                                   std::uint32_t row_stride) {
+    const std::uint64_t i = blockIdx.x * (std::uint64_t)blockDim.x + threadIdx.x;
+    if (i >= cells)
+        return;
+    const std::uint32_t slot = nbr0[i];
+    if (slot != none_slot_k)
+        out[i] = *reinterpret_cast<const uint4*>(vectors + (std::uint64_t)slot * row_stride);
+}
+
+const char* snapshot_t::finalize_layout() {
+    if (d_nbr0_rows_) {
+        (void)hipFree(d_nbr0_rows_);
+        device_bytes_ -= std::min<std::size_t>(device_bytes_, (std::size_t)view_.size * view_.m0 * 16);
+        d_nbr0_rows_ = nullptr;
+        view_.nbr0_rows = nullptr;
+    }
+    if (lanes_ != 1 || view_.chunks != 1 || view_.m0 > 64 || !view_.size || !env_size("USEARCH_AMD_INLINE_ROWS", 1))
+        return nullptr;
+    UA_HIP(hipSetDevice(device_));
+    const std::uint64_t cells = view_.size * view_.m0;
+    UA_HIP(hipMalloc(&d_nbr0_rows_, cells * 16));
+    device_bytes_ += cells * 16;
+    const std::uint64_t blocks = (cells + 255) / 256;
+    if (blocks > 0x7FFFFFFFull)
+        return "Index is too large for the inline-row layout";
+    hipLaunchKernelGGL(inline_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream_, view_.vectors, view_.nbr0,
+                       static_cast<uint4*>(d_nbr0_rows_), cells, view_.row_stride);
+    UA_HIP(hipGetLastError());
+    UA_HIP(hipStreamSynchronize(stream_));
+    view_.nbr0_rows = static_cast<const std::uint8_t*>(d_nbr0_rows_);
+    return nullptr;
 }
 
 const char* snapshot_t::build(const image_t& image, int device) {
@@ -372,7 +408,7 @@ const char* snapshot_t::build(const image_t& image, int device) {
     UA_HIP(hipGetDeviceProperties(&properties, device));
     compute_units_ = properties.multiProcessorCount > 0 ? properties.multiProcessorCount : 256;
     UA_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    return nullptr;
+    return finalize_layout();
 }
 
 static hipError_t launch_search(metric_kind_t metric, scalar_kind_t scalar, const launch_params_t& p,
@@ -497,8 +533,7 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
     }
     if (variant_request && variant_request - 1 < (std::uint32_t)variant_count_k && every_build) {
         const int requested = (int)variant_request - 1;
-        const bool tight = requested == variant_u12_w3_k || requested == variant_u8_w4_k;
-        if (tight && frontier != frontier_top_k)
+        if (requested == variant_u12x2_w2_k && frontier != frontier_top_k)
             return "That kernel build exists for the in-`top` frontier only";
         variant = requested;
     }

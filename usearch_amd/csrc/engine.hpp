@@ -175,6 +175,10 @@ class snapshot_t {
         view_.size = size, view_.entry_slot = entry_slot, view_.max_level = max_level;
     }
     void set_tombstones(bool any) { view_.has_tombstones = any ? 1u : 0u; }
+    /// Once the graph no longer changes: lays the stored rows of every node's level-0 neighbours next to each other
+    /// (`snapshot_view_t::nbr0_rows`) when rows are a single 16-byte chunk — b1 × 128, haversine … — so that a hop reads one
+    /// contiguous block. Costs size × M0 × 16 bytes of HBM; USEARCH_AMD_INLINE_ROWS=0 turns it off.
+    const char* finalize_layout();
     std::uint32_t* mutable_nbr0() { return static_cast<std::uint32_t*>(d_nbr0_); }
     std::uint32_t* mutable_upper() { return static_cast<std::uint32_t*>(d_upper_); }
     hipStream_t stream() const { return stream_; }
@@ -245,6 +249,7 @@ class snapshot_t {
     void* d_upper_ref_ = nullptr;
     void* d_upper_ = nullptr;
     void* d_keys_ = nullptr;
+    void* d_nbr0_rows_ = nullptr;
 
     int compute_units_ = 256;
     float last_distances_ms_ = 0.f;

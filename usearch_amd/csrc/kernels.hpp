@@ -842,47 +842,118 @@ UA_DEVICE float finalize_distance(partial_t p, query_norm_t a2, std::uint32_t di
 
 /**
  *  Distances from the query (in LDS) to `count` rows whose slots sit in `slots[0..count)`; results to `out[0..count)`.
- *  The wave is split into 64/G groups of G lanes, one row per group per round; each lane streams 16-byte chunks
- *  `sub, sub+G, …` of its row with `unroll_ak` loads in flight before the first use.
+ *  The wave is split into 64/G groups of G lanes; each lane streams 16-byte chunks `sub, sub+G, …` of its row with
+ *  `unroll_ak` loads in flight before the first use. A group takes `rows_ak` rows per round (rows g, g + 64/G, …): their
+ *  loads are all issued before the first one is consumed, so a round trip to HBM fetches rows_ak × 64/G rows per wave —
+ *  more bytes in flight per wave instead of more waves (a batch's drain phase grows with the waves per query in flight,
+ *  not with the bytes per wave). The summation layout of a row does not depend on `rows_ak`.
  */
-template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, bool global_ak>
+template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, bool global_ak, int rows_ak = 1>
 UA_DEVICE void measure_rows(const snapshot_view_t& ix, const std::uint8_t* query_lds, query_norm_t a2,
                             const std::uint32_t* slots, float* out, std::uint32_t count) {
     using mem = scratch_gt<global_ak>;
     constexpr std::uint32_t rows_per_round = 64 / lanes_ak;
     const std::uint32_t lane = lane_id();
     const std::uint32_t group = lane / lanes_ak, sub = lane % lanes_ak;
-    const std::uint32_t chunks_per_lane = ix.chunks / lanes_ak; // row_stride is a multiple of 16*G
-    for (std::uint32_t base = 0; base < count; base += rows_per_round) {
-        const std::uint32_t ci = base + group;
-        if (ci < count) { // a group is active or idle as a whole, so the butterfly below stays inside active lanes
-            const std::uint32_t slot = mem::load(slots + ci);
-            const uint4* row = reinterpret_cast<const uint4*>(ix.vectors + (std::uint64_t)slot * ix.row_stride) + sub;
-            partial_t p;
-            std::uint32_t it = 0;
-            for (; it + unroll_ak <= chunks_per_lane; it += unroll_ak) {
-                uint4 v[unroll_ak];
+    const std::uint32_t chunks_per_lane = ix.chunks / lanes_ak; // `chunks` is a multiple of G
+    constexpr bool fence_ak = false; // see the multi-row path: single rows do not need the scheduling fence
+    if constexpr (rows_ak == 1) {
+        for (std::uint32_t base = 0; base < count; base += rows_per_round) {
+            const std::uint32_t ci = base + group;
+            if (ci < count) { // a group is active or idle as a whole, so the butterfly below stays inside active lanes
+                const std::uint32_t slot = mem::load(slots + ci);
+                const uint4* row = reinterpret_cast<const uint4*>(ix.vectors + (std::uint64_t)slot * ix.row_stride) + sub;
+                partial_t p;
+                std::uint32_t it = 0;
+                for (; it + unroll_ak <= chunks_per_lane; it += unroll_ak) {
+                    uint4 v[unroll_ak];
 #pragma unroll
-                for (int u = 0; u < unroll_ak; ++u)
-                    v[u] = row[(std::size_t)(it + u) * lanes_ak];
-#pragma unroll
-                for (int u = 0; u < unroll_ak; ++u)
-                    accumulate_chunk<metric_ak, scalar_ak>(p, query_lds, sub + (it + u) * lanes_ak, v[u]);
-            }
-            if (it < chunks_per_lane) { // ragged tail: still issue every load before the first use
-                uint4 v[unroll_ak];
-#pragma unroll
-                for (int u = 0; u < unroll_ak; ++u)
-                    if (it + u < chunks_per_lane)
+                    for (int u = 0; u < unroll_ak; ++u)
                         v[u] = row[(std::size_t)(it + u) * lanes_ak];
 #pragma unroll
-                for (int u = 0; u < unroll_ak; ++u)
-                    if (it + u < chunks_per_lane)
+                    for (int u = 0; u < unroll_ak; ++u) {
                         accumulate_chunk<metric_ak, scalar_ak>(p, query_lds, sub + (it + u) * lanes_ak, v[u]);
+                        if constexpr (fence_ak)
+                            __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (it < chunks_per_lane) { // ragged tail: still issue every load before the first use
+                    uint4 v[unroll_ak];
+#pragma unroll
+                    for (int u = 0; u < unroll_ak; ++u)
+                        if (it + u < chunks_per_lane)
+                            v[u] = row[(std::size_t)(it + u) * lanes_ak];
+#pragma unroll
+                    for (int u = 0; u < unroll_ak; ++u)
+                        if (it + u < chunks_per_lane)
+                            accumulate_chunk<metric_ak, scalar_ak>(p, query_lds, sub + (it + u) * lanes_ak, v[u]);
+                }
+                reduce_partial<metric_ak, scalar_ak, lanes_ak>(p);
+                if (sub == 0)
+                    mem::store(out + ci, finalize_distance<metric_ak, scalar_ak>(p, a2, ix.dimensions));
             }
-            reduce_partial<metric_ak, scalar_ak, lanes_ak>(p);
-            if (sub == 0)
-                mem::store(out + ci, finalize_distance<metric_ak, scalar_ak>(p, a2, ix.dimensions));
+        }
+    } else {
+        for (std::uint32_t base = 0; base < count; base += rows_per_round * rows_ak) {
+            // row r of this group in this round; a row beyond `count` re-reads the group's first row (always present when the
+            // round runs at all for this group) so that the loads below need no predicate — its result is dropped
+            const std::uint32_t first = base + group;
+            if (first >= count)
+                continue;
+            const uint4* row[rows_ak];
+            bool present[rows_ak];
+#pragma unroll
+            for (int r = 0; r < rows_ak; ++r) {
+                const std::uint32_t ci = first + (std::uint32_t)r * rows_per_round;
+                present[r] = ci < count;
+                const std::uint32_t slot = mem::load(slots + (present[r] ? ci : first));
+                row[r] = reinterpret_cast<const uint4*>(ix.vectors + (std::uint64_t)slot * ix.row_stride) + sub;
+            }
+            partial_t p[rows_ak];
+            std::uint32_t it = 0;
+            for (; it + unroll_ak <= chunks_per_lane; it += unroll_ak) {
+                uint4 v[rows_ak][unroll_ak];
+#pragma unroll
+                for (int r = 0; r < rows_ak; ++r)
+#pragma unroll
+                    for (int u = 0; u < unroll_ak; ++u)
+                        v[r][u] = row[r][(std::size_t)(it + u) * lanes_ak];
+                // chunk by chunk, every row against the same query chunk (read from LDS once); the scheduling fence keeps the
+                // compiler from hoisting all the query reads to the top, which would cost a hundred registers
+#pragma unroll
+                for (int u = 0; u < unroll_ak; ++u) {
+#pragma unroll
+                    for (int r = 0; r < rows_ak; ++r)
+                        accumulate_chunk<metric_ak, scalar_ak>(p[r], query_lds, sub + (it + u) * lanes_ak, v[r][u]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (it < chunks_per_lane) { // ragged tail: a chunk beyond the row re-reads its last one and is not accumulated
+                uint4 v[rows_ak][unroll_ak];
+#pragma unroll
+                for (int r = 0; r < rows_ak; ++r)
+#pragma unroll
+                    for (int u = 0; u < unroll_ak; ++u) {
+                        const std::uint32_t chunk = it + u < chunks_per_lane ? it + u : chunks_per_lane - 1;
+                        v[r][u] = row[r][(std::size_t)chunk * lanes_ak];
+                    }
+#pragma unroll
+                for (int u = 0; u < unroll_ak; ++u) {
+                    if (it + u < chunks_per_lane) {
+#pragma unroll
+                        for (int r = 0; r < rows_ak; ++r)
+                            accumulate_chunk<metric_ak, scalar_ak>(p[r], query_lds, sub + (it + u) * lanes_ak, v[r][u]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < rows_ak; ++r) {
+                reduce_partial<metric_ak, scalar_ak, lanes_ak>(p[r]);
+                if (sub == 0 && present[r])
+                    mem::store(out + first + (std::uint32_t)r * rows_per_round,
+                               finalize_distance<metric_ak, scalar_ak>(p[r], a2, ix.dimensions));
+            }
         }
     }
     wave_sync<global_ak>();
@@ -1087,9 +1158,16 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     }
 
     std::uint32_t computed = 0, cycles = 0; // context_t counters, index.hpp:2208-2211
-    auto measure = [&](std::uint32_t count) {
-        measure_rows<metric_ak, scalar_ak, lanes_ak, unroll_ak, global_ak>(ix, query_lds, a2, cand_slots,
-                                                                           cand_distances, count);
+    // `unroll_ak` carries the rows a lane group takes per round in its hundreds (search_kernel packs it that way)
+    constexpr int loads_ak = unroll_ak % 100, rows_ak = unroll_ak / 100 + 1;
+    auto measure = [&](std::uint32_t count) { // the descent: a handful of rows per step, one row per lane group
+        measure_rows<metric_ak, scalar_ak, lanes_ak, loads_ak, global_ak, 1>(ix, query_lds, a2, cand_slots, cand_distances,
+                                                                            count);
+        computed += count;
+    };
+    auto measure_hop = [&](std::uint32_t count) { // the beam: up to M0 fresh neighbours per hop
+        measure_rows<metric_ak, scalar_ak, lanes_ak, loads_ak, global_ak, rows_ak>(ix, query_lds, a2, cand_slots,
+                                                                                   cand_distances, count);
         computed += count;
     };
     // index_dense.hpp:2071-2081: a member is a result candidate unless it is a tombstone or the caller's predicate
@@ -1185,6 +1263,10 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                           : ix.nbr0 + (std::uint64_t)slot * ix.m0;
     };
     std::uint32_t ahead_slot = none_slot_k, ahead_cell = none_slot_k; // list tile requested ahead of its hop
+    // rows stored next to the lists (`nbr0_rows`): one-chunk rows only, lists of one tile, level 0
+    constexpr bool inline_ak = lanes_ak == 1 && !global_ak;
+    const bool inline_rows = inline_ak && ix.nbr0_rows != nullptr && !beam_level && cells <= 64 && ix.chunks == 1;
+    uint4 ahead_row = {0u, 0u, 0u, 0u};
     tick(0);
     for (;;) {
         std::uint32_t expanded;
@@ -1214,6 +1296,18 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
         std::uint32_t first_cell = none_slot_k;
         if (!list_ready && lane < cells)
             first_cell = list[lane];
+        // rows of ≤ 16 bytes travel WITH the list: cell j of a node's list is followed, in `nbr0_rows`, by a copy of the row
+        // it names — one contiguous block per hop instead of a list line plus up to M0 scattered sectors, and no dependent
+        // round trip between "which neighbours" and "their vectors"
+        uint4 inline_row = {0u, 0u, 0u, 0u};
+        if constexpr (inline_ak) {
+            if (inline_rows) {
+                if (list_ready)
+                    inline_row = ahead_row;
+                else if (lane < cells)
+                    inline_row = reinterpret_cast<const uint4*>(ix.nbr0_rows)[(std::uint64_t)expanded * cells + lane];
+            }
+        }
         // next.pop() only touches LDS: it runs in the shadow of a memory round trip — of the list load when the list was
         // not requested ahead, else of the first probe of the visited set. Right after it the frontier's new best is the
         // likeliest next hop (unless this hop finds something closer): its list is requested then, so that the row
@@ -1225,14 +1319,18 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
             if constexpr (in_top_ak) { // the member was closed above; the next open one is the likeliest next hop
                 float ahead_distance;
                 std::uint32_t ahead_lane, ahead_index;
-                if (top.first_open(ahead_distance, ahead_slot, ahead_lane, ahead_index))
-                    ahead_cell = lane < cells ? list_of(ahead_slot)[lane] : none_slot_k;
+                if (!top.first_open(ahead_distance, ahead_slot, ahead_lane, ahead_index))
+                    ahead_slot = none_slot_k;
             } else {
                 heap_pop<global_ak>(next, next_size);
-                if (next_size) {
+                if (next_size)
                     ahead_slot = uniform_u32(cand_slot(mem::load(next)));
-                    ahead_cell = lane < cells ? list_of(ahead_slot)[lane] : none_slot_k;
-                }
+            }
+            if (ahead_slot != none_slot_k) {
+                ahead_cell = lane < cells ? list_of(ahead_slot)[lane] : none_slot_k;
+                if constexpr (inline_ak)
+                    if (inline_rows && lane < cells)
+                        ahead_row = reinterpret_cast<const uint4*>(ix.nbr0_rows)[(std::uint64_t)ahead_slot * cells + lane];
             }
         };
         if (in_top_ak || !list_ready || cells > 64 || mode_ak == scratch_global_k)
@@ -1274,16 +1372,32 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
             visits_count += count;
             if (!count)
                 continue;
-            if (fresh)
-                mem::store(cand_slots + rank_below(fresh_mask, lane), neighbor); // keeps list order
-            wave_sync<global_ak>();
-            measure(count);
+            float mine = 0.f;
+            std::uint32_t mine_slot = 0u;
+            bool candidate; // this lane holds a measured newcomer; lanes are in list order either way
+            if (inline_rows) {
+                // the row arrived with the list: every fresh lane measures its own neighbour, nothing is staged or gathered
+                if constexpr (inline_ak) {
+                    partial_t p;
+                    accumulate_chunk<metric_ak, scalar_ak>(p, query_lds, 0, inline_row);
+                    mine = finalize_distance<metric_ak, scalar_ak>(p, a2, ix.dimensions);
+                }
+                mine_slot = neighbor;
+                candidate = fresh;
+                computed += count;
+            } else {
+                if (fresh)
+                    mem::store(cand_slots + rank_below(fresh_mask, lane), neighbor); // keeps list order
+                wave_sync<global_ak>();
+                measure_hop(count);
+                mine = lane < count ? mem::load(cand_distances + lane) : 0.f;
+                mine_slot = lane < count ? mem::load(cand_slots + lane) : 0u;
+                candidate = lane < count;
+            }
             tick(3);
 
             // commit in list order with the reference's tests (index.hpp:4233-4240)
-            const float mine = lane < count ? mem::load(cand_distances + lane) : 0.f;
-            const std::uint32_t mine_slot = lane < count ? mem::load(cand_slots + lane) : 0u;
-            std::uint64_t pending = ballot(lane < count && (top.size < ef || mine < radius)); // radius only shrinks
+            std::uint64_t pending = ballot(candidate && (top.size < ef || mine < radius)); // radius only shrinks
             while (pending) {
                 const std::uint32_t i = (std::uint32_t)__ffsll((long long)pending) - 1;
                 pending &= pending - 1;
@@ -1370,23 +1484,19 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
  *  (`unroll`) against how many waves per SIMD the register allocator must leave room for (`waves`).
  */
 enum kernel_variant_t : int {
-    variant_u4_w4_k = 0,  ///< 4 loads in flight per lane
-    variant_u8_w3_k = 1,  ///< 8 loads in flight (8 loads under 128 VGPRs spills: measured 2× slower)
-    variant_u12_w2_k = 2, ///< 12 loads in flight (a whole 768-d f16 row per lane group)
-    variant_u12_w3_k = 3, ///< 12 loads in flight under the 168-VGPR budget (frontier_top_k builds only)
-    variant_u8_w4_k = 4,  ///< 8 loads in flight under the 128-VGPR budget (frontier_top_k builds only)
-    variant_count_k = 5,
+    variant_u4_w4_k = 0,    ///< 4 loads in flight per lane
+    variant_u8_w3_k = 1,    ///< 8 loads in flight (8 loads under 128 VGPRs spills: measured 2× slower)
+    variant_u12_w2_k = 2,   ///< 12 loads in flight (a whole 768-d f16 row per lane group)
+    variant_u12x2_w2_k = 3, ///< two rows per lane group per round, 12 loads each: 24 in flight (frontier_top_k builds only)
+    variant_count_k = 4,
 };
-constexpr int variant_unroll(int v) {
-    return v == variant_u4_w4_k ? 4 : (v == variant_u12_w2_k || v == variant_u12_w3_k) ? 12 : 8;
-}
+constexpr int variant_unroll(int v) { return v == variant_u4_w4_k ? 4 : v == variant_u8_w3_k ? 8 : 12; }
+constexpr int variant_rows(int v) { return v == variant_u12x2_w2_k ? 2 : 1; }
 /// Waves per SIMD the register budget of an instantiation is cut for (512 VGPRs per SIMD lane: 128 → 4, 168 → 3, 256 → 2);
 /// from the allocations the compiler reports for the widest rows (cos, G = 8) with `top` in `epl` register rows.
 constexpr int kernel_waves(int variant, int epl, int frontier = 0) {
-    if (variant == variant_u12_w3_k)
-        return 3;
-    if (variant == variant_u8_w4_k)
-        return 4;
+    if (variant == variant_u12x2_w2_k)
+        return 2;
     if (frontier) // without the heap's bookkeeping the 4-deep build fits 128 registers with any `top`
         return variant == variant_u4_w4_k ? 4 : variant == variant_u8_w3_k ? 3 : 2;
     return variant == variant_u4_w4_k ? (epl >= 8 ? 3 : 4) : variant == variant_u8_w3_k ? (epl >= 16 ? 2 : 3) : 2;
@@ -1395,7 +1505,7 @@ constexpr int kernel_waves(int variant, int epl, int frontier = 0) {
 template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak, int frontier_ak>
 __global__ __launch_bounds__(64, kernel_waves(variant_ak, epl_ak, frontier_ak)) void search_kernel(const snapshot_view_t ix,
                                                                                             const search_args_t args) {
-    constexpr int unroll_ak = variant_unroll(variant_ak);
+    constexpr int unroll_ak = variant_unroll(variant_ak) + 100 * (variant_rows(variant_ak) - 1); // rows ride in the hundreds
     extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
     std::uint8_t* query_lds = lds;
     const std::uint32_t query_bytes = query_lds_bytes<scalar_ak>(ix.chunks);

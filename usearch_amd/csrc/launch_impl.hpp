@@ -34,7 +34,7 @@ hipError_t launch_search_frontier(const launch_params_t& p, const snapshot_view_
     }
     if (p.frontier != frontier_heap_k)
         return hipErrorInvalidValue;
-    if constexpr (variant_ak == variant_u12_w3_k || variant_ak == variant_u8_w4_k)
+    if constexpr (variant_ak == variant_u12x2_w2_k)
         return hipErrorInvalidValue;
     else
         return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, epl_ak, frontier_heap_k>(p, view, args);
@@ -71,14 +71,11 @@ hipError_t launch_search_lanes(const launch_params_t& p, const snapshot_view_t& 
         switch (p.variant) {
         case variant_u8_w3_k: return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u8_w3_k>(p, view, args);
         case variant_u12_w2_k: return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u12_w2_k>(p, view, args);
-        case variant_u12_w3_k: // tighter register budgets: only the heap-less builds fit them
-        case variant_u8_w4_k:
+        case variant_u12x2_w2_k: // two rows per lane group per round: the registers only the heap-less builds have
             if constexpr (frontier_in_top_pair<scalar_ak>()) {
                 if (p.frontier != frontier_top_k || !p.entries_per_lane)
                     return hipErrorInvalidValue;
-                if (p.variant == variant_u12_w3_k)
-                    return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u12_w3_k>(p, view, args);
-                return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u8_w4_k>(p, view, args);
+                return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u12x2_w2_k>(p, view, args);
             }
             return hipErrorInvalidValue;
         default: break;
