@@ -256,7 +256,7 @@ def main() -> None:
     parser.add_argument("--connectivity", type=int, default=16)
     parser.add_argument("--expansion-add", type=int, default=128)
     parser.add_argument("--recall-queries", type=int, default=-1,
-                        help="queries with exact ground truth (-1 = the whole batch; sharded mode: 1000)")
+                        help="queries with exact ground truth (-1 = the batch, at most 10 000; sharded mode: 1000)")
     parser.add_argument("--cpu-seconds", type=float, default=12.0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-stress-rows", action="store_true")
@@ -373,7 +373,7 @@ def main() -> None:
     #      per-shard truths are merged on rank 0 (distance ascending). The metric is quoted at the smallest expansion of the
     #      sweep whose recall is >= 0.95 with 95 % confidence (lower end of the interval).
     recall, recall_half, expansion = None, None, args.expansion
-    sample = args.queries if args.recall_queries < 0 else min(args.recall_queries, args.queries)
+    sample = min(args.queries, 10_000) if args.recall_queries < 0 else min(args.recall_queries, args.queries)
     if sharded and args.recall_queries < 0:
         sample = min(1000, args.queries)
     by_distance = args.dtype in ("b1", "i8")

@@ -50,7 +50,7 @@ typedef struct usearch_amd_tuning_t {
     uint32_t next_cap;     /**< frontier heap capacity per query; 0 = 3 × expansion + 256 */
     uint32_t variant;      /**< kernel build: 0 = auto, 1 = 4 row loads in flight per lane (≤128 VGPRs, 16 waves/CU), 2 = 8 loads
                                 (≤168 VGPRs, 12 waves/CU), 3 = 12 loads (≤256 VGPRs, 8 waves/CU); for the in-`top` frontier also
-                                4 = 12 loads under 168 VGPRs, 5 = 8 loads under 128 VGPRs */
+                                4 = two rows per lane group per round, 2 × 12 loads in flight (8 waves/CU) */
     uint32_t mode;         /**< scratch placement: 0 = auto, 1 = visited set in LDS, 2 = visited set in a per-wave global
                                 hash (heaps stay in LDS), 3 = everything in global memory with exact sizes (slow) */
     uint32_t waves_per_cu; /**< persistent waves per compute unit; 0 = as many as LDS and registers admit (≤ 16) */

@@ -261,5 +261,18 @@ def distance(a: np.ndarray, b: np.ndarray, metric: str, dtype: str, ndim: int) -
     return float(lib().usearch_distance(_ptr(a), _ptr(b), SCALAR[dtype], ndim, METRIC[metric], C.byref(err)))
 
 
+def metadata(buffer: np.ndarray) -> dict:
+    """`usearch_metadata_buffer` (c/usearch.h:223-224): what the REFERENCE reads from the head of a serialized image."""
+    options = InitOptions()
+    err = C.c_char_p()
+    buffer = np.ascontiguousarray(buffer, dtype=np.uint8)
+    L = lib()
+    L.usearch_metadata_buffer.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(InitOptions), C.POINTER(C.c_char_p)]
+    L.usearch_metadata_buffer(_ptr(buffer), len(buffer), C.byref(options), C.byref(err))
+    _check(err, "usearch_metadata_buffer")
+    return {"metric_kind": options.metric_kind, "quantization": options.quantization, "dimensions": options.dimensions,
+            "connectivity": options.connectivity, "multi": bool(options.multi)}
+
+
 def max_threads() -> int:
     return int(lib().uref_max_threads())

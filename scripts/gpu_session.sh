@@ -25,6 +25,12 @@ for step in "$@"; do
                 > "$OUT/c4small.json" 2> "$OUT/c4small.log"; tail -8 "$OUT/c4small.log"; cat "$OUT/c4small.json" ;;
     c5small)  timeout 600 python bench.py --n 20000000 --dim 128 --dtype b1 --queries 100000 --no-stress-rows --cpu-seconds 4 \
                 > "$OUT/c5small.json" 2> "$OUT/c5small.log"; tail -8 "$OUT/c5small.log"; cat "$OUT/c5small.json" ;;
+    c5ab)     for inline in 0 1; do USEARCH_AMD_INLINE_ROWS=$inline timeout 300 python bench.py --n 20000000 --dim 128 --dtype b1 \
+                --queries 100000 --expansion 64 --recall-queries 1000 --no-stress-rows --no-cpu-baseline --steps 5 \
+                > "$OUT/c5_inline$inline.json" 2> "$OUT/c5_inline$inline.log"; cat "$OUT/c5_inline$inline.json"; done ;;
+    c4ab)     for dense in 1 0; do USEARCH_AMD_DENSE_ROWS=$dense timeout 300 python bench.py --n 20000000 --dim 96 --dtype i8 \
+                --queries 100000 --expansion 96 --recall-queries 1000 --no-stress-rows --no-cpu-baseline --steps 5 \
+                > "$OUT/c4_dense$dense.json" 2> "$OUT/c4_dense$dense.log"; cat "$OUT/c4_dense$dense.json"; done ;;
     *) echo "unknown step $step" ;;
   esac
 done

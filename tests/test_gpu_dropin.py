@@ -309,3 +309,169 @@ def test_batch_and_buffers_match_the_reference(lib, reference):
     ok(err)
     assert np.array_equal(copy, image)
     lib.usearch_free(index, C.byref(err))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+#  Behaviour a long-lived caller depends on: incremental adds, in-place removal, capacity, the multi flag, bad files,
+#  concurrent searches
+# ---------------------------------------------------------------------------------------------------------------------
+
+def search_one(lib, index, query, k):
+    err = C.c_char_p()
+    keys, distances = np.zeros(k, dtype=np.uint64), np.zeros(k, dtype=np.float32)
+    found = lib.usearch_search(index, ptr(query), SCALAR["f32"], k, ptr(keys), ptr(distances), C.byref(err))
+    ok(err)
+    return found, keys, distances
+
+
+def test_add_after_a_search_links_only_the_new_members(lib):
+    """index_gt::add (index.hpp:2780-2879) on a built index: the graph is extended, not rebuilt — every old and new member is
+    still found first by its own vector, and an interleaved add / search loop stays cheap."""
+    import time
+    err = C.c_char_p()
+    dimensions, first, more = 32, 3000, 1200
+    options = create_options(dimensions, metric_kind=METRIC["l2sq"], connectivity=16, expansion_add=128, expansion_search=64)
+    data = create_vectors(first + more + 64, dimensions, seed=5)
+    index = lib.usearch_init(C.byref(options), C.byref(err))
+    ok(err)
+    lib.usearch_reserve(index, first + more + 64, C.byref(err))
+    for i in range(first):
+        lib.usearch_add(index, i, ptr(data[i]), SCALAR["f32"], C.byref(err))
+        ok(err)
+    assert search_one(lib, index, data[7], 1)[1][0] == 7  # builds the first 3000
+    for i in range(first, first + more):
+        lib.usearch_add(index, i, ptr(data[i]), SCALAR["f32"], C.byref(err))
+        ok(err)
+    t0 = time.perf_counter()
+    found, keys, distances = search_one(lib, index, data[first + 5], 3)  # links the 1200 new members only
+    extend_seconds = time.perf_counter() - t0
+    assert keys[0] == first + 5 and distances[0] == 0.0
+    missed = sum(search_one(lib, index, data[i], 1)[1][0] != i for i in range(0, first + more, 37))
+    assert missed == 0
+    assert lib.usearch_size(index, C.byref(err)) == first + more
+    # one member at a time, searched right away: each step links one member
+    t0 = time.perf_counter()
+    for i in range(first + more, first + more + 64):
+        lib.usearch_add(index, i, ptr(data[i]), SCALAR["f32"], C.byref(err))
+        ok(err)
+        assert search_one(lib, index, data[i], 1)[1][0] == i
+    single_seconds = (time.perf_counter() - t0) / 64
+    print(f"extend by {more}: {extend_seconds * 1e3:.1f} ms; add + search one at a time: {single_seconds * 1e3:.2f} ms each")
+    assert single_seconds < 0.25
+    # what was extended saves and loads like anything else, and the reference reads it
+    length = lib.usearch_serialized_length(index, C.byref(err))
+    buffer = np.zeros(length, dtype=np.uint8)
+    lib.usearch_save_buffer(index, ptr(buffer), length, C.byref(err))
+    ok(err)
+    reference_index = refbind.RefIndex.from_buffer(buffer, view=True, dtype="f32")
+    rkeys, *_ = reference_index.search(data[: first + more + 64: 41], 1, dtype="f32", threads=1)
+    assert np.array_equal(rkeys[:, 0], np.arange(0, first + more + 64, 41, dtype=np.uint64))
+    lib.usearch_free(index, C.byref(err))
+
+
+def test_remove_and_rename_do_not_relink(lib):
+    """index_dense_gt::remove (index_dense.hpp:1479-1511) leaves the member in the graph as a tombstone; rename rewrites the
+    key. Neither touches a list: the serialized graph before and after differs in the keys only."""
+    err = C.c_char_p()
+    index, data = filled_index(lib, 400, 24, options=create_options(24, metric_kind=METRIC["l2sq"], connectivity=8))
+    assert search_one(lib, index, data[10], 1)[1][0] == 10
+
+    def serialized():
+        length = lib.usearch_serialized_length(index, C.byref(err))
+        buffer = np.zeros(length, dtype=np.uint8)
+        lib.usearch_save_buffer(index, ptr(buffer), length, C.byref(err))
+        ok(err)
+        return buffer
+    before = serialized()
+    assert lib.usearch_remove(index, 10, C.byref(err)) == 1
+    assert lib.usearch_rename(index, 11, 900011, C.byref(err)) == 1
+    found, keys, _ = search_one(lib, index, data[10], 5)
+    assert 10 not in keys[:found] and found == 5
+    assert search_one(lib, index, data[11], 1)[1][0] == 900011
+    after = serialized()
+    assert len(before) == len(after)
+    changed = np.nonzero(before != after)[0]
+    assert 0 < len(changed) <= 16 + 16, "only the two keys and the present / deleted counts of the head may differ"
+    lib.usearch_free(index, C.byref(err))
+
+
+def test_capacity_multi_and_damaged_files(lib):
+    err = C.c_char_p()
+    # index.hpp:2812-2818: no room, no insertion
+    options = create_options(8)
+    index = lib.usearch_init(C.byref(options), C.byref(err))
+    vector = np.ones(8, dtype=np.float32)
+    lib.usearch_add(index, 1, ptr(vector), SCALAR["f32"], C.byref(err))
+    assert err.value and b"Reserve capacity" in err.value
+    err = C.c_char_p()
+    lib.usearch_reserve(index, 2, C.byref(err))
+    lib.usearch_add(index, 1, ptr(vector), SCALAR["f32"], C.byref(err))
+    ok(err)
+    lib.usearch_free(index, C.byref(err))
+    # the multi flag survives save → load (head.multi, index_dense.hpp:1046) and the reference sees it too
+    options = create_options(8, multi=True)
+    index = lib.usearch_init(C.byref(options), C.byref(err))
+    lib.usearch_reserve(index, 8, C.byref(err))
+    for i in range(4):
+        lib.usearch_add(index, 42, ptr(np.full(8, i, dtype=np.float32)), SCALAR["f32"], C.byref(err))
+        ok(err)
+    assert lib.usearch_count(index, 42, C.byref(err)) == 4
+    length = lib.usearch_serialized_length(index, C.byref(err))
+    buffer = np.zeros(length, dtype=np.uint8)
+    lib.usearch_save_buffer(index, ptr(buffer), length, C.byref(err))
+    ok(err)
+    loaded = lib.usearch_init(None, C.byref(err))
+    lib.usearch_load_buffer(loaded, ptr(buffer), length, C.byref(err))
+    ok(err)
+    lib.usearch_reserve(loaded, 8, C.byref(err))
+    lib.usearch_add(loaded, 42, ptr(np.full(8, 9, dtype=np.float32)), SCALAR["f32"], C.byref(err))
+    ok(err)  # a duplicate key is fine in a multi-index
+    assert lib.usearch_count(loaded, 42, C.byref(err)) == 5
+    assert refbind.metadata(buffer)["multi"]
+    # a truncated image is refused when it is loaded, not when a later call walks its tapes
+    for cut in (len(buffer) - 1, len(buffer) - 40, len(buffer) // 2):
+        broken = lib.usearch_init(None, C.byref(err))
+        failure = C.c_char_p()
+        lib.usearch_load_buffer(broken, ptr(buffer[:cut].copy()), cut, C.byref(failure))
+        assert failure.value, f"a file cut at {cut} of {len(buffer)} bytes was accepted"
+        assert lib.usearch_size(broken, C.byref(err)) == 0 and not lib.usearch_contains(broken, 42, C.byref(err))
+        lib.usearch_free(broken, C.byref(err))
+    lib.usearch_free(index, C.byref(err))
+    lib.usearch_free(loaded, C.byref(err))
+
+
+def test_concurrent_callers_share_the_index(lib):
+    """The reference leases a context per thread (index_dense.hpp:1984-2000); here every call in flight leases a workspace.
+    Eight threads looping `usearch_search` get the answers a single thread gets."""
+    import threading
+    err = C.c_char_p()
+    index, data = filled_index(lib, 2000, 48, options=create_options(48, metric_kind=METRIC["cos"], connectivity=16,
+                                                                     expansion_add=64, expansion_search=64))
+    lib.usearch_change_threads_search(index, 8, C.byref(err))
+    expected = [search_one(lib, index, data[i], 5)[1].copy() for i in range(200)]
+    failures = []
+
+    def worker(offset):
+        for i in range(offset, 200, 8):
+            for _ in range(3):
+                if not np.array_equal(search_one(lib, index, data[i], 5)[1], expected[i]):
+                    failures.append(i)
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures
+    lib.usearch_free(index, C.byref(err))
+
+
+def test_the_references_own_c_test_program_passes_against_the_drop_in():
+    """/root/reference/c/test.c itself, compiled by `__graft_entry__.build()` where the reference is mounted and linked against
+    usearch_amd/lib/libusearch_c.so instead of the reference's library (oracle/Makefile `dropin_test` → oracle/_ref/)."""
+    import subprocess
+    binary = os.path.join(ROOT, "oracle", "_ref", "reference_test_c")
+    if not os.path.exists(binary):
+        pytest.skip("oracle/_ref/reference_test_c was not built (`make -C oracle dropin_test` needs /root/reference)")
+    environment = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "usearch_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    result = subprocess.run([binary], capture_output=True, text=True, timeout=600, env=environment)
+    assert result.returncode == 0, result.stdout[-2000:] + result.stderr[-2000:]

@@ -53,9 +53,8 @@ struct device_block_t {
 } // namespace
 
 const char* snapshot_t::allocate_for_build(metric_kind_t metric, scalar_kind_t scalar, std::size_t dimensions,
-                                           std::uint64_t capacity, std::uint32_t m, std::uint32_t m0,
-                                           const std::int16_t* levels, const void* vectors, std::size_t stride,
-                                           bool vectors_on_device, const std::uint64_t* keys, int device) {
+                                           std::uint64_t capacity, std::uint64_t lists_capacity, std::uint32_t m,
+                                           std::uint32_t m0, int device) {
     if (!kernel_available(metric, scalar))
         return "No MI355X kernel for this metric / scalar kind combination";
     release();
@@ -63,75 +62,131 @@ const char* snapshot_t::allocate_for_build(metric_kind_t metric, scalar_kind_t s
     UA_HIP(hipSetDevice(device));
     metric_ = metric;
     scalar_ = scalar;
-    count_present_ = capacity;
-    const std::uint64_t n = capacity;
+    count_present_ = 0;
+    upper_lists_ = 0;
     const std::uint32_t bpv = (std::uint32_t)bytes_per_vector(scalar, dimensions);
     std::uint32_t row_stride = 0, row_chunks = 0;
     row_geometry(bpv, lanes_, row_stride, row_chunks);
 
-    std::vector<std::uint32_t> upper_ref(n);
-    std::uint64_t lists = 0;
-    for (std::uint64_t i = 0; i < n; ++i) {
-        upper_ref[i] = levels[i] ? (std::uint32_t)lists : none_slot_k;
-        lists += (std::uint64_t)levels[i];
-    }
-    if (lists >= none_slot_k)
-        return "Too many upper-level lists for 32-bit references";
-    upper_lists_ = lists;
-
-    device_bytes_ = 0;
-    auto allocate = [&](void** p, std::size_t bytes) -> hipError_t {
-        device_bytes_ += std::max<std::size_t>(bytes, 16);
-        return hipMalloc(p, std::max<std::size_t>(bytes, 16));
-    };
-    const std::size_t nbr0_bytes = (std::size_t)n * m0 * 4, upper_bytes = (std::size_t)std::max<std::uint64_t>(lists, 1) * m * 4;
-    UA_HIP(allocate(&d_vectors_, (std::size_t)n * row_stride));
-    UA_HIP(allocate(&d_nbr0_, nbr0_bytes));
-    UA_HIP(allocate(&d_upper_ref_, n * 4));
-    UA_HIP(allocate(&d_upper_, upper_bytes));
-    UA_HIP(allocate(&d_keys_, n * 8));
-    UA_HIP(hipMemset(d_nbr0_, 0xFF, std::max<std::size_t>(nbr0_bytes, 16))); // every cell = none_slot_k
-    UA_HIP(hipMemset(d_upper_, 0xFF, upper_bytes));
-    UA_HIP(hipMemcpy(d_upper_ref_, upper_ref.data(), n * 4, hipMemcpyHostToDevice));
-    if (vectors_on_device) {
-        if (row_stride == bpv && stride == bpv) {
-            UA_HIP(hipMemcpy(d_vectors_, vectors, (std::size_t)n * bpv, hipMemcpyDeviceToDevice));
-        } else {
-            UA_HIP(hipMemset(d_vectors_, 0, (std::size_t)n * row_stride));
-            UA_HIP(hipMemcpy2D(d_vectors_, row_stride, vectors, stride, bpv, n, hipMemcpyDeviceToDevice));
-        }
-    } else if (const char* e = upload_rows(static_cast<std::uint8_t*>(d_vectors_), row_stride,
-                                           static_cast<const std::uint8_t*>(vectors), stride, bpv, n)) {
-        return e;
-    }
-    if (keys) {
-        UA_HIP(hipMemcpy(d_keys_, keys, n * 8, hipMemcpyHostToDevice));
-    } else {
-        std::vector<std::uint64_t> identity(n);
-        for (std::uint64_t i = 0; i < n; ++i)
-            identity[i] = i;
-        UA_HIP(hipMemcpy(d_keys_, identity.data(), n * 8, hipMemcpyHostToDevice));
-    }
-
     view_ = snapshot_view_t{};
-    view_.vectors = static_cast<const std::uint8_t*>(d_vectors_);
-    view_.nbr0 = static_cast<const std::uint32_t*>(d_nbr0_);
-    view_.upper_ref = static_cast<const std::uint32_t*>(d_upper_ref_);
-    view_.upper = static_cast<const std::uint32_t*>(d_upper_);
-    view_.keys = static_cast<const std::uint64_t*>(d_keys_);
-    view_.size = 0;
     view_.row_stride = row_stride;
     view_.chunks = row_chunks;
     view_.bytes_per_vector = bpv;
     view_.dimensions = (std::uint32_t)dimensions;
     view_.m = m;
     view_.m0 = m0;
+    device_bytes_ = 0;
+    build_capacity_ = build_lists_capacity_ = 0;
+    if (const char* e = grow_for_build(capacity, lists_capacity))
+        return e;
 
     hipDeviceProp_t properties;
     UA_HIP(hipGetDeviceProperties(&properties, device));
     compute_units_ = properties.multiProcessorCount > 0 ? properties.multiProcessorCount : 256;
     UA_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     return nullptr;
+}
+
+const char* snapshot_t::grow_for_build(std::uint64_t capacity, std::uint64_t lists_capacity) {
+    capacity = std::max<std::uint64_t>(capacity, build_capacity_);
+    lists_capacity = std::max<std::uint64_t>(std::max<std::uint64_t>(lists_capacity, 1), build_lists_capacity_);
+    if (capacity == build_capacity_ && lists_capacity == build_lists_capacity_)
+        return nullptr;
+    if (capacity >= none_slot_k || lists_capacity >= none_slot_k)
+        return "Index is too large for 32-bit slots";
+    UA_HIP(hipSetDevice(device_));
+    const std::uint32_t m = view_.m, m0 = view_.m0, row_stride = view_.row_stride;
+    // every array is re-allocated at the new size and the linked part copied over, device to device; new cells are empty
+    struct array_t {
+        void** pointer;
+        std::size_t old_bytes, new_bytes;
+        int fill; // byte value of the fresh part
+    };
+    array_t arrays[] = {
+        {&d_vectors_, (std::size_t)build_capacity_ * row_stride, (std::size_t)capacity * row_stride, 0},
+        {&d_nbr0_, (std::size_t)build_capacity_ * m0 * 4, (std::size_t)capacity * m0 * 4, 0xFF},
+        {&d_upper_ref_, (std::size_t)build_capacity_ * 4, (std::size_t)capacity * 4, 0xFF},
+        {&d_upper_, (std::size_t)build_lists_capacity_ * m * 4, (std::size_t)lists_capacity * m * 4, 0xFF},
+        {&d_keys_, (std::size_t)build_capacity_ * 8, (std::size_t)capacity * 8, 0},
+    };
+    for (array_t& array : arrays) {
+        if (array.new_bytes == array.old_bytes && *array.pointer)
+            continue;
+        void* fresh = nullptr;
+        UA_HIP(hipMalloc(&fresh, std::max<std::size_t>(array.new_bytes, 16)));
+        if (array.old_bytes && *array.pointer)
+            UA_HIP(hipMemcpy(fresh, *array.pointer, array.old_bytes, hipMemcpyDeviceToDevice));
+        if (array.new_bytes > array.old_bytes)
+            UA_HIP(hipMemset(static_cast<std::uint8_t*>(fresh) + array.old_bytes, array.fill, array.new_bytes - array.old_bytes));
+        if (*array.pointer)
+            (void)hipFree(*array.pointer);
+        *array.pointer = fresh;
+        device_bytes_ += std::max<std::size_t>(array.new_bytes, 16) - (array.old_bytes ? std::max<std::size_t>(array.old_bytes, 16) : 0);
+    }
+    build_capacity_ = capacity;
+    build_lists_capacity_ = lists_capacity;
+    view_.vectors = static_cast<const std::uint8_t*>(d_vectors_);
+    view_.nbr0 = static_cast<const std::uint32_t*>(d_nbr0_);
+    view_.upper_ref = static_cast<const std::uint32_t*>(d_upper_ref_);
+    view_.upper = static_cast<const std::uint32_t*>(d_upper_);
+    view_.keys = static_cast<const std::uint64_t*>(d_keys_);
+    if (d_nbr0_rows_) { // laid out for the old arrays: rebuilt by the next finalize_layout
+        (void)hipFree(d_nbr0_rows_);
+        d_nbr0_rows_ = nullptr;
+        view_.nbr0_rows = nullptr;
+    }
+    return nullptr;
+}
+
+const char* snapshot_t::append_for_build(std::uint64_t first, std::uint64_t count, const std::uint32_t* upper_refs,
+                                         const void* vectors, std::size_t stride, bool vectors_on_device,
+                                         const std::uint64_t* keys) {
+    if (!count)
+        return nullptr;
+    if (first + count > build_capacity_)
+        return "The build arrays are too small";
+    UA_HIP(hipSetDevice(device_));
+    const std::uint32_t bpv = view_.bytes_per_vector, row_stride = view_.row_stride;
+    std::uint8_t* rows = static_cast<std::uint8_t*>(d_vectors_) + first * row_stride;
+    if (vectors_on_device) {
+        if (row_stride == bpv && stride == bpv)
+            UA_HIP(hipMemcpy(rows, vectors, (std::size_t)count * bpv, hipMemcpyDeviceToDevice));
+        else // the padding was zeroed when the array was allocated
+            UA_HIP(hipMemcpy2D(rows, row_stride, vectors, stride, bpv, count, hipMemcpyDeviceToDevice));
+    } else if (const char* e = upload_rows(rows, row_stride, static_cast<const std::uint8_t*>(vectors), stride, bpv, count)) {
+        return e;
+    }
+    UA_HIP(hipMemcpy(static_cast<std::uint32_t*>(d_upper_ref_) + first, upper_refs, count * 4, hipMemcpyHostToDevice));
+    if (keys) {
+        UA_HIP(hipMemcpy(static_cast<std::uint64_t*>(d_keys_) + first, keys, count * 8, hipMemcpyHostToDevice));
+    } else {
+        std::vector<std::uint64_t> identity(count);
+        for (std::uint64_t i = 0; i < count; ++i)
+            identity[i] = first + i;
+        UA_HIP(hipMemcpy(static_cast<std::uint64_t*>(d_keys_) + first, identity.data(), count * 8, hipMemcpyHostToDevice));
+    }
+    count_present_ = first + count;
+    return nullptr;
+}
+
+const char* snapshot_t::set_key(std::uint64_t slot, std::uint64_t key) {
+    if (slot >= view_.size && slot >= build_capacity_)
+        return "No such member";
+    UA_HIP(hipSetDevice(device_));
+    UA_HIP(hipMemcpy(static_cast<std::uint64_t*>(d_keys_) + slot, &key, 8, hipMemcpyHostToDevice));
+    if (key == free_key_k)
+        view_.has_tombstones = 1;
+    return nullptr;
+}
+
+builder_t::~builder_t() { release_workspace(); }
+
+void builder_t::release_workspace() {
+    for (void* p : workspace_)
+        if (p)
+            (void)hipFree(p);
+    workspace_.clear();
+    workspace_nodes_ = 0;
 }
 
 const char* builder_t::build(metric_kind_t metric, scalar_kind_t scalar, std::size_t dimensions, const void* vectors,
@@ -151,11 +206,9 @@ const char* builder_t::build(metric_kind_t metric, scalar_kind_t scalar, std::si
         return "Connectivity must be at least 2";
     if (!config_.connectivity_base)
         config_.connectivity_base = 2 * m;
-    const std::uint32_t m0 = config_.connectivity_base;
-    const std::uint32_t widest = std::max(m, m0);
+    const std::uint32_t widest = std::max(m, config_.connectivity_base);
     if (widest > 56)
         return "Connectivity is too large for the device builder (base connectivity must not exceed 56)";
-    const std::uint32_t inbox_cap = std::min<std::uint32_t>(32, 64 - widest); // existing + incoming fit one wave
     const std::uint32_t ef = std::max<std::uint32_t>(widest + 1, config_.expansion_add); // index.hpp:2799-2800
     if (ef > build_max_candidates_k)
         return "Expansion is too large for the device builder";
@@ -163,82 +216,185 @@ const char* builder_t::build(metric_kind_t metric, scalar_kind_t scalar, std::si
         return "Stride is smaller than one vector";
     config_.batch_divisor = std::max<std::uint32_t>(1, config_.batch_divisor);
     config_.max_batch = std::max<std::uint32_t>(1, config_.max_batch);
-    metric_ = metric, scalar_ = scalar, dimensions_ = dimensions, size_ = count;
+    metric_ = metric, scalar_ = scalar, dimensions_ = dimensions;
+    size_ = 0, upper_lists_ = 0, entry_slot_ = 0, max_level_ = 0;
+    levels_.clear();
+    keys_.clear();
+    identity_keys_ = keys == nullptr;
+    generator_.seed(config_.seed); // one seeded generator for the whole life of the index: levels do not depend on how the
+                                   // vectors arrive (one call or many `extend`s)
+    release_workspace();
+    // the first call knows its size: exact arrays; later `extend`s grow them geometrically
+    if (const char* e = snapshot_.allocate_for_build(metric, scalar, dimensions, 0, 0, m, config_.connectivity_base, device))
+        return e;
+    const char* error = extend(vectors, count, stride, vectors_on_device, keys, true);
+    stats_.seconds_total = seconds_now() - t_begin;
+    return error;
+}
 
-    // ---- levels: the reference's distribution (index.hpp:3895-3899), one seeded generator for the whole index
-    levels_.resize(count);
+const char* builder_t::extend(const void* vectors, std::uint64_t count, std::size_t stride, bool vectors_on_device,
+                              const std::uint64_t* keys, bool exact_capacity) {
+    const double t_begin = seconds_now();
+    if (!count)
+        return nullptr;
+    if (!vectors)
+        return "Nothing to add";
+    const std::uint64_t first = size_, total = size_ + count;
+    if (total >= none_slot_k)
+        return "Index is too large for 32-bit slots";
+    if (stride < bytes_per_vector(scalar_, dimensions_))
+        return "Stride is smaller than one vector";
+    if (!keys && !identity_keys_)
+        return "Keys are needed: earlier members have them";
+    if (keys && identity_keys_ && first) { // earlier members were keyed by their row number
+        keys_.resize(first);
+        for (std::uint64_t i = 0; i < first; ++i)
+            keys_[i] = i;
+    }
+    const std::uint32_t m = config_.connectivity;
+
+    // ---- levels: the reference's distribution (index.hpp:3895-3899)
+    levels_.resize(total);
+    std::vector<std::uint32_t> upper_refs(count);
     {
-        std::mt19937_64 generator(config_.seed);
         std::uniform_real_distribution<double> uniform(0.0, 1.0);
         const double inverse_log_connectivity = 1.0 / std::log((double)m);
-        for (std::uint64_t i = 0; i < count; ++i) {
-            double u = uniform(generator);
+        for (std::uint64_t i = first; i < total; ++i) {
+            double u = uniform(generator_);
             if (u <= 0.0)
                 u = 1e-300;
             const double r = -std::log(u) * inverse_log_connectivity;
             levels_[i] = (std::int16_t)std::min(r, 30.0);
+            upper_refs[i - first] = levels_[i] ? (std::uint32_t)upper_lists_ : none_slot_k;
+            upper_lists_ += (std::uint64_t)levels_[i];
         }
     }
-    keys_.clear();
-    if (keys)
-        keys_.assign(keys, keys + count);
+    if (upper_lists_ >= none_slot_k)
+        return "Too many upper-level lists for 32-bit references";
+    if (keys) {
+        identity_keys_ = false;
+        keys_.insert(keys_.end(), keys, keys + count);
+    }
 
+    // ---- room: exact on the first call, doubling afterwards (plus the upper-level lists the spare members will need:
+    //      a member has 1 / (M - 1) of them on average)
     const double t_upload = seconds_now();
-    if (const char* e = snapshot_.allocate_for_build(metric, scalar, dimensions, count, m, m0, levels_.data(), vectors,
-                                                     stride, vectors_on_device, keys, device))
+    std::uint64_t capacity = total, lists_capacity = upper_lists_;
+    if (!exact_capacity && total > snapshot_.build_capacity()) {
+        capacity = std::max<std::uint64_t>(total, std::min<std::uint64_t>(2 * snapshot_.build_capacity(), none_slot_k - 2));
+        capacity = std::max<std::uint64_t>(capacity, 1024);
+    }
+    if (!exact_capacity && (upper_lists_ > snapshot_.build_lists_capacity() || capacity > snapshot_.build_capacity()))
+        lists_capacity = upper_lists_ + (capacity - total) / std::max<std::uint32_t>(m - 1, 1) * 3 / 2 + 1024;
+    if (const char* e = snapshot_.grow_for_build(capacity, lists_capacity))
         return e;
-    stats_.seconds_upload = seconds_now() - t_upload;
-    upper_lists_ = snapshot_.upper_lists();
-    const snapshot_view_t& view = snapshot_.view();
+    if (const char* e = snapshot_.append_for_build(first, count, upper_refs.data(), vectors, stride, vectors_on_device, keys))
+        return e;
+    stats_.seconds_upload += seconds_now() - t_upload;
+    snapshot_.set_upper_lists(upper_lists_);
+
+    if (!first)
+        max_level_ = (std::uint32_t)levels_[0], entry_slot_ = 0; // the first node only becomes the entry point, index.hpp:2835-2840
+    size_ = total;
+    snapshot_.suspend_layout(); // lists change from here on: the rows copied next to them would go stale
+    if (const char* e = link_range(std::max<std::uint64_t>(first, 1), total))
+        return e;
+    snapshot_.set_frontier(total, entry_slot_, max_level_);
+    // removed members (key == free_key_, index_dense.hpp:513) were linked like any other node — the reference keeps them in
+    // the graph too — and stop matching from here on
+    bool tombstones = false;
+    for (std::uint64_t key : keys_)
+        tombstones |= key == free_key_k;
+    snapshot_.set_tombstones(tombstones);
+    if (const char* e = snapshot_.finalize_layout()) // the graph is final for now: rows of ≤ 16 bytes move next to the lists
+        return e;
+    stats_.max_level = max_level_;
+    stats_.seconds_total += seconds_now() - t_begin;
+    return nullptr;
+}
+
+const char* builder_t::set_key(std::uint64_t slot, std::uint64_t key) {
+    if (slot >= size_)
+        return "No such member";
+    if (identity_keys_) {
+        keys_.resize(size_);
+        for (std::uint64_t i = 0; i < size_; ++i)
+            keys_[i] = i;
+        identity_keys_ = false;
+    }
+    keys_[slot] = key;
+    return snapshot_.set_key(slot, key);
+}
+
+/// Links members [begin, end) into the graph of the members before them, batch by batch.
+const char* builder_t::link_range(std::uint64_t begin, const std::uint64_t end_total) {
+    if (begin >= end_total)
+        return nullptr;
+    const metric_kind_t metric = metric_;
+    const scalar_kind_t scalar = scalar_;
+    const std::uint32_t m = config_.connectivity, m0 = config_.connectivity_base;
+    const std::uint32_t widest = std::max(m, m0);
+    const std::uint32_t inbox_cap = std::min<std::uint32_t>(32, 64 - widest); // existing + incoming fit one wave
+    const std::uint32_t ef = std::max<std::uint32_t>(widest + 1, config_.expansion_add);
+    UA_HIP(hipSetDevice(snapshot_.device()));
     hipStream_t stream = snapshot_.stream();
 
-    const std::uint64_t max_batch = std::min<std::uint64_t>(config_.max_batch, count);
-    device_block_t block;
-    std::uint32_t *d_nodes = nullptr, *d_inbox_count = nullptr, *d_touched = nullptr, *d_touched_count = nullptr;
-    std::uint64_t *d_cand_slots = nullptr, *d_cand_counts = nullptr, *d_visited = nullptr, *d_computed = nullptr;
-    cand_t* d_inbox = nullptr;
-    float* d_cand_distances = nullptr;
-    unsigned long long* d_counters = nullptr;
-    UA_HIP(block.allocate(&d_nodes, max_batch * 4));
-    UA_HIP(block.allocate(&d_cand_slots, max_batch * ef * 8));
-    UA_HIP(block.allocate(&d_cand_distances, max_batch * ef * 4));
-    UA_HIP(block.allocate(&d_cand_counts, max_batch * 8));
-    UA_HIP(block.allocate(&d_visited, max_batch * 8));
-    UA_HIP(block.allocate(&d_computed, max_batch * 8));
-    UA_HIP(block.allocate(&d_inbox_count, count * 4));
-    UA_HIP(block.allocate(&d_inbox, count * inbox_cap * 8));
-    UA_HIP(block.allocate(&d_touched, max_batch * m * 4));
-    UA_HIP(block.allocate(&d_touched_count, 16));
-    UA_HIP(block.allocate(&d_counters, 64));
-    UA_HIP(hipMemset(d_inbox_count, 0, count * 4));
-    UA_HIP(hipMemset(d_counters, 0, 64));
+    // ---- workspace: per-batch arrays sized for the largest batch, per-member inboxes for the arrays' capacity; kept between
+    //      calls (the link kernels leave every inbox empty), re-made when the arrays have grown
+    const std::uint64_t max_batch = std::max<std::uint64_t>(1, std::min<std::uint64_t>(config_.max_batch, std::max<std::uint64_t>(end_total, 1)));
+    const std::uint64_t members = snapshot_.build_capacity();
+    if (workspace_nodes_ < members || workspace_batch_ < max_batch) {
+        release_workspace();
+        auto allocate = [&](void** out, std::size_t bytes) -> hipError_t {
+            void* p = nullptr;
+            const hipError_t e = hipMalloc(&p, std::max<std::size_t>(bytes, 16));
+            if (e == hipSuccess)
+                workspace_.push_back(p);
+            *out = p;
+            return e;
+        };
+        UA_HIP(allocate((void**)&d_nodes_, max_batch * 4));
+        UA_HIP(allocate((void**)&d_cand_slots_, max_batch * ef * 8));
+        UA_HIP(allocate((void**)&d_cand_distances_, max_batch * ef * 4));
+        UA_HIP(allocate((void**)&d_cand_counts_, max_batch * 8));
+        UA_HIP(allocate((void**)&d_visited_, max_batch * 8));
+        UA_HIP(allocate((void**)&d_computed_, max_batch * 8));
+        UA_HIP(allocate((void**)&d_inbox_count_, members * 4));
+        UA_HIP(allocate((void**)&d_inbox_, members * inbox_cap * 8));
+        UA_HIP(allocate((void**)&d_touched_, max_batch * m * 4));
+        UA_HIP(allocate((void**)&d_touched_count_, 16));
+        UA_HIP(allocate((void**)&d_counters_, 64));
+        UA_HIP(hipMemset(d_inbox_count_, 0, members * 4));
+        UA_HIP(hipMemset(d_counters_, 0, 64));
+        workspace_nodes_ = members;
+        workspace_batch_ = max_batch;
+    }
+    const snapshot_view_t& view = snapshot_.view();
 
     build_args_t args{};
     args.nbr0 = snapshot_.mutable_nbr0();
     args.upper = snapshot_.mutable_upper();
     args.upper_ref = view.upper_ref;
     args.needed = m;
-    args.nodes = d_nodes;
-    args.cand_slots = d_cand_slots;
-    args.cand_distances = d_cand_distances;
-    args.cand_counts = d_cand_counts;
+    args.nodes = d_nodes_;
+    args.cand_slots = d_cand_slots_;
+    args.cand_distances = d_cand_distances_;
+    args.cand_counts = d_cand_counts_;
     args.ef = ef;
-    args.inbox_count = d_inbox_count;
-    args.inbox = d_inbox;
+    args.inbox_count = d_inbox_count_;
+    args.inbox = static_cast<cand_t*>(d_inbox_);
     args.inbox_cap = inbox_cap;
-    args.touched = d_touched;
-    args.touched_count = d_touched_count;
-    args.counters = d_counters;
+    args.touched = d_touched_;
+    args.touched_count = d_touched_count_;
+    args.counters = d_counters_;
 
-    entry_slot_ = 0;
-    max_level_ = (std::uint32_t)levels_[0]; // the first node only becomes the entry point, index.hpp:2835-2840
     std::vector<std::uint32_t> nodes;
     std::vector<std::uint64_t> host_counters(max_batch);
     const std::uint32_t resident = (std::uint32_t)snapshot_.compute_units() * 8;
 
-    for (std::uint64_t begin = 1; begin < count;) {
+    while (begin < end_total) {
         const std::uint64_t limit = std::max<std::uint64_t>(1, std::min<std::uint64_t>(max_batch, begin / config_.batch_divisor));
-        const std::uint64_t end = std::min<std::uint64_t>(count, begin + limit);
+        const std::uint64_t end = std::min<std::uint64_t>(end_total, begin + limit);
         std::uint32_t batch_top = 0;
         for (std::uint64_t i = begin; i < end; ++i)
             batch_top = std::max<std::uint32_t>(batch_top, (std::uint32_t)levels_[i]);
@@ -254,24 +410,24 @@ const char* builder_t::build(metric_kind_t metric, scalar_kind_t scalar, std::si
             if (nodes.empty())
                 continue;
             const std::uint32_t pass_count = (std::uint32_t)nodes.size();
-            UA_HIP(hipMemcpyAsync(d_nodes, nodes.data(), (std::size_t)pass_count * 4, hipMemcpyHostToDevice, stream));
+            UA_HIP(hipMemcpyAsync(d_nodes_, nodes.data(), (std::size_t)pass_count * 4, hipMemcpyHostToDevice, stream));
             UA_HIP(hipStreamSynchronize(stream)); // `nodes` is pageable and reused
 
             const double t_search = seconds_now();
             search_extras_t extras;
-            extras.query_ids = d_nodes;
+            extras.query_ids = d_nodes_;
             extras.beam_level = level;
             extras.emit_slots = true;
             extras.reference_frontier = true; // builds stay byte-for-byte reproducible against the reference-shaped oracle
             search_stats_t search_stats;
-            if (const char* e = snapshot_.search_device(view.vectors, pass_count, view.row_stride, ef, ef, d_cand_slots,
-                                                        d_cand_distances, d_cand_counts, d_visited, d_computed, stream,
+            if (const char* e = snapshot_.search_device(view.vectors, pass_count, view.row_stride, ef, ef, d_cand_slots_,
+                                                        d_cand_distances_, d_cand_counts_, d_visited_, d_computed_, stream,
                                                         search_tuning_t{}, &search_stats, false, &extras))
                 return e;
             stats_.seconds_search += seconds_now() - t_search;
 
             const double t_link = seconds_now();
-            UA_HIP(hipMemsetAsync(d_touched_count, 0, 4, stream));
+            UA_HIP(hipMemsetAsync(d_touched_count_, 0, 4, stream));
             args.level = level;
             args.capacity = level ? m : m0;
             args.count = pass_count;
@@ -285,11 +441,11 @@ const char* builder_t::build(metric_kind_t metric, scalar_kind_t scalar, std::si
             params.grid = (std::uint32_t)std::min<std::uint64_t>((std::uint64_t)pass_count * m, resident);
             UA_HIP(launch_build(metric, scalar, params, view, args));
             // traversal counters of this pass (tiny) while the link kernels run
-            UA_HIP(hipMemcpyAsync(host_counters.data(), d_computed, (std::size_t)pass_count * 8, hipMemcpyDeviceToHost, stream));
+            UA_HIP(hipMemcpyAsync(host_counters.data(), d_computed_, (std::size_t)pass_count * 8, hipMemcpyDeviceToHost, stream));
             UA_HIP(hipStreamSynchronize(stream));
             for (std::uint32_t i = 0; i < pass_count; ++i)
                 stats_.search_distances += host_counters[i];
-            UA_HIP(hipMemcpyAsync(host_counters.data(), d_visited, (std::size_t)pass_count * 8, hipMemcpyDeviceToHost, stream));
+            UA_HIP(hipMemcpyAsync(host_counters.data(), d_visited_, (std::size_t)pass_count * 8, hipMemcpyDeviceToHost, stream));
             UA_HIP(hipStreamSynchronize(stream));
             for (std::uint32_t i = 0; i < pass_count; ++i)
                 stats_.search_hops += host_counters[i];
@@ -307,23 +463,12 @@ const char* builder_t::build(metric_kind_t metric, scalar_kind_t scalar, std::si
         ++stats_.batches;
         begin = end;
     }
-    snapshot_.set_frontier(count, entry_slot_, max_level_);
-    // removed members (key == free_key_, index_dense.hpp:513) were linked like any other node — the reference keeps them in
-    // the graph too — and stop matching from here on
-    bool tombstones = false;
-    for (std::uint64_t key : keys_)
-        tombstones |= key == free_key_k;
-    snapshot_.set_tombstones(tombstones);
-    if (const char* e = snapshot_.finalize_layout()) // the graph is final: rows of ≤ 16 bytes move next to the lists
-        return e;
     unsigned long long counters[4] = {0, 0, 0, 0};
-    UA_HIP(hipMemcpy(counters, d_counters, sizeof(counters), hipMemcpyDeviceToHost));
+    UA_HIP(hipMemcpy(counters, d_counters_, sizeof(counters), hipMemcpyDeviceToHost));
     stats_.select_distances = counters[0];
     stats_.reverse_distances = counters[1];
     stats_.repruned_lists = counters[2];
     stats_.dropped_requests = counters[3];
-    stats_.max_level = max_level_;
-    stats_.seconds_total = seconds_now() - t_begin;
     return nullptr;
 }
 
@@ -373,7 +518,7 @@ const char* builder_t::save_buffer(void* buffer, std::size_t length) {
     std::memcpy(p + 17, &present, 8);
     std::memcpy(p + 25, &deleted, 8);
     std::memcpy(p + 33, &dimensions, 8);
-    p[41] = 0; // multi
+    p[41] = config_.multi ? 1 : 0; // head.multi = config.multi, index_dense.hpp:1046
     p += 64;
 
     // graph header, index.hpp:1863-1869
@@ -398,7 +543,7 @@ const char* builder_t::save_buffer(void* buffer, std::size_t length) {
     }
     offsets[n] = offset;
     std::uint8_t* tapes = p;
-    const bool identity = keys_.empty();
+    const bool identity = identity_keys_;
     parallel_ranges(n, [&](std::uint64_t begin, std::uint64_t end) {
         for (std::uint64_t i = begin; i < end; ++i) {
             std::uint8_t* tape = tapes + offsets[i];

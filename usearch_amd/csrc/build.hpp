@@ -11,6 +11,7 @@
  */
 #pragma once
 #include <cstdint>
+#include <random>
 #include <vector>
 
 #include "engine.hpp"
@@ -24,6 +25,7 @@ struct build_config_t {
     std::uint64_t seed = 0x5eed5eedull;   ///< level draw
     std::uint32_t batch_divisor = 16;     ///< a batch holds at most (nodes already linked) / divisor nodes …
     std::uint32_t max_batch = 65536;      ///< … and at most this many
+    bool multi = false;                   ///< several members may share a key: written into the image's head (index_dense.hpp:1046)
 };
 
 struct build_stats_t {
@@ -37,6 +39,11 @@ struct build_stats_t {
 
 class builder_t {
   public:
+    builder_t() = default;
+    ~builder_t();
+    builder_t(const builder_t&) = delete;
+    builder_t& operator=(const builder_t&) = delete;
+
     /**
      *  Builds the index of `count` vectors (`stride` bytes apart, storage scalar kind, host or device memory).
      *  `keys` (host) may be null: key = row number. Returns nullptr or a static message.
@@ -45,24 +52,50 @@ class builder_t {
                       std::uint64_t count, std::size_t stride, bool vectors_on_device, const std::uint64_t* keys,
                       const build_config_t& config, int device);
 
+    /**
+     *  Links `count` MORE vectors into the index built so far — what a run of `usearch_add` calls after the first build
+     *  amounts to (index_gt::add, index.hpp:2780-2879, batch-deferred): the new members get the next slots and the next draws
+     *  of the level generator, the device arrays grow geometrically, only the new members are searched for and linked.
+     */
+    const char* extend(const void* vectors, std::uint64_t count, std::size_t stride, bool vectors_on_device,
+                       const std::uint64_t* keys, bool exact_capacity = false);
+
+    /// Renames a member in place; `free_key_k` makes it a tombstone (index_dense.hpp:1479-1511: it keeps routing, stops
+    /// matching). No relinking.
+    const char* set_key(std::uint64_t slot, std::uint64_t key);
+
     snapshot_t& snapshot() { return snapshot_; }
     const build_stats_t& stats() const { return stats_; }
+    std::uint64_t size() const { return size_; }
 
     /// Size and content of the reference's serialized form (index_dense.hpp:995-1062, index.hpp:3277-3317).
     std::size_t serialized_length() const;
     const char* save_buffer(void* buffer, std::size_t length);
 
   private:
+    const char* link_range(std::uint64_t begin, std::uint64_t end);
+    void release_workspace();
+
     snapshot_t snapshot_;
     build_config_t config_;
     build_stats_t stats_;
     std::vector<std::int16_t> levels_;
-    std::vector<std::uint64_t> keys_; ///< empty = identity
+    std::vector<std::uint64_t> keys_; ///< unused while `identity_keys_`
+    bool identity_keys_ = true;
+    std::mt19937_64 generator_;
     std::uint64_t size_ = 0, upper_lists_ = 0;
     std::uint32_t entry_slot_ = 0, max_level_ = 0;
     metric_kind_t metric_ = metric_unknown_k;
     scalar_kind_t scalar_ = scalar_unknown_k;
     std::size_t dimensions_ = 0;
+    // device workspace of the link passes, kept between `extend` calls
+    std::vector<void*> workspace_;
+    std::uint64_t workspace_nodes_ = 0, workspace_batch_ = 0;
+    std::uint32_t *d_nodes_ = nullptr, *d_inbox_count_ = nullptr, *d_touched_ = nullptr, *d_touched_count_ = nullptr;
+    std::uint64_t *d_cand_slots_ = nullptr, *d_cand_counts_ = nullptr, *d_visited_ = nullptr, *d_computed_ = nullptr;
+    void* d_inbox_ = nullptr;
+    float* d_cand_distances_ = nullptr;
+    unsigned long long* d_counters_ = nullptr;
 };
 
 } // namespace usearch_amd

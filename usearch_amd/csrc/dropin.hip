@@ -28,6 +28,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <shared_mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -98,9 +99,26 @@ void fail(usearch_error_t* error, const char* message) {
         *error = message;
 }
 
+/// Runs `body`; an allocation failure or any other exception becomes an error string instead of crossing the C ABI.
+template <typename body_at> void guarded(usearch_error_t* error, body_at&& body) {
+    try {
+        body();
+    } catch (const std::bad_alloc&) {
+        fail(error, "Out of memory!");
+    } catch (const std::exception&) {
+        fail(error, "Unexpected failure inside the index");
+    }
+}
+
+using shared_lock_t = std::shared_lock<std::shared_mutex>;
+using unique_lock_t = std::unique_lock<std::shared_mutex>;
+
 /// One `usearch_index_t`.
 struct index_t {
-    std::mutex mutex;
+    /// Searches share it (the engine leases one workspace per call in flight, as the reference leases one context per thread,
+    /// index_dense.hpp:1984-2000); everything that changes the index, or links pending members, takes it alone.
+    std::shared_mutex mutex;
+    std::size_t threads_search = 0; ///< `usearch_change_threads_search`: batches in flight at once (0 = the engine's default)
     // configuration — `usearch_init_options_t`, c/usearch.h:64-110
     metric_kind_t metric = metric_cos_k;
     scalar_kind_t scalar = scalar_f32_k;
@@ -214,7 +232,16 @@ struct index_t {
         return staged ? vectors.data() + (std::size_t)slot * bpv() : image.vectors + (std::size_t)slot * image.cols;
     }
 
-    /// The device index to search: the snapshot of the image, or a fresh build of the staging arrays.
+    /// Is the device index up to date with the host-side content? (Shared lock suffices to ask.)
+    bool device_current() const {
+        if (staged)
+            return keys.empty() || (builder && builder->size() == keys.size());
+        return !has_image || snapshot != nullptr;
+    }
+    snapshot_t* device_index() { return staged ? (builder ? &builder->snapshot() : nullptr) : snapshot; }
+
+    /// Brings the device index up to date (unique lock): uploads the image, builds the staged members, or — after a build —
+    /// links only the members added since (`builder_t::extend`, the batch-deferred form of index.hpp:2780-2879).
     const char* ready(snapshot_t** out) {
         *out = nullptr;
         if (staged) {
@@ -225,14 +252,24 @@ struct index_t {
                 build_config_t config;
                 config.connectivity = (std::uint32_t)connectivity;
                 config.expansion_add = (std::uint32_t)expansion_add;
+                config.multi = multi;
                 if (const char* e = fresh->build(metric, scalar, dimensions, vectors.data(), keys.size(), bpv(), false,
                                                  keys.data(), config, device)) {
                     delete fresh;
                     return e;
                 }
                 builder = fresh;
+            } else if (builder && builder->size() < keys.size()) {
+                const std::size_t linked = (std::size_t)builder->size();
+                if (const char* e = builder->extend(vectors.data() + linked * bpv(), keys.size() - linked, bpv(), false,
+                                                    keys.data() + linked)) {
+                    delete builder, builder = nullptr; // the arrays may be half grown: start over at the next call
+                    return e;
+                }
             }
             *out = builder ? &builder->snapshot() : nullptr;
+            if (*out && threads_search)
+                (*out)->set_concurrency(threads_search);
             return nullptr;
         }
         if (has_image && !snapshot) {
@@ -246,6 +283,8 @@ struct index_t {
             snapshot = fresh;
         }
         *out = snapshot;
+        if (*out && threads_search)
+            (*out)->set_concurrency(threads_search);
         return nullptr;
     }
 
@@ -395,7 +434,7 @@ void usearch_free(usearch_index_t handle, usearch_error_t*) { delete as_index(ha
 
 size_t usearch_memory_usage(usearch_index_t handle, usearch_error_t*) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     std::size_t bytes = index.image_owned.size() + index.vectors.size() + index.keys.size() * 8;
     if (index.snapshot)
         bytes += index.snapshot->device_bytes();
@@ -404,11 +443,18 @@ size_t usearch_memory_usage(usearch_index_t handle, usearch_error_t*) {
     return bytes;
 }
 
-char const* usearch_hardware_acceleration(usearch_index_t, usearch_error_t*) { return "gfx950"; }
+char const* usearch_hardware_acceleration(usearch_index_t, usearch_error_t* error) {
+    int devices = 0;
+    if (hipGetDeviceCount(&devices) != hipSuccess || devices <= 0) {
+        fail(error, "No HIP device: this library has no CPU path, every search will fail");
+        return "none";
+    }
+    return "gfx950";
+}
 
 size_t usearch_serialized_length(usearch_index_t handle, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     std::size_t length = 0;
     if (const char* e = serialize(index, nullptr, nullptr, 0, &length))
         fail(error, e);
@@ -417,14 +463,14 @@ size_t usearch_serialized_length(usearch_index_t handle, usearch_error_t* error)
 
 void usearch_save_buffer(usearch_index_t handle, void* buffer, size_t length, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     if (const char* e = serialize(index, nullptr, buffer, length, nullptr))
         fail(error, e);
 }
 
 void usearch_save(usearch_index_t handle, char const* path, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     std::vector<std::uint8_t> bytes;
     if (const char* e = serialize(index, &bytes, nullptr, 0, nullptr))
         return fail(error, e);
@@ -439,7 +485,7 @@ void usearch_save(usearch_index_t handle, char const* path, usearch_error_t* err
 
 void usearch_load_buffer(usearch_index_t handle, void const* buffer, size_t length, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     index.drop_device();
     index.drop_image();
     index.image_owned.assign(static_cast<const std::uint8_t*>(buffer), static_cast<const std::uint8_t*>(buffer) + length);
@@ -451,7 +497,7 @@ void usearch_load_buffer(usearch_index_t handle, void const* buffer, size_t leng
 
 void usearch_view_buffer(usearch_index_t handle, void const* buffer, size_t length, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     index.drop_device();
     index.drop_image();
     if (const char* e = index.open_image(buffer, length)) // the caller's buffer is borrowed for the index lifetime
@@ -477,7 +523,7 @@ static const char* map_file(char const* path, void** mapped, std::size_t* length
 
 void usearch_view(usearch_index_t handle, char const* path, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     index.drop_device();
     index.drop_image();
     void* mapped = nullptr;
@@ -518,7 +564,7 @@ void usearch_metadata(char const* path, usearch_init_options_t* options, usearch
 
 size_t usearch_size(usearch_index_t handle, usearch_error_t*) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     if (!index.staged)
         return index.has_image ? (std::size_t)index.image.count_present : 0;
     std::size_t present = 0;
@@ -529,7 +575,7 @@ size_t usearch_size(usearch_index_t handle, usearch_error_t*) {
 
 size_t usearch_capacity(usearch_index_t handle, usearch_error_t*) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     return std::max(index.capacity, index.size());
 }
 
@@ -538,7 +584,7 @@ size_t usearch_connectivity(usearch_index_t handle, usearch_error_t*) { return a
 
 void usearch_reserve(usearch_index_t handle, size_t capacity, usearch_error_t*) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     index.capacity = std::max(index.capacity, capacity);
     if (index.staged) {
         index.keys.reserve(capacity);
@@ -554,13 +600,21 @@ void usearch_change_expansion_add(usearch_index_t handle, size_t expansion, usea
 void usearch_change_expansion_search(usearch_index_t handle, size_t expansion, usearch_error_t*) {
     as_index(handle)->expansion_search = expansion;
 }
-// the device schedules its own waves: the reference's per-thread contexts (index_dense.hpp:931-936) have no counterpart
+// Construction is batched on the device (build.hpp): there is no per-thread state to size, the call is accepted and ignored.
 void usearch_change_threads_add(usearch_index_t, size_t, usearch_error_t*) {}
-void usearch_change_threads_search(usearch_index_t, size_t, usearch_error_t*) {}
+// Searches: the number of `usearch_search*` calls that may be in flight at once — the size of the engine's workspace pool,
+// the counterpart of the reference's per-thread contexts (index_dense.hpp:931-936, 1984-2000). More callers than that wait.
+void usearch_change_threads_search(usearch_index_t handle, size_t threads, usearch_error_t*) {
+    index_t& index = *as_index(handle);
+    unique_lock_t lock(index.mutex);
+    index.threads_search = threads;
+    if (snapshot_t* device_index = index.device_index())
+        device_index->set_concurrency(threads ? threads : 16);
+}
 
 void usearch_change_metric_kind(usearch_index_t handle, usearch_metric_kind_t kind, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     const metric_kind_t metric = metric_from_c(kind);
     if (!kernel_available(metric, index.scalar))
         return fail(error, "No MI355X kernel for this metric / scalar kind combination");
@@ -578,96 +632,140 @@ void usearch_change_metric(usearch_index_t, usearch_metric_t, void*, usearch_met
 void usearch_add(usearch_index_t handle, usearch_key_t key, void const* vector, usearch_scalar_kind_t vector_kind,
                  usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
-    const scalar_kind_t kind = scalar_from_c(vector_kind);
-    if (kind == scalar_unknown_k)
-        return fail(error, "Unknown scalar kind!");
-    if (key == free_key_k)
-        return fail(error, "Free key is reserved");
-    if (!index.dimensions || !index.bpv())
-        return fail(error, "Index is not initialized");
-    if (!index.multi && index.key_lookup().count(key))
-        return fail(error, "Duplicate keys not allowed in high-level wrappers");
-    index.materialize();
-    const std::size_t bpv = index.bpv(), slot = index.keys.size();
-    if (slot + 1 >= none_slot_k)
-        return fail(error, "Index is too large for 32-bit slots");
-    index.vectors.resize((slot + 1) * bpv);
-    std::uint8_t* target = index.vectors.data() + slot * bpv;
-    std::memset(target, 0, bpv);
-    if (!cast_vector(kind, index.scalar, static_cast<const std::uint8_t*>(vector), index.dimensions, target))
-        std::memcpy(target, vector, bpv);
-    index.keys.push_back(key);
-    if (index.lookup_valid)
-        index.lookup.emplace(key, (std::uint32_t)slot);
-    delete index.builder, index.builder = nullptr; // relinked at the next search
+    guarded(error, [&] {
+        unique_lock_t lock(index.mutex);
+        const scalar_kind_t kind = scalar_from_c(vector_kind);
+        if (kind == scalar_unknown_k)
+            return fail(error, "Unknown scalar kind!");
+        if (key == free_key_k)
+            return fail(error, "Free key is reserved");
+        if (!index.dimensions || !index.bpv())
+            return fail(error, "Index is not initialized");
+        if (index.size() >= index.capacity) // index.hpp:2812-2818: the reference does not grow on its own either
+            return fail(error, "Reserve capacity ahead of insertions!");
+        if (!index.multi && index.key_lookup().count(key))
+            return fail(error, "Duplicate keys not allowed in high-level wrappers");
+        index.materialize();
+        const std::size_t bpv = index.bpv(), slot = index.keys.size();
+        if (slot + 1 >= none_slot_k)
+            return fail(error, "Index is too large for 32-bit slots");
+        index.vectors.resize((slot + 1) * bpv);
+        std::uint8_t* target = index.vectors.data() + slot * bpv;
+        std::memset(target, 0, bpv);
+        if (!cast_vector(kind, index.scalar, static_cast<const std::uint8_t*>(vector), index.dimensions, target))
+            std::memcpy(target, vector, bpv);
+        index.keys.push_back(key);
+        if (index.lookup_valid)
+            index.lookup.emplace(key, (std::uint32_t)slot);
+        // the device index, if there is one, stays: the next search links the members added since (builder_t::extend)
+    });
 }
 
 bool usearch_contains(usearch_index_t handle, usearch_key_t key, usearch_error_t*) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     return index.key_lookup().count(key) != 0;
 }
 
 size_t usearch_count(usearch_index_t handle, usearch_key_t key, usearch_error_t*) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     return index.key_lookup().count(key);
 }
 
-static size_t search_locked(index_t& index, void const* queries, scalar_kind_t kind, std::size_t queries_count,
+/// The search proper. Takes the index lock itself: shared while the device index is current (searches run side by side),
+/// alone only to bring it up to date first (upload after load / view, build, or linking the members added since).
+static size_t search_shared(index_t& index, void const* queries, scalar_kind_t kind, std::size_t queries_count,
                             std::size_t queries_stride, std::size_t count, usearch_key_t* keys, std::size_t keys_stride,
                             usearch_distance_t* distances, std::size_t distances_stride, std::size_t* counts,
-                            std::size_t* visited_total, std::size_t* computed_total, const std::uint32_t* allow_bits,
+                            std::size_t* visited_total, std::size_t* computed_total,
+                            int (*filter)(usearch_key_t key, void* filter_state), void* filter_state,
                             usearch_error_t* error) {
     if (!queries_count || !count)
         return 0;
-    snapshot_t* device_index = nullptr;
-    if (const char* e = index.ready(&device_index)) {
-        fail(error, e);
-        return 0;
-    }
-    std::vector<std::uint64_t> found(queries_count, 0), visited(queries_count, 0), computed(queries_count, 0);
-    std::vector<std::uint64_t> dense_keys(queries_count * count);
-    std::vector<float> dense_distances(queries_count * count);
-    if (!device_index) { // nothing indexed yet: index.hpp:3034-3037
-        pad_results(reinterpret_cast<usearch_key_t*>(dense_keys.data()), dense_distances.data(), dense_keys.size());
-    } else if (const char* e = device_index->search_host(queries, kind, queries_count, queries_stride, count,
-                                                         index.expansion_search, dense_keys.data(), dense_distances.data(),
-                                                         found.data(), visited.data(), computed.data(), search_tuning_t{},
-                                                         nullptr, allow_bits)) {
-        fail(error, e);
-        return 0;
-    }
-    std::size_t total_visited = 0, total_computed = 0;
-    for (std::size_t q = 0; q < queries_count; ++q) {
-        if (keys)
-            std::memcpy(reinterpret_cast<std::uint8_t*>(keys) + q * keys_stride, dense_keys.data() + q * count, count * 8);
-        if (distances)
-            std::memcpy(reinterpret_cast<std::uint8_t*>(distances) + q * distances_stride,
-                        dense_distances.data() + q * count, count * 4);
-        if (counts)
-            counts[q] = (std::size_t)found[q];
-        total_visited += (std::size_t)visited[q], total_computed += (std::size_t)computed[q];
-    }
-    if (visited_total)
-        *visited_total = total_visited;
-    if (computed_total)
-        *computed_total = total_computed;
-    return (std::size_t)found[0];
+    std::size_t result = 0;
+    guarded(error, [&] {
+        for (;;) {
+            {
+                shared_lock_t shared(index.mutex);
+                if (index.device_current()) {
+                    snapshot_t* device_index = index.device_index();
+                    // a single query that lands in the caller's dense buffers needs no staging copy at all
+                    const bool direct = queries_count == 1 || (keys_stride == count * 8 && distances_stride == count * 4);
+                    std::vector<std::uint64_t> found(queries_count, 0), visited(queries_count, 0), computed(queries_count, 0);
+                    std::vector<std::uint64_t> dense_keys(direct ? 0 : queries_count * count);
+                    std::vector<float> dense_distances(direct ? 0 : queries_count * count);
+                    std::uint64_t* out_keys = direct ? reinterpret_cast<std::uint64_t*>(keys) : dense_keys.data();
+                    float* out_distances = direct ? distances : dense_distances.data();
+                    std::vector<std::uint64_t> spare_keys;
+                    std::vector<float> spare_distances;
+                    if (!out_keys)
+                        spare_keys.resize(queries_count * count), out_keys = spare_keys.data();
+                    if (!out_distances)
+                        spare_distances.resize(queries_count * count), out_distances = spare_distances.data();
+                    std::vector<std::uint32_t> bits;
+                    if (filter) {
+                        // The callback is a host function: run it once per member and hand the device one bit per slot. The
+                        // traversal then applies it where the reference does (index.hpp:4200-4205, 4236-4240), so results are
+                        // the reference's as long as the predicate is a pure function of the key.
+                        std::vector<std::uint64_t> from_image;
+                        const std::vector<std::uint64_t>* member_keys = &index.keys;
+                        if (!index.staged && index.has_image)
+                            index.image_keys(from_image), member_keys = &from_image;
+                        bits.assign((member_keys->size() + 31) / 32 + 1, 0);
+                        for (std::size_t slot = 0; slot < member_keys->size(); ++slot)
+                            if ((*member_keys)[slot] != free_key_k && filter((*member_keys)[slot], filter_state))
+                                bits[slot >> 5] |= 1u << (slot & 31);
+                    }
+                    if (!device_index) { // nothing indexed yet: index.hpp:3034-3037
+                        pad_results(reinterpret_cast<usearch_key_t*>(out_keys), out_distances, queries_count * count);
+                    } else if (const char* e = device_index->search_host(
+                                   queries, kind, queries_count, queries_stride, count, index.expansion_search, out_keys,
+                                   out_distances, found.data(), visited.data(), computed.data(), search_tuning_t{}, nullptr,
+                                   filter ? bits.data() : nullptr)) {
+                        return fail(error, e);
+                    }
+                    std::size_t total_visited = 0, total_computed = 0;
+                    for (std::size_t q = 0; q < queries_count; ++q) {
+                        if (!direct) {
+                            if (keys)
+                                std::memcpy(reinterpret_cast<std::uint8_t*>(keys) + q * keys_stride, dense_keys.data() + q * count,
+                                            count * 8);
+                            if (distances)
+                                std::memcpy(reinterpret_cast<std::uint8_t*>(distances) + q * distances_stride,
+                                            dense_distances.data() + q * count, count * 4);
+                        }
+                        if (counts)
+                            counts[q] = (std::size_t)found[q];
+                        total_visited += (std::size_t)visited[q], total_computed += (std::size_t)computed[q];
+                    }
+                    if (visited_total)
+                        *visited_total = total_visited;
+                    if (computed_total)
+                        *computed_total = total_computed;
+                    result = (std::size_t)found[0];
+                    return;
+                }
+            }
+            unique_lock_t alone(index.mutex);
+            snapshot_t* device_index = nullptr;
+            if (const char* e = index.ready(&device_index))
+                return fail(error, e);
+        }
+    });
+    return result;
 }
 
 size_t usearch_search(usearch_index_t handle, void const* query, usearch_scalar_kind_t query_kind, size_t count,
                       usearch_key_t* keys, usearch_distance_t* distances, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
     const scalar_kind_t kind = scalar_from_c(query_kind);
     if (kind == scalar_unknown_k) {
         fail(error, "Unknown scalar kind!");
         return 0;
     }
-    return search_locked(index, query, kind, 1, bytes_per_vector(kind, index.dimensions), count, keys, count * 8, distances,
-                         count * 4, nullptr, nullptr, nullptr, nullptr, error);
+    return search_shared(index, query, kind, 1, bytes_per_vector(kind, index.dimensions), count, keys, count * 8, distances,
+                         count * 4, nullptr, nullptr, nullptr, nullptr, nullptr, error);
 }
 
 void usearch_search_many(usearch_index_t handle, void const* queries, usearch_scalar_kind_t query_kind,
@@ -675,19 +773,18 @@ void usearch_search_many(usearch_index_t handle, void const* queries, usearch_sc
                          size_t keys_stride, usearch_distance_t* distances, size_t distances_stride, size_t* counts,
                          size_t* visited_members, size_t* computed_distances, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
     const scalar_kind_t kind = scalar_from_c(query_kind);
     if (kind == scalar_unknown_k)
         return fail(error, "Unknown scalar kind!");
-    search_locked(index, queries, kind, queries_count, queries_stride, count, keys, keys_stride, distances,
-                  distances_stride, counts, visited_members, computed_distances, nullptr, error);
+    search_shared(index, queries, kind, queries_count, queries_stride, count, keys, keys_stride, distances,
+                  distances_stride, counts, visited_members, computed_distances, nullptr, nullptr, error);
 }
 
 void usearch_cluster_many(usearch_index_t handle, void const* queries, usearch_scalar_kind_t query_kind,
                           size_t queries_count, size_t queries_stride, size_t level, usearch_key_t* keys,
                           usearch_distance_t* distances, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     const scalar_kind_t kind = scalar_from_c(query_kind);
     if (kind == scalar_unknown_k)
         return fail(error, "Unknown scalar kind!");
@@ -711,34 +808,19 @@ size_t usearch_filtered_search(usearch_index_t handle, void const* query, usearc
                                int (*filter)(usearch_key_t key, void* filter_state), void* filter_state,
                                usearch_key_t* keys, usearch_distance_t* distances, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
     const scalar_kind_t kind = scalar_from_c(query_kind);
     if (kind == scalar_unknown_k) {
         fail(error, "Unknown scalar kind!");
         return 0;
     }
-    if (!filter)
-        return search_locked(index, query, kind, 1, bytes_per_vector(kind, index.dimensions), count, keys, count * 8,
-                             distances, count * 4, nullptr, nullptr, nullptr, nullptr, error);
-    // The callback is a host function: run it once per member and hand the device one bit per slot. The traversal then
-    // applies it where the reference does (index.hpp:4200-4205, 4236-4240), so results are the reference's as long as the
-    // predicate is a pure function of the key.
-    std::vector<std::uint64_t> from_image;
-    const std::vector<std::uint64_t>* member_keys = &index.keys;
-    if (!index.staged && index.has_image)
-        index.image_keys(from_image), member_keys = &from_image;
-    std::vector<std::uint32_t> bits((member_keys->size() + 31) / 32 + 1, 0);
-    for (std::size_t slot = 0; slot < member_keys->size(); ++slot)
-        if ((*member_keys)[slot] != free_key_k && filter((*member_keys)[slot], filter_state))
-            bits[slot >> 5] |= 1u << (slot & 31);
-    return search_locked(index, query, kind, 1, bytes_per_vector(kind, index.dimensions), count, keys, count * 8, distances,
-                         count * 4, nullptr, nullptr, nullptr, bits.data(), error);
+    return search_shared(index, query, kind, 1, bytes_per_vector(kind, index.dimensions), count, keys, count * 8, distances,
+                         count * 4, nullptr, nullptr, nullptr, filter, filter_state, error);
 }
 
 size_t usearch_get(usearch_index_t handle, usearch_key_t key, size_t count, void* vector, usearch_scalar_kind_t vector_kind,
                    usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     const scalar_kind_t kind = scalar_from_c(vector_kind);
     if (kind == scalar_unknown_k) {
         fail(error, "Unknown scalar kind!");
@@ -761,24 +843,27 @@ size_t usearch_get(usearch_index_t handle, usearch_key_t key, size_t count, void
     return exported;
 }
 
-size_t usearch_remove(usearch_index_t handle, usearch_key_t key, usearch_error_t*) {
+size_t usearch_remove(usearch_index_t handle, usearch_key_t key, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     if (!index.key_lookup().count(key))
         return 0;
     index.materialize();
     auto range = index.key_lookup().equal_range(key);
     std::size_t removed = 0;
-    for (auto it = range.first; it != range.second; ++it, ++removed)
+    for (auto it = range.first; it != range.second; ++it, ++removed) {
         index.keys[it->second] = free_key_k; // a tombstone: the member keeps routing, stops matching (index_dense.hpp:1479-1511)
+        if (index.builder && it->second < index.builder->size()) // in place on the device too: nothing is relinked
+            if (const char* e = index.builder->set_key(it->second, free_key_k))
+                fail(error, e);
+    }
     index.lookup.erase(key);
-    delete index.builder, index.builder = nullptr;
     return removed;
 }
 
 size_t usearch_rename(usearch_index_t handle, usearch_key_t from, usearch_key_t to, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     if (to == free_key_k) {
         fail(error, "Free key is reserved");
         return 0;
@@ -798,8 +883,10 @@ size_t usearch_rename(usearch_index_t handle, usearch_key_t from, usearch_key_t 
     for (std::uint32_t slot : slots) {
         index.keys[slot] = to;
         index.lookup.emplace(to, slot);
+        if (index.builder && slot < index.builder->size()) // keys live next to the graph in HBM: renamed in place
+            if (const char* e = index.builder->set_key(slot, to))
+                fail(error, e);
     }
-    delete index.builder, index.builder = nullptr;
     return slots.size();
 }
 
@@ -828,7 +915,7 @@ void usearch_exact_search(void const* dataset, size_t dataset_size, size_t datas
 
 void usearch_clear(usearch_index_t handle, usearch_error_t*) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     index.drop_device();
     index.drop_image();
     index.keys.clear(), index.vectors.clear();
@@ -838,7 +925,7 @@ void usearch_clear(usearch_index_t handle, usearch_error_t*) {
 
 void usearch_gpu_sync(usearch_index_t handle, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     snapshot_t* device_index = nullptr;
     if (const char* e = index.ready(&device_index))
         fail(error, e);
@@ -846,7 +933,7 @@ void usearch_gpu_sync(usearch_index_t handle, usearch_error_t* error) {
 
 void usearch_gpu_release(usearch_index_t handle, usearch_error_t*) {
     index_t& index = *as_index(handle);
-    std::lock_guard<std::mutex> lock(index.mutex);
+    unique_lock_t lock(index.mutex);
     index.drop_device();
 }
 

@@ -11,6 +11,8 @@
 #include <cstring>
 #include <thread>
 
+#include <hipcub/hipcub.hpp>
+
 #include "casts.hpp"
 #include "host_util.hpp"
 #include "kernels.hpp"
@@ -265,9 +267,106 @@ const char* snapshot_t::finalize_layout() {
     return nullptr;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+//  Loader: a serialized v2 image → the flat HBM arrays, flattened ON THE DEVICE. The host uploads three byte ranges of the
+//  image as they lie (levels, node tapes, vectors); offsets are a device prefix scan of the node sizes and the graph is
+//  scattered by a kernel — no host array of N × M0 cells (a 125M-member shard would need 16 GB of them).
+//  Format: index_dense.hpp:995-1062, index.hpp:3277-3317, docs/format.md.
+// ---------------------------------------------------------------------------------------------------------------------
+
+/// Per node: tape bytes and number of upper-level lists (its level), to be prefix-summed.
+__global__ void node_sizes_kernel(const std::int16_t* levels, std::uint64_t n, std::uint64_t node_base_bytes,
+                                  std::uint64_t level_bytes, std::uint64_t* sizes, std::uint64_t* lists) {
+    const std::uint64_t i = blockIdx.x * (std::uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const std::uint64_t level = (std::uint64_t)levels[i];
+    sizes[i] = node_base_bytes + level * level_bytes;
+    lists[i] = level;
+}
+
+/// Tapes start at an arbitrary byte of the image but are uploaded to the start of their own allocation, and every node size
+/// is even: 2-byte loads are always aligned.
+__device__ __forceinline__ std::uint32_t tape_u32(const std::uint8_t* p) {
+    const std::uint16_t* h = reinterpret_cast<const std::uint16_t*>(p);
+    return (std::uint32_t)h[0] | ((std::uint32_t)h[1] << 16);
+}
+__device__ __forceinline__ std::uint64_t tape_u64(const std::uint8_t* p) {
+    return (std::uint64_t)tape_u32(p) | ((std::uint64_t)tape_u32(p + 4) << 32);
+}
+
+/**
+ *  One thread per node: key, level-0 row (reference order, later duplicates of a slot dropped — they could only ever be seen
+ *  as "already visited", index.hpp:4229 — unused cells none), upper lists verbatim (no visited set up there,
+ *  index.hpp:3976-4001), and the checks the reference's loader implies. flags[0] = corrupt, flags[1] = any tombstone.
+ */
+__global__ void flatten_kernel(const std::uint8_t* tapes, const std::uint64_t* offsets, const std::uint64_t* first_list,
+                               const std::int16_t* levels, std::uint64_t n, std::uint32_t m, std::uint32_t m0,
+                               std::uint64_t* keys, std::uint32_t* nbr0, std::uint32_t* upper_ref, std::uint32_t* upper,
+                               std::uint32_t* flags) {
+    const std::uint64_t i = blockIdx.x * (std::uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const std::uint8_t* tape = tapes + offsets[i];
+    const std::uint64_t key = tape_u64(tape);
+    keys[i] = key;
+    if (key == free_key_k)
+        flags[1] = 1;
+    const std::int16_t level = levels[i];
+    const std::int16_t taped_level = (std::int16_t)(*reinterpret_cast<const std::uint16_t*>(tape + 8));
+    if (taped_level != level) {
+        flags[0] = 1;
+        return;
+    }
+    upper_ref[i] = level ? (std::uint32_t)first_list[i] : none_slot_k;
+    const std::uint8_t* list = tape + 10;
+    std::uint32_t count = tape_u32(list);
+    if (count > m0) {
+        flags[0] = 1;
+        return;
+    }
+    std::uint32_t* row = nbr0 + i * m0;
+    std::uint32_t kept = 0;
+    for (std::uint32_t j = 0; j < count; ++j) {
+        const std::uint32_t slot = tape_u32(list + 4 + 4 * (std::uint64_t)j);
+        if (slot >= n) {
+            flags[0] = 1;
+            return;
+        }
+        bool seen = false;
+        for (std::uint32_t k = 0; k < kept && !seen; ++k)
+            seen = row[k] == slot;
+        if (!seen)
+            row[kept++] = slot;
+    }
+    for (std::uint32_t j = kept; j < m0; ++j)
+        row[j] = none_slot_k;
+    list += 4 + 4 * (std::uint64_t)m0;
+    for (std::int16_t l = 1; l <= level; ++l, list += 4 + 4 * (std::uint64_t)m) {
+        count = tape_u32(list);
+        if (count > m) {
+            flags[0] = 1;
+            return;
+        }
+        std::uint32_t* cells = upper + (first_list[i] + (std::uint64_t)(l - 1)) * m;
+        for (std::uint32_t j = 0; j < m; ++j) {
+            std::uint32_t slot = none_slot_k;
+            if (j < count) {
+                slot = tape_u32(list + 4 + 4 * (std::uint64_t)j);
+                if (slot >= n || levels[slot] < l) {
+                    flags[0] = 1;
+                    return;
+                }
+            }
+            cells[j] = slot;
+        }
+    }
+}
+
 const char* snapshot_t::build(const image_t& image, int device) {
     if (!kernel_available(image.metric, image.scalar))
         return "No MI355X kernel for this metric / scalar kind combination";
+    release();
     device_ = device;
     UA_HIP(hipSetDevice(device));
     metric_ = image.metric;
@@ -277,97 +376,67 @@ const char* snapshot_t::build(const image_t& image, int device) {
     const std::uint64_t n = image.size;
     const std::uint32_t m = (std::uint32_t)image.connectivity, m0 = (std::uint32_t)image.connectivity_base;
     const std::uint32_t bpv = (std::uint32_t)image.cols;
-
     std::uint32_t row_stride = 0, row_chunks = 0;
     row_geometry(bpv, lanes_, row_stride, row_chunks);
-
-    // ---- host pass 1: tape offsets (sequential prefix) and the number of upper-level lists
-    std::vector<std::uint64_t> offsets(n + 1);
-    std::vector<std::uint32_t> upper_ref(n);
-    std::uint64_t offset = 0, lists = 0;
-    for (std::uint64_t i = 0; i < n; ++i) {
-        offsets[i] = offset;
-        const std::int16_t level = image.level(i);
-        if (level < 0)
-            return "Failed to pull nodes from the stream";
-        upper_ref[i] = level ? (std::uint32_t)lists : none_slot_k;
-        lists += (std::uint64_t)level;
-        offset += image.node_bytes(level);
-    }
-    offsets[n] = offset;
-    if (offset > image.tapes_length)
-        return "Failed to pull nodes from the stream";
-    if (lists >= none_slot_k)
-        return "Too many upper-level lists for 32-bit references";
-    upper_lists_ = lists;
-
-    // ---- host pass 2: keys, level-0 rows, upper lists (parallel over nodes)
-    std::vector<std::uint64_t> keys(n);
-    std::vector<std::uint32_t> nbr0((std::size_t)n * m0, none_slot_k);
-    std::vector<std::uint32_t> upper((std::size_t)std::max<std::uint64_t>(lists, 1) * m, none_slot_k);
-    std::atomic<bool> corrupt{false}, tombstones{false};
-    parallel_ranges(n, [&](std::uint64_t begin, std::uint64_t end) {
-        for (std::uint64_t i = begin; i < end; ++i) {
-            const std::uint8_t* tape = image.tapes + offsets[i];
-            const std::uint64_t key = image_t::load<std::uint64_t>(tape);
-            keys[i] = key;
-            if (key == free_key_k)
-                tombstones.store(true, std::memory_order_relaxed);
-            const std::int16_t level = image_t::load<std::int16_t>(tape + 8);
-            if (level != image.level(i)) {
-                corrupt.store(true);
-                return;
-            }
-            const std::uint8_t* list = tape + 10;
-            // level 0: keep the reference's order; a slot that re-appears later in the same list could only ever be
-            // seen as "already visited" there (index.hpp:4229), so dropping it preserves the traversal exactly
-            std::uint32_t count = image_t::load<std::uint32_t>(list);
-            if (count > m0) {
-                corrupt.store(true);
-                return;
-            }
-            std::uint32_t* row = nbr0.data() + (std::size_t)i * m0;
-            std::uint32_t kept = 0;
-            for (std::uint32_t j = 0; j < count; ++j) {
-                const std::uint32_t s = image_t::load<std::uint32_t>(list + 4 + 4 * j);
-                if (s >= n) {
-                    corrupt.store(true);
-                    return;
-                }
-                bool seen = false;
-                for (std::uint32_t k = 0; k < kept && !seen; ++k)
-                    seen = row[k] == s;
-                if (!seen)
-                    row[kept++] = s;
-            }
-            list += 4 + 4 * (std::size_t)m0;
-            // upper levels: no visited set is consulted there (index.hpp:3976-4001): keep lists verbatim
-            for (std::int16_t l = 1; l <= level; ++l, list += 4 + 4 * (std::size_t)m) {
-                count = image_t::load<std::uint32_t>(list);
-                if (count > m) {
-                    corrupt.store(true);
-                    return;
-                }
-                std::uint32_t* cells = upper.data() + ((std::size_t)upper_ref[i] + (l - 1)) * m;
-                for (std::uint32_t j = 0; j < count; ++j) {
-                    const std::uint32_t s = image_t::load<std::uint32_t>(list + 4 + 4 * j);
-                    if (s >= n || image.level(s) < l) {
-                        corrupt.store(true);
-                        return;
-                    }
-                    cells[j] = s;
-                }
-            }
-        }
-    });
-    if (corrupt.load())
-        return "Failed to pull nodes from the stream";
     if (n && image.level(image.entry_slot) < (std::int16_t)image.max_level)
         return "Failed to pull the header from the stream";
 
-    // ---- upload
-    release();
-    device_ = device;
+    // ---- scratch that lives for the load only: levels, tape bytes, the two prefix sums
+    struct scratch_t {
+        std::vector<void*> pointers;
+        ~scratch_t() {
+            for (void* p : pointers)
+                if (p)
+                    (void)hipFree(p);
+        }
+        hipError_t allocate(void** out, std::size_t bytes) {
+            *out = nullptr;
+            const hipError_t e = hipMalloc(out, std::max<std::size_t>(bytes, 16));
+            if (e == hipSuccess)
+                pointers.push_back(*out);
+            return e;
+        }
+    } scratch;
+    std::int16_t* d_levels = nullptr;
+    std::uint8_t* d_tapes = nullptr;
+    std::uint64_t *d_sizes = nullptr, *d_offsets = nullptr, *d_level_counts = nullptr, *d_first_list = nullptr;
+    std::uint32_t* d_flags = nullptr;
+    void* d_scan = nullptr;
+    std::uint64_t tapes_bytes = 0, lists = 0;
+    if (n) {
+        UA_HIP(scratch.allocate((void**)&d_levels, n * 2));
+        UA_HIP(scratch.allocate((void**)&d_sizes, n * 8));
+        UA_HIP(scratch.allocate((void**)&d_offsets, n * 8));
+        UA_HIP(scratch.allocate((void**)&d_level_counts, n * 8));
+        UA_HIP(scratch.allocate((void**)&d_first_list, n * 8));
+        UA_HIP(scratch.allocate((void**)&d_flags, 16));
+        UA_HIP(hipMemset(d_flags, 0, 16));
+        UA_HIP(hipMemcpy(d_levels, image.levels, n * 2, hipMemcpyHostToDevice)); // 2-byte aligned in its own allocation
+        const unsigned blocks = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(node_sizes_kernel, dim3(blocks), dim3(256), 0, nullptr, d_levels, n,
+                           (std::uint64_t)image.node_bytes(0), (std::uint64_t)(4 + 4 * (std::uint64_t)m), d_sizes,
+                           d_level_counts);
+        UA_HIP(hipGetLastError());
+        std::size_t scan_bytes = 0;
+        UA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_sizes, d_offsets, (int)n));
+        UA_HIP(scratch.allocate(&d_scan, scan_bytes));
+        UA_HIP(hipcub::DeviceScan::ExclusiveSum(d_scan, scan_bytes, d_sizes, d_offsets, (int)n));
+        UA_HIP(hipcub::DeviceScan::ExclusiveSum(d_scan, scan_bytes, d_level_counts, d_first_list, (int)n));
+        std::uint64_t last[2] = {0, 0}, last_size[2] = {0, 0};
+        UA_HIP(hipMemcpy(&last[0], d_offsets + (n - 1), 8, hipMemcpyDeviceToHost));
+        UA_HIP(hipMemcpy(&last[1], d_first_list + (n - 1), 8, hipMemcpyDeviceToHost));
+        UA_HIP(hipMemcpy(&last_size[0], d_sizes + (n - 1), 8, hipMemcpyDeviceToHost));
+        UA_HIP(hipMemcpy(&last_size[1], d_level_counts + (n - 1), 8, hipMemcpyDeviceToHost));
+        tapes_bytes = last[0] + last_size[0];
+        lists = last[1] + last_size[1];
+        if (tapes_bytes > image.tapes_length)
+            return "Failed to pull nodes from the stream";
+        if (lists >= none_slot_k)
+            return "Too many upper-level lists for 32-bit references";
+    }
+    upper_lists_ = lists;
+
+    // ---- the index's own arrays
     const std::size_t vectors_bytes = (std::size_t)n * row_stride;
     auto allocate = [&](void** p, std::size_t bytes) -> hipError_t {
         device_bytes_ += std::max<std::size_t>(bytes, 16);
@@ -375,19 +444,30 @@ const char* snapshot_t::build(const image_t& image, int device) {
     };
     device_bytes_ = 0;
     UA_HIP(allocate(&d_vectors_, vectors_bytes));
-    UA_HIP(allocate(&d_nbr0_, nbr0.size() * 4));
-    UA_HIP(allocate(&d_upper_ref_, upper_ref.size() * 4));
-    UA_HIP(allocate(&d_upper_, upper.size() * 4));
-    UA_HIP(allocate(&d_keys_, keys.size() * 8));
+    UA_HIP(allocate(&d_nbr0_, (std::size_t)n * m0 * 4));
+    UA_HIP(allocate(&d_upper_ref_, (std::size_t)n * 4));
+    UA_HIP(allocate(&d_upper_, (std::size_t)std::max<std::uint64_t>(lists, 1) * m * 4));
+    UA_HIP(allocate(&d_keys_, (std::size_t)n * 8));
+    UA_HIP(hipMemset(d_upper_, 0xFF, (std::size_t)std::max<std::uint64_t>(lists, 1) * m * 4));
+    bool tombstones = false;
     if (n) {
+        UA_HIP(scratch.allocate((void**)&d_tapes, tapes_bytes));
+        UA_HIP(hipMemcpy(d_tapes, image.tapes, tapes_bytes, hipMemcpyHostToDevice));
+        const unsigned blocks = (unsigned)((n + 127) / 128);
+        hipLaunchKernelGGL(flatten_kernel, dim3(blocks), dim3(128), 0, nullptr, d_tapes, d_offsets, d_first_list, d_levels, n,
+                           m, m0, static_cast<std::uint64_t*>(d_keys_), static_cast<std::uint32_t*>(d_nbr0_),
+                           static_cast<std::uint32_t*>(d_upper_ref_), static_cast<std::uint32_t*>(d_upper_), d_flags);
+        UA_HIP(hipGetLastError());
+        std::uint32_t flags[2] = {0, 0};
+        UA_HIP(hipMemcpy(flags, d_flags, 8, hipMemcpyDeviceToHost));
+        if (flags[0])
+            return "Failed to pull nodes from the stream";
+        tombstones = flags[1] != 0;
         if (const char* e = upload_rows(static_cast<std::uint8_t*>(d_vectors_), row_stride, image.vectors, bpv, bpv, n))
             return e;
-        UA_HIP(hipMemcpy(d_nbr0_, nbr0.data(), nbr0.size() * 4, hipMemcpyHostToDevice));
-        UA_HIP(hipMemcpy(d_upper_ref_, upper_ref.data(), upper_ref.size() * 4, hipMemcpyHostToDevice));
-        UA_HIP(hipMemcpy(d_keys_, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
     }
-    UA_HIP(hipMemcpy(d_upper_, upper.data(), upper.size() * 4, hipMemcpyHostToDevice));
 
+    view_ = snapshot_view_t{};
     view_.vectors = static_cast<const std::uint8_t*>(d_vectors_);
     view_.nbr0 = static_cast<const std::uint32_t*>(d_nbr0_);
     view_.upper_ref = static_cast<const std::uint32_t*>(d_upper_ref_);
@@ -402,7 +482,7 @@ const char* snapshot_t::build(const image_t& image, int device) {
     view_.m0 = m0;
     view_.max_level = (std::uint32_t)image.max_level;
     view_.entry_slot = (std::uint32_t)image.entry_slot;
-    view_.has_tombstones = tombstones.load() ? 1u : 0u;
+    view_.has_tombstones = tombstones ? 1u : 0u;
 
     hipDeviceProp_t properties;
     UA_HIP(hipGetDeviceProperties(&properties, device));
@@ -530,6 +610,13 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
         // measured on 10M x 768 f16 (profiles/): a whole row per round trip (12 loads per lane, 8 waves per CU) beats 8 loads
         // at 12 waves per CU at every expansion — the traversal is latency-bound, fewer round trips per hop win
         variant = chunks_per_lane >= 12 ? variant_u12_w2_k : variant_u8_w3_k;
+        // Without the heap (profiles/r02_sweep_variants.log, ef = 608): every build lands within 3 % of the others — the
+        // kernel moves 4.6-4.9 TB/s of rows plus the visited-set traffic, which is what random 1.5-KB gathers reach on this
+        // memory system at all — and what separates them is the DRAIN of the batch: with one wave per query the last queries
+        // run alone, for about 0.65 × waves / queries of the launch. Few waves with many bytes in flight each (two rows per
+        // lane group per round, 8 waves per CU) win while that matters; 16 waves per CU win once the batch is long enough.
+        if (frontier == frontier_top_k && chunks_per_lane >= 12)
+            variant = count >= 40000 ? variant_u4_w4_k : variant_u12x2_w2_k;
     }
     if (variant_request && variant_request - 1 < (std::uint32_t)variant_count_k && every_build) {
         const int requested = (int)variant_request - 1;

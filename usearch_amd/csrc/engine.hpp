@@ -162,15 +162,24 @@ class snapshot_t {
     const char* search_finish(search_call_t& call, search_stats_t* stats);
 
     /**
-     *  Construction support (build.hip): allocates the HBM arrays of an index of `capacity` nodes whose levels are
-     *  already drawn, every list empty. `vectors` (host or device memory, `stride` bytes between rows) are re-pitched to
-     *  the row stride; `keys` may be null (key = slot). The graph arrays are then filled in place by the link kernels
-     *  while `set_frontier` tells the search how much of the graph exists.
+     *  Construction support (build.hip): allocates the HBM arrays of an index with room for `capacity` members and
+     *  `lists_capacity` upper-level lists, every list empty; `append_for_build` uploads members, `grow_for_build` makes room
+     *  for more. The graph arrays are filled in place by the link kernels while `set_frontier` tells the search how much of
+     *  the graph exists.
      */
     const char* allocate_for_build(metric_kind_t metric, scalar_kind_t scalar, std::size_t dimensions,
-                                   std::uint64_t capacity, std::uint32_t m, std::uint32_t m0,
-                                   const std::int16_t* levels, const void* vectors, std::size_t stride,
-                                   bool vectors_on_device, const std::uint64_t* keys, int device);
+                                   std::uint64_t capacity, std::uint64_t lists_capacity, std::uint32_t m, std::uint32_t m0,
+                                   int device);
+    /// Re-allocates the build arrays for `capacity` members / `lists_capacity` upper-level lists, keeping what is linked.
+    const char* grow_for_build(std::uint64_t capacity, std::uint64_t lists_capacity);
+    /// Uploads members [first, first + count): rows (re-pitched), keys (null = the slot number), upper-list references.
+    const char* append_for_build(std::uint64_t first, std::uint64_t count, const std::uint32_t* upper_refs,
+                                 const void* vectors, std::size_t stride, bool vectors_on_device, const std::uint64_t* keys);
+    /// Overwrites one member's key in HBM (rename; `free_key_k` = tombstone).
+    const char* set_key(std::uint64_t slot, std::uint64_t key);
+    std::uint64_t build_capacity() const { return build_capacity_; }
+    std::uint64_t build_lists_capacity() const { return build_lists_capacity_; }
+    void set_upper_lists(std::uint64_t lists) { upper_lists_ = lists; }
     void set_frontier(std::uint64_t size, std::uint32_t entry_slot, std::uint32_t max_level) {
         view_.size = size, view_.entry_slot = entry_slot, view_.max_level = max_level;
     }
@@ -179,6 +188,7 @@ class snapshot_t {
     /// (`snapshot_view_t::nbr0_rows`) when rows are a single 16-byte chunk — b1 × 128, haversine … — so that a hop reads one
     /// contiguous block. Costs size × M0 × 16 bytes of HBM; USEARCH_AMD_INLINE_ROWS=0 turns it off.
     const char* finalize_layout();
+    void suspend_layout() { view_.nbr0_rows = nullptr; } ///< while the lists are being rewritten (construction)
     std::uint32_t* mutable_nbr0() { return static_cast<std::uint32_t*>(d_nbr0_); }
     std::uint32_t* mutable_upper() { return static_cast<std::uint32_t*>(d_upper_); }
     hipStream_t stream() const { return stream_; }
@@ -250,6 +260,7 @@ class snapshot_t {
     void* d_upper_ = nullptr;
     void* d_keys_ = nullptr;
     void* d_nbr0_rows_ = nullptr;
+    std::uint64_t build_capacity_ = 0, build_lists_capacity_ = 0; ///< room in the arrays above while an index is under construction
 
     int compute_units_ = 256;
     float last_distances_ms_ = 0.f;

@@ -124,6 +124,20 @@ struct image_t {
             return "Failed to pull the header from the stream";
         if (cols != bytes_per_vector(scalar, dimensions))
             return "Vector size doesn't match the scalar kind and dimensions";
+        // The node tapes are variable-length (one list per level): everything that later walks them — key lookup, `get`,
+        // the flattener — relies on this one pass having seen that every level is sane and that the tapes fit the image
+        // (a truncated or corrupt file fails here, like the reference's "Failed to pull nodes from the stream").
+        if (connectivity >= none_slot_k || connectivity_base >= none_slot_k)
+            return "Failed to pull the header from the stream";
+        std::uint64_t needed = 0;
+        for (std::uint64_t i = 0; i < size; ++i) {
+            const std::int16_t node_level = level(i);
+            if (node_level < 0 || (std::uint64_t)node_level > max_level)
+                return "Failed to pull nodes from the stream";
+            needed += node_bytes(node_level);
+            if (needed > tapes_length)
+                return "Failed to pull nodes from the stream";
+        }
         return nullptr;
     }
 
