@@ -11,7 +11,7 @@ cd "$REPO"
 for step in "$@"; do
   echo "=== $step $(date +%T)"
   case $step in
-    tests)    timeout 900 python -m pytest tests -m gpu -x -q > "$OUT/pytest.log" 2>&1; tail -15 "$OUT/pytest.log" ;;
+    tests)    timeout 900 python -m pytest tests -m gpu -q --maxfail=8 > "$OUT/pytest.log" 2>&1; tail -15 "$OUT/pytest.log" ;;
     sweep10m) timeout 600 python scripts/sweep.py --n 10000000 --ef 592 256 --modes 2 --waves 0 --variants 1 2 3 4 5 \
                 --frontiers 1 2 --steps 3 > "$OUT/sweep10m.log" 2>&1; cat "$OUT/sweep10m.log" ;;
     sweepv)   timeout 600 python scripts/sweep.py --n 10000000 --ef 608 --queries 10000 100000 --modes 2 --waves 0 --variants 3 1 2 4 \

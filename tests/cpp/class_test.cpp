@@ -83,6 +83,8 @@ int main(int argc, char** argv) {
     auto doubles = index_dense_t::make(dimensions, usearch_metric_pearson_k, usearch_scalar_f64_k);
     EXPECT(doubles);
     std::vector<double> wide(data.begin(), data.begin() + 300 * dimensions);
+    EXPECT(!doubles.index.add(0, wide.data())); // index.hpp:2812-2818: "Reserve capacity ahead of insertions!"
+    EXPECT(doubles.index.try_reserve(300));
     for (std::size_t i = 0; i < 300; ++i)
         EXPECT(doubles.index.add(i, wide.data() + i * dimensions));
     auto nearest = doubles.index.search(wide.data() + 17 * dimensions, 3);
@@ -95,6 +97,7 @@ int main(int argc, char** argv) {
         std::memcpy(&bits, &data[i], 4);
         narrow[i].bits = (std::uint16_t)(bits >> 16);
     }
+    EXPECT(brains.index.try_reserve(300));
     for (std::size_t i = 0; i < 300; ++i)
         EXPECT(brains.index.add(i, narrow.data() + i * dimensions));
     auto brain_hit = brains.index.search(narrow.data() + 5 * dimensions, 3);

@@ -157,6 +157,7 @@ def test_c_test_program(lib, count, dimensions, tmp_path):
     # test_get_vector, c/test.c:170-199: a multi-index returns every vector stored under one key
     options = create_options(dimensions, multi=True)
     index = lib.usearch_init(C.byref(options), C.byref(err))
+    lib.usearch_reserve(index, count, C.byref(err))  # c/test.c:177
     for i in range(count):
         lib.usearch_add(index, 1, ptr(data[i]), SCALAR["f32"], C.byref(err))
         ok(err)
