@@ -380,8 +380,13 @@ def main() -> None:
     truth, truth_distances = None, None
     if sample and (rank == 0 or sharded):
         t0 = time.time()
-        exact = index.search(queries_host[:sample], args.k, dtype=args.dtype, exact=True)
+        # ground truth: the matrix-unit exact kernel where the pair has one (f16 / bf16 within float tolerance of the bit-exact
+        # kernel, i8 identical to it; tests/test_gpu_exact.py), the wave-per-query exact kernel otherwise
+        tiled = metric in ("cos", "ip", "l2sq") and args.dtype in ("f16", "bf16", "i8") and not (
+            metric == "l2sq" and args.dtype != "i8") and args.k <= 64
+        exact = index.search(queries_host[:sample], args.k, dtype=args.dtype, exact="tiled" if tiled else True)
         truth, truth_distances = exact.keys, exact.distances
+        exact_ms = exact.stats.kernel_ms
         if sharded and world > 1:
             gathered = [None] * world
             dist.all_gather_object(gathered, (truth, truth_distances))
@@ -391,7 +396,8 @@ def main() -> None:
             truth = np.take_along_axis(all_keys, order, axis=1)
             truth_distances = np.take_along_axis(all_distances, order, axis=1)
         if rank == 0:
-            log(f"[bench] exact ground truth for {sample} queries in {time.time() - t0:.1f}s"
+            log(f"[bench] exact ground truth for {sample} queries in {time.time() - t0:.1f}s "
+                f"({'matrix-unit' if tiled else 'wave-per-query'} kernel {exact_ms:.1f} ms)"
                 + (" (recall counted by distance: ties)" if by_distance else ""))
     sweep = [args.expansion] if args.expansion else [64, 96, 128, 192, 256, 320, 384, 448, 512, 576, 640, 704, 768, 896, 1024]
 

@@ -169,6 +169,19 @@ USEARCH_AMD_EXPORT void usearch_amd_cluster_many(usearch_amd_snapshot_t snapshot
                                                  uint64_t* visited, uint64_t* computed, usearch_amd_error_t* error);
 
 /**
+ *  The same exact search as a TILED MATRIX PRODUCT on the matrix units (usearch_amd/csrc/exact_tiled.hip) — what the reference's
+ *  `exact_search_t` does with its distance matrix (index_plugins.hpp:2071-2164): dataset rows are read once per 64 queries
+ *  instead of once per query. Pairs: cos / ip over f16 and bf16 (f32 accumulation in the matrix unit: distances within the
+ *  float tolerance of `usearch_amd_exact_search_many`, which remains the bit-exact path) and cos / ip / l2sq over i8
+ *  (bit-identical to it, ties included); `wanted` ≤ 64. Other pairs: an error.
+ */
+USEARCH_AMD_EXPORT void usearch_amd_exact_search_many_tiled(usearch_amd_snapshot_t snapshot, void const* queries,
+                                                            int query_kind, size_t queries_count, size_t queries_stride,
+                                                            size_t wanted, usearch_amd_key_t* keys,
+                                                            usearch_amd_distance_t* distances, uint64_t* counts,
+                                                            float* kernel_ms, usearch_amd_error_t* error);
+
+/**
  *  Exact search of a raw host dataset — `usearch_exact_search` (c/usearch.h:467-474, c/lib.cpp:468-501): keys are row
  *  offsets of `dataset`. `metric_kind` / `scalar_kind` use the C enumerators of c/usearch.h:40-62. Ties between equal
  *  distances (unspecified in the reference: `std::partial_sort` by distance) resolve to the later row first.

@@ -65,3 +65,60 @@ def test_exact_search_of_a_raw_dataset():
     wide[:, :16] = rng.integers(0, 256, (1000, 16), dtype=np.uint8)
     keys, distances = usearch_amd.exact_search(wide[:, :16], wide[:50, :16], 5, metric="hamming")
     assert np.array_equal(keys[:, 0] == np.arange(50), distances[:, 0] == 0) and np.all(distances[:, 0] == 0)
+
+
+@pytest.mark.parametrize("metric,dtype,ndim,n,k", [("l2sq", "i8", 96, 20011, 10), ("cos", "i8", 40, 9000, 64),
+                                                   ("ip", "i8", 130, 5003, 7)])
+def test_tiled_exact_search_is_bit_identical_for_i8(reference, metric, dtype, ndim, n, k):
+    """The matrix-unit kernel (exact_tiled.hip) sums integers exactly and closes with the same arithmetic as the
+    wave-per-query kernel, so keys, distance bits and counts are identical — ties resolved as lower_bound insertion in slot
+    order does — tombstones skipped, ragged query counts, ragged row tiles, ragged dimensions."""
+    from usearch_amd import Index
+    removed = np.arange(5, n, 13) + 1000
+    image, vectors, _ = util.build_image(n, ndim, metric, dtype, seed=93, remove=removed[:200], expansion_add=16, connectivity=4)
+    queries = util.make_vectors(131, ndim, dtype, seed=94)
+    queries[:20] = vectors[:20]
+    index = Index.restore(image)
+    exact = index.search(queries, k, exact=True)
+    tiled = index.search(queries, k, exact="tiled")
+    assert np.array_equal(exact.counts, tiled.counts)
+    assert np.array_equal(exact.keys, tiled.keys)
+    assert util.same_float_bits(exact.distances, tiled.distances)
+    assert not np.isin(tiled.keys, removed[:200]).any()
+
+
+@pytest.mark.parametrize("metric,dtype,ndim,n,k", [("cos", "f16", 768, 12001, 10), ("ip", "f16", 100, 9000, 32),
+                                                   ("cos", "bf16", 96, 7000, 10), ("ip", "bf16", 768, 3000, 5)])
+def test_tiled_exact_search_of_float_pairs_is_within_tolerance(reference, metric, dtype, ndim, n, k):
+    """f16 / bf16: products are exact, the matrix unit accumulates them in f32 in its own order — every distance within the
+    float tolerance of the bit-exact kernel's, the same neighbours wherever distances are separated by more than that."""
+    from usearch_amd import Index
+    image, vectors, _ = util.build_image(n, ndim, metric, dtype, seed=95, expansion_add=16, connectivity=4)
+    queries = util.make_vectors(70, ndim, dtype, seed=96)
+    queries[:10] = vectors[:10]
+    index = Index.restore(image)
+    exact = index.search(queries, k, exact=True)
+    tiled = index.search(queries, k, exact="tiled")
+    assert np.array_equal(exact.counts, tiled.counts)
+    scale = np.maximum(1.0, np.abs(exact.distances))
+    assert np.all(np.abs(exact.distances - tiled.distances) <= util.tolerance(dtype) * scale)
+    assert (exact.keys == tiled.keys).mean() > 0.97
+    assert np.all(np.diff(tiled.distances, axis=1) >= 0)
+    with pytest.raises(RuntimeError):  # no matrix-unit kernel for this pair: said so, not silently rerouted
+        image32, _, _ = util.build_image(500, 16, "l2sq", "f32", seed=1)
+        Index.restore(image32).search(np.zeros((2, 16), dtype=np.float32), 3, exact="tiled")
+
+
+def test_exact_search_of_a_raw_i8_dataset_takes_the_matrix_units(monkeypatch):
+    """`usearch_exact_search` over i8 rows routes to the tiled kernel on its own (bit-identical); the environment switch brings
+    the wave-per-query kernel back for the comparison."""
+    import usearch_amd
+    rng = np.random.default_rng(9)
+    dataset = rng.integers(-100, 100, (30000, 64)).astype(np.int8)
+    queries = rng.integers(-100, 100, (200, 64)).astype(np.int8)
+    keys, distances = usearch_amd.exact_search(dataset, queries, 10, metric="l2sq")
+    monkeypatch.setenv("USEARCH_AMD_NO_TILED_EXACT", "1")
+    plain_keys, plain_distances = usearch_amd.exact_search(dataset, queries, 10, metric="l2sq")
+    assert np.array_equal(keys, plain_keys) and util.same_float_bits(distances, plain_distances)
+    brute = ((queries[:, None, :].astype(np.int32) - dataset[None, :6000, :].astype(np.int32)) ** 2).sum(-1)
+    assert np.all(distances[:, 0] <= brute.min(axis=1))

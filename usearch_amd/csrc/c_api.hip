@@ -390,6 +390,18 @@ void usearch_amd_exact_search_many(usearch_amd_snapshot_t snapshot, void const* 
         fail(error, e);
 }
 
+void usearch_amd_exact_search_many_tiled(usearch_amd_snapshot_t snapshot, void const* queries, int query_kind,
+                                         size_t queries_count, size_t queries_stride, size_t wanted,
+                                         usearch_amd_key_t* keys, usearch_amd_distance_t* distances, uint64_t* counts,
+                                         float* kernel_ms, usearch_amd_error_t* error) {
+    const scalar_kind_t kind = scalar_from_c(query_kind);
+    if (kind == scalar_unknown_k)
+        return fail(error, "Unknown scalar kind!");
+    if (const char* e = as_snapshot(snapshot)->exact_host(queries, kind, queries_count, queries_stride, wanted, keys,
+                                                          distances, counts, kernel_ms, true))
+        fail(error, e);
+}
+
 void usearch_amd_exact_search_dataset(void const* dataset, size_t dataset_count, size_t dataset_stride,
                                       void const* queries, size_t queries_count, size_t queries_stride,
                                       int scalar_kind, size_t dimensions, int metric_kind, size_t wanted,

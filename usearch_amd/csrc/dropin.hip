@@ -435,7 +435,9 @@ void usearch_free(usearch_index_t handle, usearch_error_t*) { delete as_index(ha
 size_t usearch_memory_usage(usearch_index_t handle, usearch_error_t*) {
     index_t& index = *as_index(handle);
     unique_lock_t lock(index.mutex);
-    std::size_t bytes = index.image_owned.size() + index.vectors.size() + index.keys.size() * 8;
+    // what the host side holds (the handle itself, the reserved staging arrays, an owned image) plus the arrays in HBM; never
+    // zero for a live index (c/test.c:83 expects as much of a freshly reserved one)
+    std::size_t bytes = sizeof(index_t) + index.image_owned.capacity() + index.vectors.capacity() + index.keys.capacity() * 8;
     if (index.snapshot)
         bytes += index.snapshot->device_bytes();
     if (index.builder)
@@ -586,7 +588,7 @@ void usearch_reserve(usearch_index_t handle, size_t capacity, usearch_error_t*) 
     index_t& index = *as_index(handle);
     unique_lock_t lock(index.mutex);
     index.capacity = std::max(index.capacity, capacity);
-    if (index.staged) {
+    if (index.staged || !index.has_image) { // the staging arrays are where `usearch_add` puts members
         index.keys.reserve(capacity);
         index.vectors.reserve(capacity * index.bpv());
     }

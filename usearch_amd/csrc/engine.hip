@@ -1219,7 +1219,7 @@ const char* snapshot_t::exact_device(const void* queries, std::size_t count, std
 
 const char* snapshot_t::exact_host(const void* queries, scalar_kind_t query_kind, std::size_t count,
                                    std::size_t stride_bytes, std::size_t wanted, std::uint64_t* keys, float* distances,
-                                   std::uint64_t* counts, float* kernel_ms) {
+                                   std::uint64_t* counts, float* kernel_ms, bool tiled) {
     if (!count || !wanted)
         return nullptr;
     const std::size_t bpv = view_.bytes_per_vector, dims = view_.dimensions;
@@ -1245,9 +1245,14 @@ const char* snapshot_t::exact_host(const void* queries, scalar_kind_t query_kind
     float* d_distances = reinterpret_cast<float*>(reinterpret_cast<std::uint8_t*>(d_keys) + pad(count * wanted * 8));
     std::uint64_t* d_counts = reinterpret_cast<std::uint64_t*>(reinterpret_cast<std::uint8_t*>(d_distances) + pad(count * wanted * 4));
     UA_HIP(hipMemcpy(d_queries, dense.data(), bpv * count, hipMemcpyHostToDevice));
-    if (const char* e = exact_search_device(metric_, scalar_, lanes_, view_, d_queries, count, bpv, wanted, true, d_keys,
-                                            d_distances, d_counts, ws.stream, kernel_ms))
+    if (tiled) {
+        if (const char* e = exact_search_tiled_device(kernel_metric(metric_), scalar_, view_, d_queries, count, bpv, wanted,
+                                                      true, d_keys, d_distances, d_counts, ws.stream, kernel_ms))
+            return e;
+    } else if (const char* e = exact_search_device(metric_, scalar_, lanes_, view_, d_queries, count, bpv, wanted, true, d_keys,
+                                                   d_distances, d_counts, ws.stream, kernel_ms)) {
         return e;
+    }
     if (keys)
         UA_HIP(hipMemcpy(keys, d_keys, count * wanted * 8, hipMemcpyDeviceToHost));
     if (distances)
@@ -1301,8 +1306,15 @@ const char* exact_search_dataset_host(metric_kind_t metric, scalar_kind_t scalar
         view.chunks = row_chunks;
         view.bytes_per_vector = (std::uint32_t)bpv;
         view.dimensions = (std::uint32_t)dimensions;
-        error = exact_search_device(metric, scalar, lanes, view, d_queries, queries_count, bpv, wanted, false, d_keys,
-                                    d_distances, d_counts, nullptr, nullptr);
+        // i8: the matrix-unit kernel returns the very same bits (exact integer sums, same closing arithmetic, same tie order);
+        // the float kinds only reach it when asked (tolerance instead of bit equality)
+        if (scalar == scalar_i8_k && exact_tiled_available(metric, scalar, wanted) && queries_count >= 32 &&
+            !env_size("USEARCH_AMD_NO_TILED_EXACT", 0))
+            error = exact_search_tiled_device(metric, scalar, view, d_queries, queries_count, bpv, wanted, false, d_keys,
+                                              d_distances, d_counts, nullptr, nullptr);
+        else
+            error = exact_search_device(metric, scalar, lanes, view, d_queries, queries_count, bpv, wanted, false, d_keys,
+                                        d_distances, d_counts, nullptr, nullptr);
     }
     if (e == hipSuccess && !error) {
         e = hipMemcpy(host_keys.data(), d_keys, host_keys.size() * 8, hipMemcpyDeviceToHost);

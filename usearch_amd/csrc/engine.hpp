@@ -219,10 +219,11 @@ class snapshot_t {
     const char* exact_device(const void* queries, std::size_t count, std::size_t stride_bytes, std::size_t wanted,
                              std::uint64_t* keys, float* distances, std::uint64_t* counts, hipStream_t stream,
                              float* kernel_ms);
-    /// Same with host buffers and any query scalar kind.
+    /// Same with host buffers and any query scalar kind. `tiled`: the matrix-unit kernel where one exists for the pair
+    /// (exact_tiled.hip; an error otherwise) instead of the bit-exact wave-per-query one.
     const char* exact_host(const void* queries, scalar_kind_t query_kind, std::size_t count, std::size_t stride_bytes,
                            std::size_t wanted, std::uint64_t* keys, float* distances, std::uint64_t* counts,
-                           float* kernel_ms);
+                           float* kernel_ms, bool tiled = false);
 
     /// out[q][j] = metric(query q, stored row slots[q][j]); host buffers, queries in storage kind.
     const char* distances_host(const void* queries, std::size_t count, std::size_t stride_bytes,
@@ -359,6 +360,17 @@ const char* exact_search_device(metric_kind_t metric, scalar_kind_t scalar, std:
                                 const snapshot_view_t& view, const void* queries, std::size_t count,
                                 std::size_t stride_bytes, std::size_t wanted, bool map_keys, std::uint64_t* keys,
                                 float* distances, std::uint64_t* counts, hipStream_t stream, float* kernel_ms);
+
+/// Is there a tiled (matrix-unit) exact-search kernel for this pair and result count? (exact_tiled.hip: cos / ip over f16 and
+/// bf16 — float tolerance — and cos / ip / l2sq over i8 — bit-identical to the wave-per-query kernel.)
+bool exact_tiled_available(metric_kind_t metric, scalar_kind_t scalar, std::size_t wanted);
+
+/// Many-to-many exact search as a tiled matrix product (index_plugins.hpp:2071-2164): rows are read once per 64 queries. Same
+/// contract as `exact_search_device`.
+const char* exact_search_tiled_device(metric_kind_t metric, scalar_kind_t scalar, const snapshot_view_t& view,
+                                      const void* queries, std::size_t count, std::size_t stride_bytes, std::size_t wanted,
+                                      bool map_keys, std::uint64_t* keys, float* distances, std::uint64_t* counts,
+                                      hipStream_t stream, float* kernel_ms);
 
 /// Host-buffer exact search of a raw dataset — `usearch_exact_search` (c/usearch.h:467-474): keys are dataset offsets.
 const char* exact_search_dataset_host(metric_kind_t metric, scalar_kind_t scalar, std::size_t dimensions,

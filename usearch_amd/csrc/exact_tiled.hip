@@ -1,0 +1,437 @@
+/**
+ *  usearch_amd/csrc/exact_tiled.hip — many-to-many EXACT search as a tiled matrix product on the MFMA units.
+ *
+ *  The reference's `exact_search_t` (/root/reference/include/usearch/index_plugins.hpp:2071-2164: a queries × dataset distance
+ *  matrix, then a partial sort per query) and `index_gt::search_exact_` (index.hpp:4252-4268) are the one place on this path
+ *  where operands ARE reused — every query meets every row — so unlike the graph walk this is a GEMM: a workgroup owns a tile
+ *  of 64 queries and streams its share of the dataset through in tiles of 128 rows, rows are read once per 64 queries instead
+ *  of once per query, the products run on `v_mfma_f32_32x32x16_{f16,bf16}` / `v_mfma_i32_32x32x32_i8`, and the per-query
+ *  top-k is folded in the epilogue of every tile (a candidate survives only if it beats the query's current k-th best).
+ *
+ *  Pairs: cos and ip over f16 / bf16 (f32 accumulation inside the matrix unit: results within the float tolerance of the
+ *  wave-per-query kernel of kernels.hpp, which stays THE bit-exact path), and ip / cos / l2sq over i8 (exact int32 sums and
+ *  the same closing arithmetic as `finalize_distance`: bit-identical to that kernel, ties included — selection is the total
+ *  order (distance ↑, slot ↓) that `search_exact_`'s lower_bound inserts produce).
+ *
+ *  Both operands are row-major with the summation index contiguous, and the A and B fragments of these MFMA shapes use the
+ *  same (lane half, element) → k assignment, so every lane simply loads 16 consecutive bytes of "its" query row and of "its"
+ *  dataset row: no transposition anywhere. C/D: column (dataset row) = lane & 31, row (query) = (reg & 3) + 8·(reg >> 2) +
+ *  4·(lane >> 5).
+ */
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+#include "engine.hpp"
+#include "host_util.hpp"
+
+namespace usearch_amd {
+
+namespace {
+
+constexpr int tile_queries_k = 64;  ///< queries per workgroup
+constexpr int tile_rows_k = 128;    ///< dataset rows per inner tile
+constexpr int chunk_bytes_k = 128;  ///< bytes of every row staged per step of the summation loop (4 MFMA steps of 32 bytes)
+constexpr int pitch_k = chunk_bytes_k + 16; ///< LDS row pitch: keeps 16-byte reads of consecutive rows off the same banks
+constexpr int max_wanted_k = 64;    ///< per-query results the epilogue keeps (one lane per entry)
+
+using f32x16_t = float __attribute__((ext_vector_type(16)));
+using i32x16_t = int __attribute__((ext_vector_type(16)));
+using f16x8_t = _Float16 __attribute__((ext_vector_type(8)));
+using bf16x8_t = __bf16 __attribute__((ext_vector_type(8)));
+using i32x4_t = int __attribute__((ext_vector_type(4)));
+
+template <int scalar_ak> struct accumulator_gt {
+    using type = f32x16_t;
+};
+template <> struct accumulator_gt<scalar_i8_k> {
+    using type = i32x16_t;
+};
+
+template <int scalar_ak>
+__device__ __forceinline__ typename accumulator_gt<scalar_ak>::type multiply(uint4 a, uint4 b,
+                                                                             typename accumulator_gt<scalar_ak>::type c) {
+    if constexpr (scalar_ak == scalar_f16_k)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else if constexpr (scalar_ak == scalar_bf16_k)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, a), __builtin_bit_cast(i32x4_t, b), c, 0, 0, 0);
+}
+
+/// Σx² of every row, as the closing arithmetic wants it: f32 for the float kinds, exact int32 for i8 (stored as bits).
+template <int scalar_ak>
+__global__ __launch_bounds__(256) void row_norms_kernel(const std::uint8_t* rows, std::uint64_t count, std::uint64_t stride,
+                                                        std::uint32_t bytes, std::uint32_t* out) {
+    const std::uint64_t row = blockIdx.x * 4ull + threadIdx.x / 64;
+    const std::uint32_t lane = threadIdx.x % 64;
+    if (row >= count)
+        return;
+    const std::uint8_t* p = rows + row * stride;
+    float sum = 0.f;
+    int exact = 0;
+    for (std::uint32_t b = lane * 2; b < bytes; b += 128) {
+        if constexpr (scalar_ak == scalar_i8_k) {
+            const int x = (std::int8_t)p[b], y = b + 1 < bytes ? (std::int8_t)p[b + 1] : 0;
+            exact += x * x + y * y;
+        } else {
+            const std::uint32_t bits = (std::uint32_t)p[b] | ((std::uint32_t)p[b + 1] << 8);
+            const float x = scalar_ak == scalar_bf16_k ? __builtin_bit_cast(float, bits << 16)
+                                                       : (float)__builtin_bit_cast(_Float16, (std::uint16_t)bits);
+            sum = __builtin_fmaf(x, x, sum);
+        }
+    }
+#pragma unroll
+    for (int offset = 32; offset >= 1; offset >>= 1) {
+        sum += __shfl_xor(sum, offset, 64);
+        exact += __shfl_xor(exact, offset, 64);
+    }
+    if (lane == 0)
+        out[row] = scalar_ak == scalar_i8_k ? (std::uint32_t)exact : __builtin_bit_cast(std::uint32_t, sum);
+}
+
+/// (distance, slot) `a` goes before `b` in what `search_exact_` returns: closer first, the later slot first among equals.
+__device__ __forceinline__ bool goes_before(float da, std::uint32_t sa, float db, std::uint32_t sb) {
+    return da < db || (da == db && sa > sb);
+}
+
+/**
+ *  grid = (query tiles, row partitions), 256 threads = 4 waves. Wave w multiplies all 64 queries of the tile with rows
+ *  [32w, 32w + 32) of every row tile: two 32 × 32 accumulators.
+ */
+template <int metric_ak, int scalar_ak>
+__global__ __launch_bounds__(256) void exact_tiled_kernel(const snapshot_view_t ix, const std::uint8_t* queries,
+                                                          std::uint64_t query_stride, std::uint32_t query_count,
+                                                          std::uint32_t wanted, std::uint64_t rows_per_partition,
+                                                          const std::uint32_t* row_norms, const std::uint32_t* query_norms,
+                                                          std::uint32_t map_keys, float* out_distances,
+                                                          std::uint64_t* out_keys, std::uint64_t* out_counts) {
+    using accumulator_t = typename accumulator_gt<scalar_ak>::type;
+    extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
+    std::uint8_t* stage_q = lds;                                      // [64][pitch]
+    std::uint8_t* stage_r = stage_q + tile_queries_k * pitch_k;       // [128][pitch]
+    float* tile_d = reinterpret_cast<float*>(lds);                    // [64][129], aliases the staging area after the products
+    constexpr std::uint32_t staging_bytes = (tile_queries_k + tile_rows_k) * pitch_k;
+    constexpr std::uint32_t tile_bytes = tile_queries_k * (tile_rows_k + 1) * 4;
+    constexpr std::uint32_t shared_bytes = staging_bytes > tile_bytes ? staging_bytes : tile_bytes;
+    float* top_d = reinterpret_cast<float*>(lds + shared_bytes);      // [64][max_wanted_k]
+    std::uint32_t* top_s = reinterpret_cast<std::uint32_t*>(top_d + tile_queries_k * max_wanted_k);
+    std::uint32_t* top_n = top_s + tile_queries_k * max_wanted_k;      // [64]
+    std::uint32_t* norms_q = top_n + tile_queries_k;                   // [64]
+    std::uint32_t* norms_r = norms_q + tile_queries_k;                 // [128]
+    std::uint32_t* valid_r = norms_r + tile_rows_k;                    // [128] 1 = a live member
+
+    const std::uint32_t thread = threadIdx.x, wave = thread / 64, lane = thread % 64;
+    const std::uint32_t first_query = blockIdx.x * tile_queries_k;
+    const std::uint64_t first_row = (std::uint64_t)blockIdx.y * rows_per_partition;
+    const std::uint64_t last_row = first_row + rows_per_partition < ix.size ? first_row + rows_per_partition : ix.size;
+    const std::uint32_t bytes = ix.bytes_per_vector;
+    const std::uint32_t chunks = (bytes + chunk_bytes_k - 1) / chunk_bytes_k;
+
+    if (thread < tile_queries_k) {
+        top_n[thread] = 0;
+        norms_q[thread] = first_query + thread < query_count ? query_norms[first_query + thread] : 0u;
+    }
+    __syncthreads();
+
+    for (std::uint64_t tile_row = first_row; tile_row < last_row; tile_row += tile_rows_k) {
+        accumulator_t acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[t][r] = 0;
+        if (thread < tile_rows_k) {
+            const std::uint64_t row = tile_row + thread;
+            const bool inside = row < last_row;
+            norms_r[thread] = inside ? row_norms[row] : 0u;
+            valid_r[thread] = inside && (!ix.has_tombstones || ix.keys[row] != free_key_k) ? 1u : 0u;
+        }
+        for (std::uint32_t chunk = 0; chunk < chunks; ++chunk) {
+            // ---- stage 128 bytes of every query and of every row of the tile: 8 consecutive threads fetch one row's 128 bytes
+            const std::uint32_t segment = thread % 8, byte = chunk * chunk_bytes_k + segment * 16;
+            {
+                for (std::uint32_t pass = 0; pass < tile_queries_k / 32; ++pass) {
+                    const std::uint32_t i = pass * 32 + thread / 8;
+                    uint4 value = {0u, 0u, 0u, 0u};
+                    if (first_query + i < query_count && byte < bytes) {
+                        const std::uint8_t* source = queries + (std::uint64_t)(first_query + i) * query_stride + byte;
+                        if (byte + 16 <= bytes && (query_stride % 16 == 0) && ((std::uintptr_t)queries % 16 == 0))
+                            value = *reinterpret_cast<const uint4*>(source);
+                        else { // ragged end of a row, or an unaligned batch: byte by byte
+                            std::uint8_t parts[16] = {0};
+                            for (std::uint32_t b = 0; b < 16 && byte + b < bytes; ++b)
+                                parts[b] = source[b];
+                            value = *reinterpret_cast<const uint4*>(parts);
+                        }
+                    }
+                    *reinterpret_cast<uint4*>(stage_q + i * pitch_k + segment * 16) = value;
+                }
+                for (std::uint32_t pass = 0; pass < tile_rows_k / 32; ++pass) {
+                    const std::uint32_t j = pass * 32 + thread / 8;
+                    const std::uint64_t row = tile_row + j;
+                    uint4 value = {0u, 0u, 0u, 0u};
+                    // stored rows are 16-byte aligned and zero padded to whole 16-byte chunks (`ix.chunks`)
+                    if (row < last_row && byte < ix.chunks * 16u)
+                        value = *reinterpret_cast<const uint4*>(ix.vectors + row * ix.row_stride + byte);
+                    *reinterpret_cast<uint4*>(stage_r + j * pitch_k + segment * 16) = value;
+                }
+            }
+            __syncthreads();
+            // ---- four steps of 32 bytes: lane half h of every fragment owns bytes [32·step + 16h, +16) of its row
+#pragma unroll
+            for (std::uint32_t step = 0; step < chunk_bytes_k / 32; ++step) {
+                const std::uint32_t offset = step * 32 + (lane >> 5) * 16;
+                const uint4 b = *reinterpret_cast<const uint4*>(stage_r + (wave * 32 + (lane & 31)) * pitch_k + offset);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(stage_q + (t * 32 + (lane & 31)) * pitch_k + offset);
+                    acc[t] = multiply<scalar_ak>(a, b, acc[t]);
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- distances of the tile into LDS (the staging area is free now): D[query][row of the tile]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const std::uint32_t i = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const std::uint32_t j = wave * 32 + (lane & 31);
+                float distance;
+                if constexpr (scalar_ak == scalar_i8_k) {
+                    const int ab = acc[t][r], a2 = (int)norms_q[i], b2 = (int)norms_r[j];
+                    if constexpr (metric_ak == metric_cos_k) { // metric_cos_i8_t, index_plugins.hpp:1583-1607
+                        const float a2f = __builtin_sqrtf((float)a2), b2f = __builtin_sqrtf((float)b2);
+                        distance = ab != 0 ? 1.f - (float)ab / (a2f * b2f) : 0.f;
+                    } else if constexpr (metric_ak == metric_ip_k) {
+                        distance = 1.f - (float)ab;
+                    } else { // metric_l2sq_i8_t 1613-1630
+                        distance = (float)(a2 + b2 - 2 * ab);
+                    }
+                } else {
+                    const float ab = acc[t][r], a2 = __builtin_bit_cast(float, norms_q[i]), b2 = __builtin_bit_cast(float, norms_r[j]);
+                    if constexpr (metric_ak == metric_cos_k) { // metric_cos_gt, index_plugins.hpp:1334-1359
+                        if (a2 == 0.f && b2 == 0.f)
+                            distance = 0.f;
+                        else if (a2 == 0.f || b2 == 0.f)
+                            distance = 1.f;
+                        else
+                            distance = 1.f - ab / (__builtin_sqrtf(a2) * __builtin_sqrtf(b2));
+                    } else {
+                        distance = 1.f - ab;
+                    }
+                }
+                tile_d[i * (tile_rows_k + 1) + j] = valid_r[j] ? distance : __builtin_inff();
+            }
+        }
+        __syncthreads();
+
+        // ---- fold: wave w owns queries [16w, 16w + 16); a candidate enters a query's list if the list is not full or it goes
+        //      before the list's last entry. Lists are kept in order, one lane per entry.
+        for (std::uint32_t local = 0; local < tile_queries_k / 4; ++local) {
+            const std::uint32_t i = wave * (tile_queries_k / 4) + local;
+            if (first_query + i >= query_count)
+                break;
+            float* list_d = top_d + i * max_wanted_k;
+            std::uint32_t* list_s = top_s + i * max_wanted_k;
+            std::uint32_t size = top_n[i];
+#pragma unroll
+            for (std::uint32_t half = 0; half < tile_rows_k / 64; ++half) {
+                const std::uint32_t j = half * 64 + lane;
+                const float candidate = tile_d[i * (tile_rows_k + 1) + j];
+                const std::uint32_t slot = (std::uint32_t)(tile_row + j);
+                float worst_d = size ? list_d[size - 1] : 0.f;
+                std::uint32_t worst_s = size ? list_s[size - 1] : 0u;
+                std::uint64_t pending = __ballot(candidate != __builtin_inff() &&
+                                                 (size < wanted || goes_before(candidate, slot, worst_d, worst_s)));
+                while (pending) {
+                    const std::uint32_t source = (std::uint32_t)__ffsll((long long)pending) - 1;
+                    pending &= pending - 1;
+                    const float d = __shfl(candidate, (int)source, 64);
+                    const std::uint32_t s = (std::uint32_t)(tile_row + half * 64 + source);
+                    if (size == wanted && !goes_before(d, s, worst_d, worst_s))
+                        continue;
+                    // position = entries that go before the newcomer; the ones at and after it move one cell down
+                    const bool mine = lane < size;
+                    const float my_d = mine ? list_d[lane] : 0.f;
+                    const std::uint32_t my_s = mine ? list_s[lane] : 0u;
+                    const std::uint32_t position = (std::uint32_t)__popcll(__ballot(mine && goes_before(my_d, my_s, d, s)));
+                    const std::uint32_t grown = size < wanted ? size + 1 : size;
+                    if (mine && lane >= position && lane + 1 < grown)
+                        list_d[lane + 1] = my_d, list_s[lane + 1] = my_s;
+                    if (lane == position)
+                        list_d[position] = d, list_s[position] = s;
+                    size = grown;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                    worst_d = list_d[size - 1], worst_s = list_s[size - 1];
+                }
+            }
+            if (lane == 0)
+                top_n[i] = size;
+        }
+        __syncthreads(); // the tile's distances are consumed: the area becomes staging again
+    }
+
+    // ---- this partition's lists, laid out [partition][query][wanted] like the wave-per-query kernel's
+    for (std::uint32_t cell = thread; cell < tile_queries_k * wanted; cell += 256) {
+        const std::uint32_t i = cell / wanted, position = cell % wanted;
+        const std::uint32_t q = first_query + i;
+        if (q >= query_count)
+            continue;
+        const std::uint64_t out = ((std::uint64_t)blockIdx.y * query_count + q) * wanted + position;
+        std::uint64_t key = 0;
+        std::uint32_t bits = signaling_nan_bits_k;
+        if (position < top_n[i]) {
+            const std::uint32_t slot = top_s[i * max_wanted_k + position];
+            key = map_keys ? ix.keys[slot] : (std::uint64_t)slot;
+            bits = __builtin_bit_cast(std::uint32_t, top_d[i * max_wanted_k + position]);
+        }
+        out_keys[out] = key;
+        reinterpret_cast<std::uint32_t*>(out_distances)[out] = bits;
+    }
+    if (thread < tile_queries_k && first_query + thread < query_count)
+        out_counts[(std::uint64_t)blockIdx.y * query_count + first_query + thread] = top_n[thread];
+}
+
+constexpr std::uint32_t tiled_lds_bytes() {
+    constexpr std::uint32_t staging = (tile_queries_k + tile_rows_k) * pitch_k;
+    constexpr std::uint32_t tile = tile_queries_k * (tile_rows_k + 1) * 4;
+    return (staging > tile ? staging : tile) + tile_queries_k * max_wanted_k * 8 + tile_queries_k * 4 + tile_queries_k * 4 +
+           tile_rows_k * 4 + tile_rows_k * 4;
+}
+
+template <int metric_ak, int scalar_ak>
+hipError_t launch_tiled(const snapshot_view_t& view, const std::uint8_t* queries, std::uint64_t query_stride,
+                        std::uint32_t query_count, std::uint32_t wanted, std::uint32_t partitions,
+                        std::uint64_t rows_per_partition, const std::uint32_t* row_norms, const std::uint32_t* query_norms,
+                        bool map_keys, float* out_distances, std::uint64_t* out_keys, std::uint64_t* out_counts,
+                        hipStream_t stream) {
+    auto kernel = exact_tiled_kernel<metric_ak, scalar_ak>;
+    const std::uint32_t lds = tiled_lds_bytes();
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
+    const dim3 grid((query_count + tile_queries_k - 1) / tile_queries_k, partitions);
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, view, queries, query_stride, query_count, wanted,
+                       rows_per_partition, row_norms, query_norms, map_keys ? 1u : 0u, out_distances, out_keys, out_counts);
+    return hipGetLastError();
+}
+
+template <int scalar_ak>
+hipError_t launch_norms(const std::uint8_t* rows, std::uint64_t count, std::uint64_t stride, std::uint32_t bytes,
+                        std::uint32_t* out, hipStream_t stream) {
+    if (!count)
+        return hipSuccess;
+    hipLaunchKernelGGL(row_norms_kernel<scalar_ak>, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, stream, rows, count,
+                       stride, bytes, out);
+    return hipGetLastError();
+}
+
+} // namespace
+
+bool exact_tiled_available(metric_kind_t metric, scalar_kind_t scalar, std::size_t wanted) {
+    if (!wanted || wanted > (std::size_t)max_wanted_k)
+        return false;
+    if (scalar == scalar_f16_k || scalar == scalar_bf16_k)
+        return metric == metric_cos_k || metric == metric_ip_k;
+    if (scalar == scalar_i8_k)
+        return metric == metric_cos_k || metric == metric_ip_k || metric == metric_l2sq_k;
+    return false;
+}
+
+const char* exact_search_tiled_device(metric_kind_t metric, scalar_kind_t scalar, const snapshot_view_t& view,
+                                      const void* queries, std::size_t count, std::size_t stride_bytes, std::size_t wanted,
+                                      bool map_keys, std::uint64_t* keys, float* distances, std::uint64_t* counts,
+                                      hipStream_t stream, float* kernel_ms) {
+    if (kernel_ms)
+        *kernel_ms = 0.f;
+    if (!exact_tiled_available(metric, scalar, wanted))
+        return "No tiled exact-search kernel for this metric / scalar kind / result count";
+    if (!count)
+        return nullptr;
+    if (count >= none_slot_k || view.size >= none_slot_k)
+        return "Batch is too large";
+    if (!view.size)
+        return "Nothing to scan";
+    // enough (query tile, partition) workgroups to fill the chip several times over; few enough lists per query to fold
+    const std::uint64_t query_tiles = (count + tile_queries_k - 1) / tile_queries_k;
+    std::uint64_t partitions = std::max<std::uint64_t>(1, (2048 + query_tiles - 1) / query_tiles);
+    partitions = std::min<std::uint64_t>(partitions, std::max<std::uint64_t>(1, 8192 / wanted));
+    partitions = std::min<std::uint64_t>(partitions, std::max<std::uint64_t>(1, view.size / (4 * tile_rows_k)));
+    partitions = std::min<std::uint64_t>(partitions, 65535);
+    std::uint64_t rows_per_partition = (view.size + partitions - 1) / partitions;
+    rows_per_partition = (rows_per_partition + tile_rows_k - 1) / tile_rows_k * tile_rows_k;
+    partitions = (view.size + rows_per_partition - 1) / rows_per_partition;
+
+    struct scratch_t {
+        std::vector<void*> pointers;
+        hipEvent_t begin = nullptr, end = nullptr;
+        ~scratch_t() {
+            for (void* p : pointers)
+                if (p)
+                    (void)hipFree(p);
+            if (begin)
+                (void)hipEventDestroy(begin);
+            if (end)
+                (void)hipEventDestroy(end);
+        }
+        hipError_t allocate(void** out, std::size_t bytes) {
+            *out = nullptr;
+            const hipError_t e = hipMalloc(out, std::max<std::size_t>(bytes, 16));
+            if (e == hipSuccess)
+                pointers.push_back(*out);
+            return e;
+        }
+    } scratch;
+    std::uint32_t *row_norms = nullptr, *query_norms = nullptr;
+    float* partial_distances = nullptr;
+    std::uint64_t *partial_keys = nullptr, *partial_counts = nullptr;
+    UA_HIP(scratch.allocate((void**)&row_norms, view.size * 4));
+    UA_HIP(scratch.allocate((void**)&query_norms, count * 4));
+    UA_HIP(scratch.allocate((void**)&partial_distances, partitions * count * wanted * 4));
+    UA_HIP(scratch.allocate((void**)&partial_keys, partitions * count * wanted * 8));
+    UA_HIP(scratch.allocate((void**)&partial_counts, partitions * count * 8));
+    if (kernel_ms) {
+        UA_HIP(hipEventCreate(&scratch.begin));
+        UA_HIP(hipEventCreate(&scratch.end));
+        UA_HIP(hipEventRecord(scratch.begin, stream));
+    }
+    const std::uint8_t* query_bytes = static_cast<const std::uint8_t*>(queries);
+    hipError_t e = hipSuccess;
+#define UA_TILED(m, sc)                                                                                                 \
+    if (e == hipSuccess && metric == m && scalar == sc) {                                                              \
+        e = launch_norms<sc>(view.vectors, view.size, view.row_stride, view.bytes_per_vector, row_norms, stream);      \
+        if (e == hipSuccess)                                                                                           \
+            e = launch_norms<sc>(query_bytes, count, stride_bytes, view.bytes_per_vector, query_norms, stream);        \
+        if (e == hipSuccess)                                                                                           \
+            e = launch_tiled<m, sc>(view, query_bytes, stride_bytes, (std::uint32_t)count, (std::uint32_t)wanted,      \
+                                    (std::uint32_t)partitions, rows_per_partition, row_norms, query_norms, map_keys,   \
+                                    partial_distances, partial_keys, partial_counts, stream);                          \
+    }
+    UA_TILED(metric_cos_k, scalar_f16_k)
+    UA_TILED(metric_ip_k, scalar_f16_k)
+    UA_TILED(metric_cos_k, scalar_bf16_k)
+    UA_TILED(metric_ip_k, scalar_bf16_k)
+    UA_TILED(metric_cos_k, scalar_i8_k)
+    UA_TILED(metric_ip_k, scalar_i8_k)
+    UA_TILED(metric_l2sq_k, scalar_i8_k)
+#undef UA_TILED
+    if (e != hipSuccess)
+        return hip_message(e);
+    if (kernel_ms)
+        UA_HIP(hipEventRecord(scratch.end, stream));
+    if (const char* error = merge_shards_device(partial_distances, partial_keys, partial_counts, partitions, count, wanted,
+                                                distances, keys, counts, stream, false))
+        return error;
+    if (kernel_ms)
+        UA_HIP(hipEventElapsedTime(kernel_ms, scratch.begin, scratch.end));
+    return nullptr;
+}
+
+} // namespace usearch_amd

@@ -82,7 +82,8 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_snapshot_metric_kind", "usearch_amd_snapshot_lanes_per_row", "usearch_amd_search_many",
     "usearch_amd_search_many_device", "usearch_amd_last_peaks", "usearch_amd_distances",
     "usearch_amd_last_distances_ms", "usearch_amd_merge_many", "usearch_amd_merge_many_device",
-    "usearch_amd_exact_search_many", "usearch_amd_exact_search_dataset", "usearch_amd_cluster_many",
+    "usearch_amd_exact_search_many", "usearch_amd_exact_search_many_tiled", "usearch_amd_exact_search_dataset",
+    "usearch_amd_cluster_many",
     "usearch_amd_test_containers", "usearch_amd_cast",
     "usearch_amd_build", "usearch_amd_build_free", "usearch_amd_build_snapshot",
     "usearch_amd_build_serialized_length", "usearch_amd_build_save_buffer", "usearch_amd_build_stats",
@@ -131,6 +132,7 @@ def library() -> C.CDLL:
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, err_p]
     L.usearch_amd_exact_search_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), err_p]
+    L.usearch_amd_exact_search_many_tiled.argtypes = L.usearch_amd_exact_search_many.argtypes
     L.usearch_amd_exact_search_dataset.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                                    C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p,
                                                    C.c_size_t, C.c_void_p, C.c_size_t, err_p]
@@ -304,7 +306,7 @@ class Index:
     # ---- search
     def search(self, vectors: np.ndarray, count: int = 10, *, expansion: Optional[int] = None,
                dtype: Optional[str] = None, tuning: Optional[Tuning] = None,
-               exact: bool = False) -> Union[Matches, BatchMatches]:
+               exact: Union[bool, str] = False) -> Union[Matches, BatchMatches]:
         """`Index.search` (index.py:700-748): one vector → `Matches`, a 2-D batch → `BatchMatches`.
 
         `dtype` names the scalar kind of `vectors` when numpy cannot tell (bit-packed `b1` rows are `uint8`);
@@ -332,7 +334,10 @@ class Index:
         err = C.c_char_p()
         if exact:  # brute force over every stored vector (Index.search(..., exact=True), index.py:700-748)
             kernel_ms = C.c_float()
-            library().usearch_amd_exact_search_many(self._handle, _pointer(vectors), SCALAR_KINDS[dtype], q,
+            # exact="tiled": the matrix-unit kernel (f16 / bf16 cos, ip within float tolerance; i8 bit-identical)
+            entry = (library().usearch_amd_exact_search_many_tiled if exact == "tiled"
+                     else library().usearch_amd_exact_search_many)
+            entry(self._handle, _pointer(vectors), SCALAR_KINDS[dtype], q,
                                                     vectors.shape[1] * vectors.itemsize if q <= 1 else vectors.strides[0],
                                                     count, _pointer(keys), _pointer(distances), _pointer(counts),
                                                     C.byref(kernel_ms), C.byref(err))
