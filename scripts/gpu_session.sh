@@ -31,6 +31,10 @@ for step in "$@"; do
     c4ab)     for dense in 1 0; do USEARCH_AMD_DENSE_ROWS=$dense timeout 300 python bench.py --n 20000000 --dim 96 --dtype i8 \
                 --queries 100000 --expansion 96 --recall-queries 1000 --no-stress-rows --no-cpu-baseline --steps 5 \
                 > "$OUT/c4_dense$dense.json" 2> "$OUT/c4_dense$dense.log"; cat "$OUT/c4_dense$dense.json"; done ;;
+    sharded2) timeout 600 python -m pytest tests/test_gpu_sharded.py tests/test_gpu_exact.py -q > "$OUT/sharded2.log" 2>&1; tail -15 "$OUT/sharded2.log" ;;
+    prof10m)  timeout 1500 bash scripts/profile_round.sh $TAG/headline ;;
+    profc4)   PROFILE_TRAFFIC_ONLY=1 timeout 1500 bash scripts/profile_round.sh $TAG/c4 --n 100000000 --dim 96 --dtype i8 --queries 100000 ;;
+    profc5)   PROFILE_TRAFFIC_ONLY=1 timeout 1500 bash scripts/profile_round.sh $TAG/c5 --n 125000000 --dim 128 --dtype b1 --queries 100000 ;;
     *) echo "unknown step $step" ;;
   esac
 done

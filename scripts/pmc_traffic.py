@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""scripts/pmc_traffic.py <FETCH_SIZE csv> <WRITE_SIZE csv> [kernel substring] → JSON with the HBM bytes per launch of the
+"""scripts/pmc_traffic.py <FETCH_SIZE csv> <WRITE_SIZE csv> [kernel substring] [bench line json] → JSON with the HBM bytes per launch of the
 search kernel, from rocprofv3 PMC passes collected SEPARATELY (TCC slots: FETCH_SIZE and WRITE_SIZE do not fit one pass),
 corrected as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes: counters are in KiB; on gfx950 FETCH_SIZE tallies
-128-byte requests at 64 bytes, so wide (16 B/lane) reads are doubled; WRITE_SIZE is taken as is (uncalibrated)."""
+128-byte requests at 64 bytes, so wide (16 B/lane) reads are doubled; WRITE_SIZE is taken as is (uncalibrated). With a bench
+line (the JSON bench.py printed in one of the profiled runs) the result also names the workload and the sources it was measured
+on: bench.py attaches a `roofline.traffic` only to lines of that very workload built from those very sources."""
 import csv
 import json
 import sys
@@ -32,7 +34,14 @@ def main():
     fetch_bytes = fetch_kib * 1024 * 2 if fetch_kib is not None else None
     write_bytes = write_kib * 1024 if write_kib is not None else None
     total = (fetch_bytes or 0) + (write_bytes or 0) if fetch_bytes is not None else None
-    print(json.dumps({"hbm_bytes_per_launch": total, "fetch_bytes_per_launch": fetch_bytes,
+    identity = {}
+    if len(sys.argv) > 4:
+        try:
+            line = json.load(open(sys.argv[4]))
+            identity = {"workload": line["config"]["workload"], "sources": line["config"]["sources"]}
+        except (OSError, ValueError, KeyError):
+            pass
+    print(json.dumps({**identity, "hbm_bytes_per_launch": total, "fetch_bytes_per_launch": fetch_bytes,
                       "write_bytes_per_launch": write_bytes, "launches_averaged": [fetch_n, write_n], "kernel": kernel_name,
                       "correction": "FETCH_SIZE[KiB] x 1024 x 2 (gfx950: 128-B requests tallied at 64 B) + "
                                     "WRITE_SIZE[KiB] x 1024 (uncalibrated)"}))

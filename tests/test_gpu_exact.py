@@ -97,8 +97,8 @@ def test_tiled_exact_search_of_float_pairs_is_within_tolerance(reference, metric
     queries = util.make_vectors(70, ndim, dtype, seed=96)
     queries[:10] = vectors[:10]
     index = Index.restore(image)
-    exact = index.search(queries, k, exact=True)
-    tiled = index.search(queries, k, exact="tiled")
+    exact = index.search(queries, k, exact=True, dtype=dtype)
+    tiled = index.search(queries, k, exact="tiled", dtype=dtype)
     assert np.array_equal(exact.counts, tiled.counts)
     scale = np.maximum(1.0, np.abs(exact.distances))
     assert np.all(np.abs(exact.distances - tiled.distances) <= util.tolerance(dtype) * scale)

@@ -163,6 +163,38 @@ class Communicator:
         _raise(err, "usearch_amd_comm_init_custom")
         return cls(handle, "torch-distributed", keep=(callbacks, transport))
 
+    # ---- the device step with HOST-side collectives (gloo, MPI …): blocks are staged through pinned memory
+    @classmethod
+    def over_host_collectives(cls, rank: int, world: int, device: int,
+                              all_gather: Callable[[np.ndarray, np.ndarray], None],
+                              broadcast: Optional[Callable[[np.ndarray, int], None]]) -> "Communicator":
+        """`all_gather(send u8[n], receive u8[world·n])`, `broadcast(buffer u8[n], root)` over host memory; the search, the
+        packing and the merge run on the device (`usearch_amd_transport_t::buffers_on_host = 1`)."""
+
+        def view(pointer: int, nbytes: int) -> np.ndarray:
+            return np.ctypeslib.as_array(C.cast(pointer, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+        def gather_callback(_context, send, receive, nbytes, _stream):
+            try:
+                all_gather(view(send, nbytes), view(receive, nbytes * world))
+                return None
+            except Exception as error:
+                return _message(error)
+
+        def broadcast_callback(_context, buffer, nbytes, root, _stream):
+            try:
+                broadcast(view(buffer, nbytes), root)
+                return None
+            except Exception as error:
+                return _message(error)
+
+        callbacks = (ALL_GATHER_T(gather_callback), BROADCAST_T(broadcast_callback) if broadcast else BROADCAST_T())
+        transport = Transport(None, callbacks[0], callbacks[1], 1, LOCAL_SEARCH_T())
+        err = C.c_char_p()
+        handle = _bind(binding.library()).usearch_amd_comm_init_custom(C.byref(transport), rank, world, device, C.byref(err))
+        _raise(err, "usearch_amd_comm_init_custom")
+        return cls(handle, "host-collectives", keep=(callbacks, transport))
+
     # ---- everything in host memory, the device search replaced by `local_search`: the protocol without a GPU
     @classmethod
     def on_host(cls, rank: int, world: int, all_gather: Callable[[np.ndarray, np.ndarray], None],
