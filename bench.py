@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — batched HNSW search throughput on MI355X, one process per GPU.
 
-    python bench.py [--gpus N --steps K --warmup W] [--n N --dim D --dtype f16 --metric cos --queries Q --k 10 ...]
+    python bench.py [--gpus N --steps K --warmup W] [--vectors N --dim D --dtype f16 --metric cos --queries Q --k 10 ...]
 
 A *step* is one pass of the hot path over one batch: `--queries` (default 10 000) queries searched against the
 HBM-resident index, inputs and outputs already in HBM. Rank 0 prints ONE JSON line (contract in the task statement),
@@ -14,12 +14,12 @@ with two extra objects:
 Default workload = the configuration BASELINE.json's metric is quoted on: 10M x 768 f16 cosine, batch 10 000, k = 10.
 The seeded synthetic vectors are generated in HBM and the index is built ON THE GPU (`usearch_amd.build`, ≈20 s for 10M;
 `--builder reference` lets the reference build it on the host cores instead — minutes per million vectors, so only for
-small `--n`). The reference is handed the very same index (`save_buffer` → `usearch_view_buffer`) for the CPU baseline.
+small `--vectors`). The reference is handed the very same index (`save_buffer` → `usearch_view_buffer`) for the CPU baseline.
 `--gpus N` without a launcher re-executes itself under `torch.distributed.run` with N ranks (one per GPU); under a launcher
 (RANK / WORLD_SIZE in the environment) it is one of the ranks. With N > 1 every rank builds (deterministically, so
 identically) and holds a replica and searches its own batch: weak scaling, no collective on the data path, `value` = the
 queries all ranks answered per second. `--sharded` is the capacity mode for indexes beyond one GPU: every rank builds and
-holds its own shard of `--n` vectors EACH, the batch is broadcast, every rank searches its shard, per-shard top-k travel in
+holds its own shard of `--vectors` vectors EACH, the batch is broadcast, every rank searches its shard, per-shard top-k travel in
 ONE packed RCCL all-gather and are merged (`usearch_amd_sharded_search_many`, usearch_amd/csrc/sharded.hip). Per-GPU work
 is fixed as N grows (weak scaling of the index size): `value` = batch × shards ÷ time, "shard-queries/s" — the 1-GPU point
 is one shard searched by the same batch — and `config.queries_per_second` is the rate against the whole N-shard index
@@ -143,7 +143,9 @@ def relaunch_with_ranks(gpus: int) -> None:
         probe.bind(("127.0.0.1", 0))
         port = probe.getsockname()[1]
     command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    command += ["--vectors" if argument == "--n" else argument.replace("--n=", "--vectors=", 1) if argument.startswith("--n=")
+                else argument for argument in sys.argv[1:]]
     log(f"[bench] --gpus {gpus} without a launcher: " + " ".join(command))
     os.execv(sys.executable, command)
 
@@ -245,7 +247,10 @@ def main() -> None:
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=5)
     parser.add_argument("--warmup", type=int, default=1)
-    parser.add_argument("--n", type=int, default=int(os.environ.get("BENCH_N", 10_000_000)), help="vectors in the index")
+    # (`--n` would collide with the launcher's own abbreviations — torch.distributed.run reads "--n" as an ambiguous prefix of
+    # --nnodes / --nproc-per-node even behind the script name — hence the long name; `--n` stays as an alias for direct runs)
+    parser.add_argument("--vectors", "--n", dest="n", type=int, default=int(os.environ.get("BENCH_N", 10_000_000)),
+                        help="vectors in the index (per shard with --sharded)")
     parser.add_argument("--dim", type=int, default=768)
     parser.add_argument("--dtype", default="f16", choices=list(DTYPE_BYTES))
     parser.add_argument("--metric", default=None)
@@ -295,7 +300,7 @@ def main() -> None:
     import usearch_amd
 
     # ---- the index. Replicas: every rank builds the same seeded data (the device build is deterministic). Shards: rank r
-    #      builds its own `--n` vectors with keys offset by r * n.
+    #      builds its own `--vectors` vectors with keys offset by r * n.
     sharded = args.sharded
     data_seed = 42 + (rank if sharded else 0)
     key_base = rank * args.n if sharded else 0
@@ -534,11 +539,17 @@ def main() -> None:
             agree = float(np.mean(found_keys[:folded] == merged_keys))
         else:
             agree = float(np.mean(found_keys == rkeys))
+        # one query at a time on one core: what a `usearch_search` loop sees from the reference (latency, not throughput)
+        t1 = time.perf_counter()
+        for i in range(32):
+            ref_index.search(queries_host[i:i + 1], args.k, dtype=args.dtype, threads=1)
+        reference_single_us = (time.perf_counter() - t1) / 32 * 1e6
         cpu = {"value": sample_q / cpu_seconds, "unit": "shard-queries/s" if sharded else "queries/s", "cores": threads,
                "kind": "reference",
                "sample": f"{sample_q} of the step's {args.queries} queries, same index, same ef={expansion}, "
                          f"OpenMP static,32 loop of cpp/bench.cpp:352-377; serial (auto-vectorised) metrics, SimSIMD "
-                         f"unavailable offline; {cpu_seconds:.1f}s; label agreement with the GPU {agree:.4f}"}
+                         f"unavailable offline; {cpu_seconds:.1f}s; label agreement with the GPU {agree:.4f}; one query at a "
+                         f"time on one core: {reference_single_us:.0f} us"}
         del ref_index, image
 
     stress = None
@@ -589,7 +600,7 @@ def main() -> None:
                        if recall is not None else None,
                        "parallelism": ("shards" if sharded else "replicas") + str(world),
                        "queries_per_second": queries_per_second,
-                       "scaling_definition": ("weak: every GPU holds one shard of --n vectors and searches the whole batch; value = "
+                       "scaling_definition": ("weak: every GPU holds one shard of --vectors vectors and searches the whole batch; value = "
                                               "batch x shards / time (shard-queries/s), the 1-GPU point is one shard; "
                                               "queries_per_second is the rate against the whole index") if sharded else
                                              "weak: every GPU holds a replica and searches its own batch; value = all batches / time",

@@ -88,6 +88,15 @@ USEARCH_AMD_EXPORT int usearch_amd_device_count(usearch_amd_error_t* error);
  */
 USEARCH_AMD_EXPORT usearch_amd_snapshot_t usearch_amd_snapshot_from_buffer(void const* image, size_t length, int device,
                                                                            usearch_amd_error_t* error);
+/**
+ *  An image saved with `exclude_vectors` (`serialization_config_t`, index_dense.hpp:1004: the graph alone, the file starts with the
+ *  64-byte head) together with the vectors the caller kept: `vectors` = one row per member in slot order, rows
+ *  `vectors_stride` bytes apart (0 = dense), in the index's scalar kind. An image that carries its matrix loads here too (the
+ *  external rows are ignored then).
+ */
+USEARCH_AMD_EXPORT usearch_amd_snapshot_t usearch_amd_snapshot_from_parts(void const* graph, size_t graph_length,
+                                                                          void const* vectors, size_t vectors_stride,
+                                                                          int device, usearch_amd_error_t* error);
 /** Same from a `.usearch` file (memory-mapped during the call). Replaces `usearch_load` (c/usearch.h:170). */
 USEARCH_AMD_EXPORT usearch_amd_snapshot_t usearch_amd_snapshot_from_file(char const* path, int device,
                                                                          usearch_amd_error_t* error);

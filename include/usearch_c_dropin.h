@@ -10,10 +10,14 @@
  *                  `usearch_search_many` run on the MI355X through an HBM snapshot of the index (include/usearch_amd.h).
  *                  A filter callback is a host function: it is evaluated once per member into one bit per slot, which the
  *                  traversal applies where the reference applies the predicate (index.hpp:4200-4205, 4236-4240).
- *    construction  `usearch_add` stages the vector on the host; the next search / save links ALL staged vectors on the
- *                  device in one batched build (`usearch_amd_build`). Bulk-load-then-search is the intended pattern:
- *                  `usearch_add`, `_remove`, `_rename`, `_change_metric_kind` after a build cost a rebuild at the next
- *                  search. Removed members stay in the graph as tombstones, as in the reference.
+ *    construction  `usearch_add` stages the vector on the host (and, like the reference, fails without reserved room:
+ *                  index.hpp:2812-2818); the next search / save links what was staged on the device — everything in one batched
+ *                  build the first time, afterwards only the members added since (the graph is extended in place, the batch-
+ *                  deferred form of index.hpp:2780-2879). `usearch_remove` writes the tombstone and `usearch_rename` the new key
+ *                  in place in HBM; only `usearch_change_metric_kind` costs a rebuild. Limits of the device builder are said
+ *                  at `usearch_init`: connectivity ≤ 28, expansion_add ≤ 256.
+ *    concurrency   searches share the index (one engine workspace per call in flight, `usearch_change_threads_search` sizes
+ *                  the pool); mutations and the deferred linking take it alone.
  *    persistence   `usearch_save*` writes and `usearch_load* / view*` read the reference's v2 format: files move freely
  *                  between the two libraries.
  *    refused       by name, never computed elsewhere: a user-defined metric function (`usearch_change_metric`,

@@ -19,22 +19,27 @@ for step in "$@"; do
     sweepwaves) timeout 600 python scripts/sweep.py --n 10000000 --ef 592 --modes 2 --waves 8 12 16 --variants 1 2 3 4 5 \
                 --frontiers 2 --steps 3 > "$OUT/sweepwaves.log" 2>&1; cat "$OUT/sweepwaves.log" ;;
     bench)    timeout 900 python bench.py --steps 20 --warmup 5 --wave-clock > "$OUT/bench.json" 2> "$OUT/bench.log"; tail -25 "$OUT/bench.log"; cat "$OUT/bench.json" ;;
-    sharded1) timeout 600 python bench.py --sharded --n 2000000 --dim 128 --dtype b1 --queries 100000 --steps 5 --warmup 2 \
+    sharded1) timeout 600 python bench.py --sharded --vectors 2000000 --dim 128 --dtype b1 --queries 100000 --steps 5 --warmup 2 \
                 > "$OUT/sharded1.json" 2> "$OUT/sharded1.log"; tail -12 "$OUT/sharded1.log"; cat "$OUT/sharded1.json" ;;
-    c4small)  timeout 600 python bench.py --n 20000000 --dim 96 --dtype i8 --queries 100000 --no-stress-rows --cpu-seconds 4 \
+    c4small)  timeout 600 python bench.py --vectors 20000000 --dim 96 --dtype i8 --queries 100000 --no-stress-rows --cpu-seconds 4 \
                 > "$OUT/c4small.json" 2> "$OUT/c4small.log"; tail -8 "$OUT/c4small.log"; cat "$OUT/c4small.json" ;;
-    c5small)  timeout 600 python bench.py --n 20000000 --dim 128 --dtype b1 --queries 100000 --no-stress-rows --cpu-seconds 4 \
+    c5small)  timeout 600 python bench.py --vectors 20000000 --dim 128 --dtype b1 --queries 100000 --no-stress-rows --cpu-seconds 4 \
                 > "$OUT/c5small.json" 2> "$OUT/c5small.log"; tail -8 "$OUT/c5small.log"; cat "$OUT/c5small.json" ;;
-    c5ab)     for inline in 0 1; do USEARCH_AMD_INLINE_ROWS=$inline timeout 300 python bench.py --n 20000000 --dim 128 --dtype b1 \
+    c5ab)     for inline in 0 1; do USEARCH_AMD_INLINE_ROWS=$inline timeout 300 python bench.py --vectors 20000000 --dim 128 --dtype b1 \
                 --queries 100000 --expansion 64 --recall-queries 1000 --no-stress-rows --no-cpu-baseline --steps 5 \
                 > "$OUT/c5_inline$inline.json" 2> "$OUT/c5_inline$inline.log"; cat "$OUT/c5_inline$inline.json"; done ;;
-    c4ab)     for dense in 1 0; do USEARCH_AMD_DENSE_ROWS=$dense timeout 300 python bench.py --n 20000000 --dim 96 --dtype i8 \
+    c4ab)     for dense in 1 0; do USEARCH_AMD_DENSE_ROWS=$dense timeout 300 python bench.py --vectors 20000000 --dim 96 --dtype i8 \
                 --queries 100000 --expansion 96 --recall-queries 1000 --no-stress-rows --no-cpu-baseline --steps 5 \
                 > "$OUT/c4_dense$dense.json" 2> "$OUT/c4_dense$dense.log"; cat "$OUT/c4_dense$dense.json"; done ;;
     sharded2) timeout 600 python -m pytest tests/test_gpu_sharded.py tests/test_gpu_exact.py -q > "$OUT/sharded2.log" 2>&1; tail -15 "$OUT/sharded2.log" ;;
     prof10m)  timeout 1500 bash scripts/profile_round.sh $TAG/headline ;;
-    profc4)   PROFILE_TRAFFIC_ONLY=1 timeout 1500 bash scripts/profile_round.sh $TAG/c4 --n 100000000 --dim 96 --dtype i8 --queries 100000 ;;
-    profc5)   PROFILE_TRAFFIC_ONLY=1 timeout 1500 bash scripts/profile_round.sh $TAG/c5 --n 125000000 --dim 128 --dtype b1 --queries 100000 ;;
+    profc4)   PROFILE_TRAFFIC_ONLY=1 timeout 1500 bash scripts/profile_round.sh $TAG/c4 --vectors 100000000 --dim 96 --dtype i8 --queries 100000 ;;
+    profc5)   PROFILE_TRAFFIC_ONLY=1 timeout 1500 bash scripts/profile_round.sh $TAG/c5 --vectors 125000000 --dim 128 --dtype b1 --queries 100000 ;;
+    w5ab)     for lib in "" "$REPO/usearch_amd/lib_waves5/libusearch_amd.so"; do for shape in "--dim 128 --dtype b1 --expansion 64" "--dim 96 --dtype i8 --expansion 64"; do
+                echo "--- library ${lib:-product} $shape"
+                USEARCH_AMD_LIBRARY=$lib timeout 300 python bench.py --vectors 20000000 $shape --queries 100000 \
+                  --recall-queries 1000 --no-stress-rows --no-cpu-baseline --steps 5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), 'QPS', d['config']['persistent_waves'], 'waves', d['roofline']['kernel_ms'], 'ms')"
+              done; done ;;
     *) echo "unknown step $step" ;;
   esac
 done

@@ -18,3 +18,29 @@ def test_synthetic_vectors_in_every_storage_kind():
 
 def test_host_core_count_respects_the_cgroup_quota():
     assert 1 <= bench.host_cores() <= (__import__("os").cpu_count() or 1)
+
+
+def test_gpus_flag_relaunches_itself_as_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher becomes N ranks under torch.distributed.run; nothing the script accepts
+    may collide with the launcher's own option abbreviations ("--n" reads as an ambiguous prefix of --nnodes / --nproc-per-node
+    there, even behind the script name)."""
+    import sys
+
+    from torch.distributed.run import get_args_parser
+    captured = {}
+    monkeypatch.setattr(bench.os, "execv", lambda program, command: captured.update(program=program, command=command))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5", "--n", "1000", "--sharded",
+                                      "--dtype", "b1", "--dim", "128", "--queries", "100000", "--no-cpu-baseline"])
+    bench.relaunch_with_ranks(4)
+    command = captured["command"]
+    assert command[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in command
+    parsed = get_args_parser().parse_args(command[3:])  # raises SystemExit on an ambiguous / unknown option
+    assert parsed.training_script.endswith("bench.py") and parsed.master_addr == "127.0.0.1"
+    assert parsed.training_script_args == ["--gpus", "4", "--steps", "20", "--warmup", "5", "--vectors", "1000", "--sharded",
+                                           "--dtype", "b1", "--dim", "128", "--queries", "100000", "--no-cpu-baseline"]
+    # every option bench.py itself defines survives the launcher's parser behind the script name
+    import re
+    options = sorted(set(re.findall(r'add_argument\("(--[a-z-]+)"', open(bench.__file__).read())))
+    assert "--vectors" in options and len(options) > 15
+    for option in options:
+        get_args_parser().parse_args(["--nproc-per-node=2", bench.__file__, option, "1"])

@@ -328,3 +328,21 @@ def test_cluster_on_an_empty_index(reference):
     image, _, _ = util.build_image(0, 16, "cos", "f32")
     keys, distances, visited, computed = Index.restore(image).cluster(np.ones((3, 16), dtype=np.float32), 1)
     assert np.all(keys == 0) and np.all(np.isnan(distances)) and np.all(computed == 0)
+
+
+def test_graph_only_image_with_the_callers_vectors(reference):
+    """`serialization_config_t::exclude_vectors` (index_dense.hpp:1004): the file holds the graph alone, the vectors stayed with
+    the caller. Loaded together they are the index that was saved — strided rows included."""
+    from usearch_amd import Index
+    image, vectors, _ = util.build_image(2500, 48, "cos", "f16", seed=81)
+    queries = util.make_vectors(60, 48, "f16", seed=82)
+    whole = Index.restore(image).search(queries, 10)
+    graph_only = util.without_vectors(image)
+    with pytest.raises(RuntimeError, match="exclude_vectors"):
+        Index.restore(graph_only)
+    padded = np.zeros((len(vectors), 64), dtype=np.float16)
+    padded[:, :48] = vectors
+    for matrix in (vectors, padded[:, :48]):
+        parts = Index.restore(graph_only, vectors=matrix).search(queries, 10)
+        assert np.array_equal(parts.keys, whole.keys) and util.same_float_bits(parts.distances, whole.distances)
+        assert np.array_equal(parts.computed_per_query, whole.computed_per_query)

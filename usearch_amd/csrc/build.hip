@@ -14,6 +14,8 @@
 
 namespace usearch_amd {
 
+static_assert(builder_max_expansion_k == build_max_candidates_k, "build.hpp and build_kernels.hpp disagree");
+
 namespace {
 
 double seconds_now() {

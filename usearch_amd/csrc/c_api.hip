@@ -296,6 +296,32 @@ usearch_amd_snapshot_t usearch_amd_snapshot_from_buffer(void const* buffer, size
     return snapshot;
 }
 
+usearch_amd_snapshot_t usearch_amd_snapshot_from_parts(void const* graph, size_t graph_length, void const* vectors,
+                                                       size_t vectors_stride, int device, usearch_amd_error_t* error) {
+    if (!vectors) {
+        fail(error, "No vectors");
+        return nullptr;
+    }
+    image_t image;
+    image.external_vectors = static_cast<const std::uint8_t*>(vectors);
+    image.external_stride = vectors_stride;
+    if (const char* e = image.open(graph, graph_length)) {
+        fail(error, e);
+        return nullptr;
+    }
+    snapshot_t* snapshot = new (std::nothrow) snapshot_t();
+    if (!snapshot) {
+        fail(error, "Out of memory!");
+        return nullptr;
+    }
+    if (const char* e = snapshot->build(image, device)) {
+        fail(error, e);
+        delete snapshot;
+        return nullptr;
+    }
+    return snapshot;
+}
+
 usearch_amd_snapshot_t usearch_amd_snapshot_from_file(char const* path, int device, usearch_amd_error_t* error) {
     int fd = ::open(path, O_RDONLY);
     if (fd < 0) {

@@ -427,6 +427,18 @@ usearch_index_t usearch_init(usearch_init_options_t* options, usearch_error_t* e
     if (options->expansion_search)
         index->expansion_search = options->expansion_search;
     index->multi = options->multi;
+    // the device builder's limits, said here instead of at the first search (build.hip: a node's existing and incoming links
+    // are ranked by one wave)
+    if (2 * index->connectivity > 56 || index->connectivity < 2) {
+        fail(error, "Connectivity must be between 2 and 28 for the device builder (base connectivity 2·M ≤ 56)");
+        delete index;
+        return nullptr;
+    }
+    if (index->expansion_add > builder_max_expansion_k) {
+        fail(error, "Expansion (add) is too large for the device builder");
+        delete index;
+        return nullptr;
+    }
     return index;
 }
 

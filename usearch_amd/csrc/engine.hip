@@ -463,7 +463,8 @@ const char* snapshot_t::build(const image_t& image, int device) {
         if (flags[0])
             return "Failed to pull nodes from the stream";
         tombstones = flags[1] != 0;
-        if (const char* e = upload_rows(static_cast<std::uint8_t*>(d_vectors_), row_stride, image.vectors, bpv, bpv, n))
+        if (const char* e = upload_rows(static_cast<std::uint8_t*>(d_vectors_), row_stride, image.vectors,
+                                        (std::size_t)image.vector_stride, bpv, n))
             return e;
     }
 
@@ -624,9 +625,9 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
             return "That kernel build exists for the in-`top` frontier only";
         variant = requested;
     }
-    const std::uint32_t variant_waves_per_cu = 4u * (std::uint32_t)kernel_waves(variant, (int)entries_per_lane, frontier);
+    const std::uint32_t variant_waves_per_cu = 4u * (std::uint32_t)kernel_waves(variant, (int)entries_per_lane, frontier, (int)lanes_);
     const std::uint32_t waves_cap = tuning.waves_per_cu ? tuning.waves_per_cu
-                                                        : (std::uint32_t)env_size("USEARCH_AMD_WAVES_PER_CU", 16);
+                                                        : (std::uint32_t)env_size("USEARCH_AMD_WAVES_PER_CU", 32);
     call.waves_cap = std::min(waves_cap, variant_waves_per_cu);
 
     auto lds_bytes_for = [&](int mode, std::uint32_t cap_next, std::uint32_t cap_hash) -> std::uint64_t {

@@ -27,6 +27,12 @@ struct image_t {
 
     std::uint64_t rows = 0, cols = 0;
     const std::uint8_t* vectors = nullptr;
+    std::uint64_t vector_stride = 0; ///< bytes between rows of `vectors` (= cols inside an image)
+    /// For images saved with `exclude_vectors` (index_dense.hpp:1004: the file starts with the 64-byte head): the caller's own
+    /// matrix, one row per slot in slot order, set BEFORE `open`. The reference keeps such vectors outside the index as well
+    /// (`copy_vector = false`, index_dense.hpp:2038-2039).
+    const std::uint8_t* external_vectors = nullptr;
+    std::uint64_t external_stride = 0;
 
     std::uint16_t version[3] = {0, 0, 0};
     metric_kind_t metric = metric_unknown_k;
@@ -61,18 +67,20 @@ struct image_t {
         // Which of the three layouts of index_dense.hpp:1004-1030 is this? The reference sniffs it the same way
         // (`index_dense_metadata_from_buffer`, index_dense.hpp:321-371): the 64-byte head right away = saved with
         // `exclude_vectors`; else the magic behind a matrix announced by two u32 — or by two u64 (`use_64_bit_dimensions`).
-        if (length >= 7 && std::memcmp(p, "usearch", 7) == 0)
-            return "The image was saved without its vectors (exclude_vectors): nothing to search";
-        std::size_t dimensions_length = 8;
-        rows = load<std::uint32_t>(p);
-        cols = load<std::uint32_t>(p + 4);
+        const bool without_vectors = length >= 7 && std::memcmp(p, "usearch", 7) == 0;
+        if (without_vectors && !external_vectors)
+            return "The image was saved without its vectors (exclude_vectors): hand the matrix in alongside "
+                   "(usearch_amd_snapshot_from_parts)";
+        std::size_t dimensions_length = without_vectors ? 0 : 8;
+        rows = without_vectors ? 0 : load<std::uint32_t>(p);
+        cols = without_vectors ? 0 : load<std::uint32_t>(p + 4);
         const auto magic_behind = [&](std::uint64_t r, std::uint64_t c, std::size_t header) {
             if (c && r > (std::uint64_t)length / c)
                 return false;
             const std::uint64_t offset = r * c + header;
             return offset + 64 <= (std::uint64_t)length && std::memcmp(bytes + offset, "usearch", 7) == 0;
         };
-        if (!magic_behind(rows, cols, 8) && length >= 16) {
+        if (!without_vectors && !magic_behind(rows, cols, 8) && length >= 16) {
             const std::uint64_t rows64 = load<std::uint64_t>(p), cols64 = load<std::uint64_t>(p + 8);
             if (magic_behind(rows64, cols64, 16))
                 rows = rows64, cols = cols64, dimensions_length = 16;
@@ -81,6 +89,7 @@ struct image_t {
         if ((std::uint64_t)(end - p) < rows * cols)
             return "Failed to read vectors";
         vectors = p;
+        vector_stride = cols;
         p += rows * cols;
         if ((std::size_t)(end - p) < 64)
             return "Failed to read the index ";
@@ -110,6 +119,14 @@ struct image_t {
         max_level = load<std::uint64_t>(p + 24);
         entry_slot = load<std::uint64_t>(p + 32);
         p += 40;
+        if (without_vectors) { // the matrix is the caller's: one row of the head's scalar kind and dimensions per slot
+            rows = size;
+            cols = bytes_per_vector(scalar, dimensions);
+            vectors = external_vectors;
+            vector_stride = external_stride ? external_stride : cols;
+            if (vector_stride < cols)
+                return "Stride is smaller than one vector";
+        }
         if (size != rows)
             return "Index size and the number of vectors doesn't match";
         if (size >= none_slot_k)

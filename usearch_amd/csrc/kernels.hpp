@@ -1490,20 +1490,32 @@ enum kernel_variant_t : int {
     variant_u12x2_w2_k = 3, ///< two rows per lane group per round, 12 loads each: 24 in flight (frontier_top_k builds only)
     variant_count_k = 4,
 };
+/// Waves per SIMD the smallest builds are cut for — `top` of one cell per lane (expansion ≤ 64), 4 loads in flight, rows of one
+/// 16-byte chunk (G = 1) or of ≤ 128 bytes (G = 2). Their hops are a chain of short dependent round trips (list, visited set, a
+/// few rows, the commit), so what pays is hops in flight. 20 M × 128 b1: 9.9 → 10.9 → 11.7 M QPS at 4 → 5 → 6 waves per SIMD
+/// (128 → 96 → 80 VGPRs); 20 M × 96 i8: 9.2 → 10.8 M QPS at 5, 9.6 M at 6 (the spills win) — profiles/r02_short_rows.log.
+#ifndef USEARCH_AMD_TINY_ROW_WAVES
+#define USEARCH_AMD_TINY_ROW_WAVES 6
+#endif
+#ifndef USEARCH_AMD_SHORT_ROW_WAVES
+#define USEARCH_AMD_SHORT_ROW_WAVES 5
+#endif
 constexpr int variant_unroll(int v) { return v == variant_u4_w4_k ? 4 : v == variant_u8_w3_k ? 8 : 12; }
 constexpr int variant_rows(int v) { return v == variant_u12x2_w2_k ? 2 : 1; }
 /// Waves per SIMD the register budget of an instantiation is cut for (512 VGPRs per SIMD lane: 128 → 4, 168 → 3, 256 → 2);
 /// from the allocations the compiler reports for the widest rows (cos, G = 8) with `top` in `epl` register rows.
-constexpr int kernel_waves(int variant, int epl, int frontier = 0) {
+constexpr int kernel_waves(int variant, int epl, int frontier = 0, int lanes = 8) {
     if (variant == variant_u12x2_w2_k)
         return 2;
+    if (variant == variant_u4_w4_k && epl == 1 && lanes <= 2)
+        return lanes == 1 ? USEARCH_AMD_TINY_ROW_WAVES : USEARCH_AMD_SHORT_ROW_WAVES;
     if (frontier) // without the heap's bookkeeping the 4-deep build fits 128 registers with any `top`
         return variant == variant_u4_w4_k ? 4 : variant == variant_u8_w3_k ? 3 : 2;
     return variant == variant_u4_w4_k ? (epl >= 8 ? 3 : 4) : variant == variant_u8_w3_k ? (epl >= 16 ? 2 : 3) : 2;
 }
 
 template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak, int frontier_ak>
-__global__ __launch_bounds__(64, kernel_waves(variant_ak, epl_ak, frontier_ak)) void search_kernel(const snapshot_view_t ix,
+__global__ __launch_bounds__(64, kernel_waves(variant_ak, epl_ak, frontier_ak, lanes_ak)) void search_kernel(const snapshot_view_t ix,
                                                                                             const search_args_t args) {
     constexpr int unroll_ak = variant_unroll(variant_ak) + 100 * (variant_rows(variant_ak) - 1); // rows ride in the hundreds
     extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];

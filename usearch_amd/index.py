@@ -18,7 +18,8 @@ from typing import Optional, Union
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIBRARY_PATH = os.path.join(HERE, "lib", "libusearch_amd.so")
+# USEARCH_AMD_LIBRARY names an experimental build of the same library (scripts/ A/B runs); the product is the in-tree one
+LIBRARY_PATH = os.environ.get("USEARCH_AMD_LIBRARY") or os.path.join(HERE, "lib", "libusearch_amd.so")
 
 # `usearch_scalar_kind_t` / `usearch_metric_kind_t` of c/usearch.h:40-62
 SCALAR_KINDS = {"f32": 1, "f64": 2, "f16": 3, "i8": 4, "b1": 5, "bf16": 6}
@@ -76,6 +77,7 @@ _library = None
 
 EXPORTED_SYMBOLS = [
     "usearch_amd_device_count", "usearch_amd_snapshot_from_buffer", "usearch_amd_snapshot_from_file",
+    "usearch_amd_snapshot_from_parts",
     "usearch_amd_snapshot_free", "usearch_amd_snapshot_size", "usearch_amd_snapshot_dimensions",
     "usearch_amd_snapshot_connectivity", "usearch_amd_snapshot_max_level", "usearch_amd_snapshot_bytes_per_vector",
     "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_scalar_kind",
@@ -107,6 +109,8 @@ def library() -> C.CDLL:
     L.usearch_amd_device_count.argtypes = [err_p]
     L.usearch_amd_snapshot_from_buffer.restype = C.c_void_p
     L.usearch_amd_snapshot_from_buffer.argtypes = [C.c_void_p, C.c_size_t, C.c_int, err_p]
+    L.usearch_amd_snapshot_from_parts.restype = C.c_void_p
+    L.usearch_amd_snapshot_from_parts.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, err_p]
     L.usearch_amd_snapshot_from_file.restype = C.c_void_p
     L.usearch_amd_snapshot_from_file.argtypes = [C.c_char_p, C.c_int, err_p]
     L.usearch_amd_snapshot_free.argtypes = [C.c_void_p, err_p]
@@ -226,11 +230,20 @@ class Index:
 
     @classmethod
     def restore(cls, source: Union[str, os.PathLike, bytes, bytearray, memoryview, np.ndarray], device: int = 0,
-                expansion_search: int = 0) -> "Index":
-        """Uploads a `.usearch` file or an in-memory image (`usearch_save` / `usearch_save_buffer` output)."""
+                expansion_search: int = 0, vectors: Optional[np.ndarray] = None) -> "Index":
+        """Uploads a `.usearch` file or an in-memory image (`usearch_save` / `usearch_save_buffer` output). `vectors`: the
+        matrix the caller kept for an image saved with `exclude_vectors` (one row per member, in slot order)."""
         L = library()
         err = C.c_char_p()
-        if isinstance(source, (str, os.PathLike)):
+        if vectors is not None:
+            image = np.ascontiguousarray(np.frombuffer(source, dtype=np.uint8)
+                                         if not isinstance(source, np.ndarray) else source, dtype=np.uint8)
+            vectors = np.asarray(vectors)
+            if vectors.ndim != 2 or vectors.strides[1] != vectors.itemsize:
+                vectors = np.ascontiguousarray(vectors)
+            handle = L.usearch_amd_snapshot_from_parts(_pointer(image), image.size, _pointer(vectors), vectors.strides[0],
+                                                       device, C.byref(err))
+        elif isinstance(source, (str, os.PathLike)):
             handle = L.usearch_amd_snapshot_from_file(os.fspath(source).encode(), device, C.byref(err))
         else:
             image = np.ascontiguousarray(np.frombuffer(source, dtype=np.uint8)
