@@ -230,6 +230,8 @@ const char* builder_t::build(metric_kind_t metric, scalar_kind_t scalar, std::si
     if (const char* e = snapshot_.allocate_for_build(metric, scalar, dimensions, 0, 0, m, config_.connectivity_base, device))
         return e;
     const char* error = extend(vectors, count, stride, vectors_on_device, keys, true);
+    release_workspace(); // a one-shot build gives its link workspace back (an inbox per member: 32 GB for 125M members);
+                         // `extend` makes a new one — and keeps it — when members are added later
     stats_.seconds_total = seconds_now() - t_begin;
     return error;
 }
