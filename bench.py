@@ -265,6 +265,8 @@ def main() -> None:
     parser.add_argument("--cpu-seconds", type=float, default=12.0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-stress-rows", action="store_true")
+    parser.add_argument("--no-host-api", action="store_true",
+                        help="skip the host-buffer and single-query legs (profiled runs: every launch of the timed kernel is a timed batch)")
     parser.add_argument("--stress-n", type=int, default=1_000_000)
     parser.add_argument("--sharded", action="store_true")
     parser.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
@@ -490,7 +492,7 @@ def main() -> None:
     # ---- the same batch through the HOST-buffer entry point (query upload + result download over PCIe included):
     #      reported for DESIGN.md, never as `value`
     host_api_qps, single_query_us = None, None
-    if rank == 0 and world == 1 and not sharded:
+    if rank == 0 and world == 1 and not sharded and not args.no_host_api:
         index.expansion_search = expansion
         index.search(queries_host, args.k, dtype=args.dtype)
         t1 = time.perf_counter()
@@ -621,6 +623,11 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "search_kernel", "kernel_ms": kernel_s * 1e3,
+                         # template arguments of the timed instantiation as rocprofv3 prints them: metric and scalar codes, lanes
+                         # per row, build, scratch mode, `top` cells per lane, frontier
+                         "kernel_instantiation": (f"search_kernel<{ord({'tanimoto': 't', 'jaccard': 't'}.get(metric, {'cos': 'c', 'ip': 'i', 'l2sq': 'e', 'hamming': 'b', 'pearson': 'p', 'haversine': 'h', 'divergence': 'd', 'sorensen': 's'}.get(metric, '?')))}, "
+                                                  f"{ {'b1': 1, 'bf16': 4, 'f64': 10, 'f32': 11, 'f16': 12, 'i8': 23}[args.dtype]}, {index.lanes_per_row}, "
+                                                  f"{stats.variant - 1}, {stats.mode - 1}, {stats.top_cells}, {stats.frontier - 1}>"),
                          "algorithmic_bytes_per_launch": step_bytes,
                          "lines_touched_bytes_per_launch": touched_bytes,
                          "lines_touched_frac": touched_bytes / kernel_s / 1e9 / HBM_PEAK_GBPS if kernel_s > 0 else None,

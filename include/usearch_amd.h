@@ -76,7 +76,8 @@ typedef struct usearch_amd_stats_t {
     uint32_t variant;        /**< kernel build of the first launch (values of usearch_amd_tuning_t::variant) */
     float tail_idle;         /**< with wave_clock: share of (waves × span) during which waves were not there — batch tail */
     float span_ms;           /**< with wave_clock: first wave start → last wave exit, device wall clock */
-    uint32_t reserved;
+    uint32_t top_cells;      /**< cells of `top` per lane in registers (1, 4, 8, 16), 0 = `top` in scratch memory; with mode,
+                                  variant and frontier this names the kernel instantiation of the first launch */
 } usearch_amd_stats_t;
 
 /** Number of visible HIP devices; 0 (and an error) when the runtime finds none. */

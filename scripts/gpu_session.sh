@@ -40,6 +40,7 @@ for step in "$@"; do
                 USEARCH_AMD_LIBRARY=$lib timeout 300 python bench.py --vectors 20000000 $shape --queries 100000 \
                   --recall-queries 1000 --no-stress-rows --no-cpu-baseline --steps 5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), 'QPS', d['config']['persistent_waves'], 'waves', d['roofline']['kernel_ms'], 'ms')"
               done; done ;;
+    exactcheck) timeout 900 python scripts/exact_check.py --vectors 1000000 20000000 40000000 100000000 --dim 96 --dtype i8 > "$OUT/exactcheck.log" 2>&1; cat "$OUT/exactcheck.log" ;;
     *) echo "unknown step $step" ;;
   esac
 done

@@ -11,24 +11,30 @@ import sys
 
 
 def mean_counter(path, name, kernel):
-    """Mean per launch over the instantiation of `kernel` with the largest launches: the index build of the same process
-    runs (smaller-expansion) instantiations of the search kernel as well, and warm-up / sweep launches of the timed
-    instantiation have the same size as the timed ones."""
+    """Mean per launch over the (instantiation, grid size) of `kernel` with the largest launches: the index build of the same
+    process runs other instantiations of the search kernel, and the timed instantiation is also launched for small batches (a
+    single query, a recall sample) — the timed batches are the ones with the biggest grid, warm-up launches of the same size
+    included."""
     groups = {}
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             if row["Counter_Name"] == name and kernel in row["Kernel_Name"]:
-                groups.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+                groups.setdefault((row["Kernel_Name"], row.get("Grid_Size", "")), []).append(float(row["Counter_Value"]))
     if not groups:
         return None, 0, None
     best = max(groups, key=lambda k: sum(groups[k]) / len(groups[k]))
     values = groups[best]
-    return sum(values) / len(values), len(values), best.split("(")[0]
+    return sum(values) / len(values), len(values), best[0].split("(")[0] + f" grid {best[1]}"
 
 
 def main():
     fetch_csv, write_csv = sys.argv[1], sys.argv[2]
     kernel = sys.argv[3] if len(sys.argv) > 3 else "search_kernel"
+    if len(sys.argv) > 4:  # the bench line names the timed instantiation exactly
+        try:
+            kernel = json.load(open(sys.argv[4]))["roofline"].get("kernel_instantiation") or kernel
+        except (OSError, ValueError, KeyError):
+            pass
     fetch_kib, fetch_n, kernel_name = mean_counter(fetch_csv, "FETCH_SIZE", kernel)
     write_kib, write_n, _ = mean_counter(write_csv, "WRITE_SIZE", kernel)
     fetch_bytes = fetch_kib * 1024 * 2 if fetch_kib is not None else None

@@ -16,7 +16,7 @@ cd /tmp
 python "$REPO/bench.py" "$@" --no-cpu-baseline --no-stress-rows --steps 5 --warmup 2 > "$OUT/pick.json" 2> "$OUT/pick.log"
 tail -4 "$OUT/pick.log"
 EF=$(python -c "import json; print(json.load(open('$OUT/pick.json'))['config']['expansion_search'])" 2>/dev/null || echo 256)
-QUICK="$* --expansion $EF --recall-queries 0 --no-cpu-baseline --no-stress-rows --steps 3 --warmup 1"
+QUICK="$* --expansion $EF --recall-queries 0 --no-cpu-baseline --no-stress-rows --no-host-api --steps 5 --warmup 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python "$REPO/bench.py" $QUICK > "$OUT/stats_bench.json" 2> "$OUT/stats.log"
 find "$OUT/stats" -name "*kernel_stats.csv" | head -1 | while read f; do cp "$f" "$OUT/kernel_stats.csv"; done
 GROUPS_LIMIT=${PROFILE_TRAFFIC_ONLY:+2}

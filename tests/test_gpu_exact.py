@@ -122,3 +122,18 @@ def test_exact_search_of_a_raw_i8_dataset_takes_the_matrix_units(monkeypatch):
     assert np.array_equal(keys, plain_keys) and util.same_float_bits(distances, plain_distances)
     brute = ((queries[:, None, :].astype(np.int32) - dataset[None, :6000, :].astype(np.int32)) ** 2).sum(-1)
     assert np.all(distances[:, 0] <= brute.min(axis=1))
+
+
+def test_tiled_exact_search_over_more_rows_than_one_launch_has_threads(monkeypatch):
+    """70M rows: a wave per row would be 4.5·10⁹ threads, past the 2³² a launch may have — the helper kernels walk rows with a
+    grid stride instead (a 100M-row index once got its ground truth from norms that were never computed)."""
+    import usearch_amd
+    rng = np.random.default_rng(11)
+    rows = 70_000_000
+    dataset = rng.integers(-120, 120, (rows, 16), dtype=np.int8)
+    queries = dataset[rng.integers(0, rows, 64)] + rng.integers(-2, 3, (64, 16)).astype(np.int8)
+    keys, distances = usearch_amd.exact_search(dataset, queries, 10, metric="l2sq")
+    monkeypatch.setenv("USEARCH_AMD_NO_TILED_EXACT", "1")
+    plain_keys, plain_distances = usearch_amd.exact_search(dataset, queries, 10, metric="l2sq")
+    assert np.array_equal(keys, plain_keys) and util.same_float_bits(distances, plain_distances)
+    assert np.all(distances >= 0) and np.all(distances[:, 0] <= 16 * 4)

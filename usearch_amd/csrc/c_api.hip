@@ -106,7 +106,7 @@ void stats_to_c(const search_stats_t& s, usearch_amd_stats_t* out) {
     out->variant = s.variant;
     out->tail_idle = s.tail_idle;
     out->span_ms = s.span_ms;
-    out->reserved = 0;
+    out->top_cells = s.top_cells;
 }
 
 void fail(usearch_amd_error_t* error, const char* message) {

@@ -235,12 +235,13 @@ void snapshot_t::release() {
 /// out[i][j] = the stored row of nbr0[i][j], one 16-byte chunk per cell (empty cells are left alone: never read).
 __global__ void inline_rows_kernel(const std::uint8_t* vectors, const std::uint32_t* nbr0, uint4* out, std::uint64_t cells,
                                    std::uint32_t row_stride) {
-    const std::uint64_t i = blockIdx.x * (std::uint64_t)blockDim.x + threadIdx.x;
-    if (i >= cells)
-        return;
-    const std::uint32_t slot = nbr0[i];
-    if (slot != none_slot_k)
-        out[i] = *reinterpret_cast<const uint4*>(vectors + (std::uint64_t)slot * row_stride);
+    // grid-stride: cells = members × M0 passes 2^32 (the thread limit of one launch) at 134M members of M0 = 32
+    for (std::uint64_t i = blockIdx.x * (std::uint64_t)blockDim.x + threadIdx.x; i < cells;
+         i += (std::uint64_t)gridDim.x * blockDim.x) {
+        const std::uint32_t slot = nbr0[i];
+        if (slot != none_slot_k)
+            out[i] = *reinterpret_cast<const uint4*>(vectors + (std::uint64_t)slot * row_stride);
+    }
 }
 
 const char* snapshot_t::finalize_layout() {
@@ -256,9 +257,7 @@ const char* snapshot_t::finalize_layout() {
     const std::uint64_t cells = view_.size * view_.m0;
     UA_HIP(hipMalloc(&d_nbr0_rows_, cells * 16));
     device_bytes_ += cells * 16;
-    const std::uint64_t blocks = (cells + 255) / 256;
-    if (blocks > 0x7FFFFFFFull)
-        return "Index is too large for the inline-row layout";
+    const std::uint64_t blocks = std::min<std::uint64_t>((cells + 255) / 256, 1u << 22);
     hipLaunchKernelGGL(inline_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream_, view_.vectors, view_.nbr0,
                        static_cast<uint4*>(d_nbr0_rows_), cells, view_.row_stride);
     UA_HIP(hipGetLastError());
@@ -700,6 +699,7 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
     call.stats = search_stats_t{};
     call.stats.frontier = frontier == frontier_top_k ? 2u : 1u;
     call.stats.variant = (std::uint32_t)variant + 1;
+    call.stats.top_cells = entries_per_lane;
 
     // diagnostic: per-phase shader-clock ticks of the search kernel, printed to stderr (USEARCH_AMD_PHASES=1)
     call.want_phases = env_size("USEARCH_AMD_PHASES", 0) != 0;

@@ -46,6 +46,7 @@ struct search_stats_t {
     float tail_idle = 0.f;               ///< with `wave_clock`: share of wave-time between the first start and the last exit
                                          ///< that waves spent gone (the drain phase of the batch), first launch
     float span_ms = 0.f;                 ///< with `wave_clock`: first start → last exit on the device's 100-MHz clock
+    std::uint32_t top_cells = 0;         ///< `top` cells per lane in registers of the first launch (0 = scratch memory)
 };
 
 /// What index construction asks of the search on top of a plain query batch (see search_args_t).

@@ -62,31 +62,31 @@ __device__ __forceinline__ typename accumulator_gt<scalar_ak>::type multiply(uin
 template <int scalar_ak>
 __global__ __launch_bounds__(256) void row_norms_kernel(const std::uint8_t* rows, std::uint64_t count, std::uint64_t stride,
                                                         std::uint32_t bytes, std::uint32_t* out) {
-    const std::uint64_t row = blockIdx.x * 4ull + threadIdx.x / 64;
+    // one wave per row, grid-stride: a launch may not exceed 2^32 threads, and 100M rows × 64 lanes would
     const std::uint32_t lane = threadIdx.x % 64;
-    if (row >= count)
-        return;
-    const std::uint8_t* p = rows + row * stride;
-    float sum = 0.f;
-    int exact = 0;
-    for (std::uint32_t b = lane * 2; b < bytes; b += 128) {
-        if constexpr (scalar_ak == scalar_i8_k) {
-            const int x = (std::int8_t)p[b], y = b + 1 < bytes ? (std::int8_t)p[b + 1] : 0;
-            exact += x * x + y * y;
-        } else {
-            const std::uint32_t bits = (std::uint32_t)p[b] | ((std::uint32_t)p[b + 1] << 8);
-            const float x = scalar_ak == scalar_bf16_k ? __builtin_bit_cast(float, bits << 16)
-                                                       : (float)__builtin_bit_cast(_Float16, (std::uint16_t)bits);
-            sum = __builtin_fmaf(x, x, sum);
+    for (std::uint64_t row = blockIdx.x * 4ull + threadIdx.x / 64; row < count; row += (std::uint64_t)gridDim.x * 4) {
+        const std::uint8_t* p = rows + row * stride;
+        float sum = 0.f;
+        int exact = 0;
+        for (std::uint32_t b = lane * 2; b < bytes; b += 128) {
+            if constexpr (scalar_ak == scalar_i8_k) {
+                const int x = (std::int8_t)p[b], y = b + 1 < bytes ? (std::int8_t)p[b + 1] : 0;
+                exact += x * x + y * y;
+            } else {
+                const std::uint32_t bits = (std::uint32_t)p[b] | ((std::uint32_t)p[b + 1] << 8);
+                const float x = scalar_ak == scalar_bf16_k ? __builtin_bit_cast(float, bits << 16)
+                                                           : (float)__builtin_bit_cast(_Float16, (std::uint16_t)bits);
+                sum = __builtin_fmaf(x, x, sum);
+            }
         }
-    }
 #pragma unroll
-    for (int offset = 32; offset >= 1; offset >>= 1) {
-        sum += __shfl_xor(sum, offset, 64);
-        exact += __shfl_xor(exact, offset, 64);
+        for (int offset = 32; offset >= 1; offset >>= 1) {
+            sum += __shfl_xor(sum, offset, 64);
+            exact += __shfl_xor(exact, offset, 64);
+        }
+        if (lane == 0)
+            out[row] = scalar_ak == scalar_i8_k ? (std::uint32_t)exact : __builtin_bit_cast(std::uint32_t, sum);
     }
-    if (lane == 0)
-        out[row] = scalar_ak == scalar_i8_k ? (std::uint32_t)exact : __builtin_bit_cast(std::uint32_t, sum);
 }
 
 /// (distance, slot) `a` goes before `b` in what `search_exact_` returns: closer first, the later slot first among equals.
@@ -328,8 +328,8 @@ hipError_t launch_norms(const std::uint8_t* rows, std::uint64_t count, std::uint
                         std::uint32_t* out, hipStream_t stream) {
     if (!count)
         return hipSuccess;
-    hipLaunchKernelGGL(row_norms_kernel<scalar_ak>, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, stream, rows, count,
-                       stride, bytes, out);
+    hipLaunchKernelGGL(row_norms_kernel<scalar_ak>, dim3((unsigned)std::min<std::uint64_t>((count + 3) / 4, 1u << 20)), dim3(256), 0,
+                       stream, rows, count, stride, bytes, out);
     return hipGetLastError();
 }
 

@@ -51,7 +51,7 @@ class Stats(C.Structure):
     _fields_ = [("passes", C.c_uint32), ("retried_lds", C.c_uint32), ("retried_global", C.c_uint32),
                 ("kernel_ms", C.c_float), ("mode", C.c_uint32), ("grid", C.c_uint32), ("lds_bytes", C.c_uint32),
                 ("frontier", C.c_uint32), ("variant", C.c_uint32), ("tail_idle", C.c_float), ("span_ms", C.c_float),
-                ("reserved", C.c_uint32)]
+                ("top_cells", C.c_uint32)]
 
 
 class BuildConfig(C.Structure):
