@@ -487,7 +487,11 @@ def main() -> None:
     # lines touched: what the same accesses cost in whole 128-byte lines (short rows: a 96-byte row is one line, a 16-byte
     # row still one) — the bound that applies when rows are shorter than a line
     row_lines = -(-index.row_stride // 128) if index.row_stride >= 128 else 1
-    touched_bytes = float(np.sum(computed * row_lines * 128 + visited * 128 * -(-4 * m0 // 128) + 128 + row_lines * 128))
+    list_bytes = 128 * -(-4 * m0 // 128)
+    if index.inline_rows:  # the neighbours' rows lie next to the list: a hop is one contiguous block, whatever is fresh
+        touched_bytes = float(np.sum(visited * (list_bytes + 128 * -(-m0 * 16 // 128)) + 128 + row_lines * 128))
+    else:
+        touched_bytes = float(np.sum(computed * row_lines * 128 + visited * list_bytes + 128 + row_lines * 128))
 
     # ---- the same batch through the HOST-buffer entry point (query upload + result download over PCIe included):
     #      reported for DESIGN.md, never as `value`
@@ -616,6 +620,7 @@ def main() -> None:
                        "scratch_mode": {1: "lds", 2: "global-hash", 3: "global"}.get(stats.mode, "?"),
                        "frontier": {1: "heap", 2: "in-top"}.get(stats.frontier, "?"), "kernel_build": stats.variant,
                        "persistent_waves": stats.grid, "lds_bytes_per_wave": stats.lds_bytes,
+                       "rows_inline_with_lists": bool(index.inline_rows),
                        "batch_tail_idle": float(np.mean(tails)) if args.wave_clock else None,
                        "host_buffer_api_qps_pcie_inclusive": host_api_qps,
                        "single_query_latency_us_host_api": single_query_us,

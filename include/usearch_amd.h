@@ -117,6 +117,9 @@ USEARCH_AMD_EXPORT int usearch_amd_snapshot_scalar_kind(usearch_amd_snapshot_t s
 USEARCH_AMD_EXPORT int usearch_amd_snapshot_metric_kind(usearch_amd_snapshot_t snapshot);
 /** Lanes that share one stored row (G): fixes the floating-point summation layout, see DESIGN.md. */
 USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_lanes_per_row(usearch_amd_snapshot_t snapshot);
+/** 1 when the stored rows of every member's level-0 neighbours are kept next to its list (rows of ≤ 16 bytes: one contiguous
+ *  read per hop instead of a list line plus scattered rows), 0 otherwise. */
+USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_inline_rows(usearch_amd_snapshot_t snapshot);
 
 /**
  *  Batched search with HOST buffers — `usearch_search` (c/usearch.h:371-374) for `queries_count` queries at once.

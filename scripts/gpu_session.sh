@@ -41,6 +41,7 @@ for step in "$@"; do
                   --recall-queries 1000 --no-stress-rows --no-cpu-baseline --steps 5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), 'QPS', d['config']['persistent_waves'], 'waves', d['roofline']['kernel_ms'], 'ms')"
               done; done ;;
     exactcheck) timeout 900 python scripts/exact_check.py --vectors 1000000 20000000 40000000 100000000 --dim 96 --dtype i8 > "$OUT/exactcheck.log" 2>&1; cat "$OUT/exactcheck.log" ;;
+    exact10m) timeout 900 python scripts/exact_check.py --vectors 10000000 --dim 768 --dtype f16 --queries 1000 > "$OUT/exact10m.log" 2>&1; cat "$OUT/exact10m.log" ;;
     *) echo "unknown step $step" ;;
   esac
 done

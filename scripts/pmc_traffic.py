@@ -10,18 +10,30 @@ import json
 import sys
 
 
-def mean_counter(path, name, kernel):
-    """Mean per launch over the (instantiation, grid size) of `kernel` with the largest launches: the index build of the same
-    process runs other instantiations of the search kernel, and the timed instantiation is also launched for small batches (a
-    single query, a recall sample) — the timed batches are the ones with the biggest grid, warm-up launches of the same size
-    included."""
-    groups = {}
+def mean_counter(path, name, kernel, last=0):
+    """Mean per launch of `name` over the TIMED launches of `kernel`. With `last` (= warm-up + timed steps of the profiled
+    bench run, which does nothing else after the index build: `--recall-queries 0 --no-host-api`) those are the last `last`
+    dispatches of that instantiation — the index build of the same process may run the very same instantiation at the very same
+    grid size (100M x 96 i8: expansion 80 and the builder's 128 share one build), so neither the name nor the grid tells them
+    apart; dispatch order does. Without `last`: the (instantiation, grid size) group with the largest mean."""
+    rows = []
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             if row["Counter_Name"] == name and kernel in row["Kernel_Name"]:
-                groups.setdefault((row["Kernel_Name"], row.get("Grid_Size", "")), []).append(float(row["Counter_Value"]))
-    if not groups:
+                rows.append(row)
+    if not rows:
         return None, 0, None
+    if last:
+        rows.sort(key=lambda row: int(row["Dispatch_Id"]))
+        chosen = rows[-last:]
+        values = [float(row["Counter_Value"]) for row in chosen]
+        milliseconds = [(int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6 for row in chosen]
+        label = (chosen[-1]["Kernel_Name"].split("(")[0] + f", last {len(chosen)} dispatches, grid {chosen[-1].get('Grid_Size', '')}, "
+                 f"{sum(milliseconds) / len(milliseconds):.3f} ms each under the counter pass")
+        return sum(values) / len(values), len(values), label
+    groups = {}
+    for row in rows:
+        groups.setdefault((row["Kernel_Name"], row.get("Grid_Size", "")), []).append(float(row["Counter_Value"]))
     best = max(groups, key=lambda k: sum(groups[k]) / len(groups[k]))
     values = groups[best]
     return sum(values) / len(values), len(values), best[0].split("(")[0] + f" grid {best[1]}"
@@ -30,13 +42,16 @@ def mean_counter(path, name, kernel):
 def main():
     fetch_csv, write_csv = sys.argv[1], sys.argv[2]
     kernel = sys.argv[3] if len(sys.argv) > 3 else "search_kernel"
-    if len(sys.argv) > 4:  # the bench line names the timed instantiation exactly
+    last = 0
+    if len(sys.argv) > 4:  # the bench line names the timed instantiation exactly, and how many launches of it were timed
         try:
-            kernel = json.load(open(sys.argv[4]))["roofline"].get("kernel_instantiation") or kernel
+            line = json.load(open(sys.argv[4]))
+            kernel = line["roofline"].get("kernel_instantiation") or kernel
+            last = int(line["steps"]) + int(line["warmup"])
         except (OSError, ValueError, KeyError):
             pass
-    fetch_kib, fetch_n, kernel_name = mean_counter(fetch_csv, "FETCH_SIZE", kernel)
-    write_kib, write_n, _ = mean_counter(write_csv, "WRITE_SIZE", kernel)
+    fetch_kib, fetch_n, kernel_name = mean_counter(fetch_csv, "FETCH_SIZE", kernel, last)
+    write_kib, write_n, _ = mean_counter(write_csv, "WRITE_SIZE", kernel, last)
     fetch_bytes = fetch_kib * 1024 * 2 if fetch_kib is not None else None
     write_bytes = write_kib * 1024 if write_kib is not None else None
     total = (fetch_bytes or 0) + (write_bytes or 0) if fetch_bytes is not None else None

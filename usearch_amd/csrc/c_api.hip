@@ -357,6 +357,7 @@ size_t usearch_amd_snapshot_device_bytes(usearch_amd_snapshot_t s) { return as_s
 int usearch_amd_snapshot_scalar_kind(usearch_amd_snapshot_t s) { return scalar_to_c(as_snapshot(s)->scalar()); }
 int usearch_amd_snapshot_metric_kind(usearch_amd_snapshot_t s) { return metric_to_c(as_snapshot(s)->metric()); }
 size_t usearch_amd_snapshot_lanes_per_row(usearch_amd_snapshot_t s) { return as_snapshot(s)->lanes_per_row(); }
+size_t usearch_amd_snapshot_inline_rows(usearch_amd_snapshot_t s) { return as_snapshot(s)->view().nbr0_rows ? 1 : 0; }
 
 void usearch_amd_search_many(usearch_amd_snapshot_t snapshot, void const* queries, int query_kind,
                              size_t queries_count, size_t queries_stride, size_t wanted, size_t expansion,

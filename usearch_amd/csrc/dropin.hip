@@ -499,14 +499,16 @@ void usearch_save(usearch_index_t handle, char const* path, usearch_error_t* err
 
 void usearch_load_buffer(usearch_index_t handle, void const* buffer, size_t length, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
-    index.drop_device();
-    index.drop_image();
-    index.image_owned.assign(static_cast<const std::uint8_t*>(buffer), static_cast<const std::uint8_t*>(buffer) + length);
-    if (const char* e = index.open_image(index.image_owned.data(), length)) {
+    guarded(error, [&] { // the copy of a large file may not fit: an error string, not an exception across the C ABI
+        unique_lock_t lock(index.mutex);
+        index.drop_device();
         index.drop_image();
-        fail(error, e);
-    }
+        index.image_owned.assign(static_cast<const std::uint8_t*>(buffer), static_cast<const std::uint8_t*>(buffer) + length);
+        if (const char* e = index.open_image(index.image_owned.data(), length)) {
+            index.drop_image();
+            fail(error, e);
+        }
+    });
 }
 
 void usearch_view_buffer(usearch_index_t handle, void const* buffer, size_t length, usearch_error_t* error) {

@@ -81,7 +81,8 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_snapshot_free", "usearch_amd_snapshot_size", "usearch_amd_snapshot_dimensions",
     "usearch_amd_snapshot_connectivity", "usearch_amd_snapshot_max_level", "usearch_amd_snapshot_bytes_per_vector",
     "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_scalar_kind",
-    "usearch_amd_snapshot_metric_kind", "usearch_amd_snapshot_lanes_per_row", "usearch_amd_search_many",
+    "usearch_amd_snapshot_metric_kind", "usearch_amd_snapshot_lanes_per_row", "usearch_amd_snapshot_inline_rows",
+    "usearch_amd_search_many",
     "usearch_amd_search_many_device", "usearch_amd_last_peaks", "usearch_amd_distances",
     "usearch_amd_last_distances_ms", "usearch_amd_merge_many", "usearch_amd_merge_many_device",
     "usearch_amd_exact_search_many", "usearch_amd_exact_search_many_tiled", "usearch_amd_exact_search_dataset",
@@ -115,7 +116,7 @@ def library() -> C.CDLL:
     L.usearch_amd_snapshot_from_file.argtypes = [C.c_char_p, C.c_int, err_p]
     L.usearch_amd_snapshot_free.argtypes = [C.c_void_p, err_p]
     for name in ("size", "dimensions", "connectivity", "max_level", "bytes_per_vector", "row_stride", "device_bytes",
-                 "lanes_per_row"):
+                 "lanes_per_row", "inline_rows"):
         f = getattr(L, f"usearch_amd_snapshot_{name}")
         f.restype = C.c_size_t
         f.argtypes = [C.c_void_p]
@@ -311,6 +312,11 @@ class Index:
     @property
     def lanes_per_row(self) -> int:
         return library().usearch_amd_snapshot_lanes_per_row(self._handle)
+
+    @property
+    def inline_rows(self) -> bool:
+        """Rows of ≤ 16 bytes are stored next to the neighbour lists (one contiguous read per hop)."""
+        return bool(library().usearch_amd_snapshot_inline_rows(self._handle))
 
     @property
     def hardware_acceleration(self) -> str:
