@@ -573,7 +573,9 @@ def main() -> None:
         sources = source_hash()
         traffic, traffic_source = None, None
         candidates = [args.traffic_json] if args.traffic_json else []
-        candidates += [os.path.join(ROOT, "profiles", d, "traffic.json") for d in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True)]
+        for directory, _, files in sorted(os.walk(os.path.join(ROOT, "profiles")), reverse=True):
+            if "traffic.json" in files:
+                candidates.append(os.path.join(directory, "traffic.json"))
         for candidate in candidates:
             try:
                 recorded = json.load(open(candidate))

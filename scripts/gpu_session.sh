@@ -42,6 +42,9 @@ for step in "$@"; do
               done; done ;;
     exactcheck) timeout 900 python scripts/exact_check.py --vectors 1000000 20000000 40000000 100000000 --dim 96 --dtype i8 > "$OUT/exactcheck.log" 2>&1; cat "$OUT/exactcheck.log" ;;
     exact10m) timeout 900 python scripts/exact_check.py --vectors 10000000 --dim 768 --dtype f16 --queries 1000 > "$OUT/exact10m.log" 2>&1; cat "$OUT/exact10m.log" ;;
+    c2)       timeout 600 python bench.py --vectors 1000000 --dim 768 --dtype f32 --steps 10 --warmup 2 > "$OUT/c2.json" 2> "$OUT/c2.log"; tail -6 "$OUT/c2.log"; cat "$OUT/c2.json" ;;
+    c5sharded) timeout 900 python bench.py --sharded --vectors 125000000 --dim 128 --dtype b1 --queries 100000 --steps 10 --warmup 2 \
+                > "$OUT/c5sharded.json" 2> "$OUT/c5sharded.log"; tail -6 "$OUT/c5sharded.log"; cat "$OUT/c5sharded.json" ;;
     *) echo "unknown step $step" ;;
   esac
 done
