@@ -45,6 +45,12 @@ for step in "$@"; do
     c2)       timeout 600 python bench.py --vectors 1000000 --dim 768 --dtype f32 --steps 10 --warmup 2 > "$OUT/c2.json" 2> "$OUT/c2.log"; tail -6 "$OUT/c2.log"; cat "$OUT/c2.json" ;;
     c5sharded) timeout 900 python bench.py --sharded --vectors 125000000 --dim 128 --dtype b1 --queries 100000 --steps 10 --warmup 2 \
                 > "$OUT/c5sharded.json" 2> "$OUT/c5sharded.log"; tail -6 "$OUT/c5sharded.log"; cat "$OUT/c5sharded.json" ;;
+    tailhist) USEARCH_AMD_WAVE_CLOCK=2 timeout 600 python scripts/sweep.py --n 10000000 --ef 608 --queries 10000 --modes 2 --waves 0 --variants 4 1 \
+                --frontiers 2 --steps 2 > "$OUT/tailhist.log" 2>&1; cat "$OUT/tailhist.log" ;;
+    visits)   timeout 600 python scripts/sweep.py --n 20000000 --dim 128 --dtype b1 --ef 64 --queries 100000 --modes 2 1 --waves 0 --steps 3 \
+                --env "" USEARCH_AMD_HASH_CAP=4096 USEARCH_AMD_HASH_CAP=2048 > "$OUT/visits_b1.log" 2>&1; cat "$OUT/visits_b1.log"
+              timeout 600 python scripts/sweep.py --n 20000000 --dim 96 --dtype i8 --ef 80 --queries 100000 --modes 2 1 --waves 0 --steps 3 \
+                --env "" USEARCH_AMD_HASH_CAP=4096 > "$OUT/visits_i8.log" 2>&1; cat "$OUT/visits_i8.log" ;;
     *) echo "unknown step $step" ;;
   esac
 done
