@@ -51,6 +51,16 @@ for step in "$@"; do
                 --env "" USEARCH_AMD_HASH_CAP=4096 USEARCH_AMD_HASH_CAP=2048 > "$OUT/visits_b1.log" 2>&1; cat "$OUT/visits_b1.log"
               timeout 600 python scripts/sweep.py --n 20000000 --dim 96 --dtype i8 --ef 80 --queries 100000 --modes 2 1 --waves 0 --steps 3 \
                 --env "" USEARCH_AMD_HASH_CAP=4096 > "$OUT/visits_i8.log" 2>&1; cat "$OUT/visits_i8.log" ;;
+    phases)   export USEARCH_AMD_LIBRARY=$REPO/usearch_amd/lib_phases/libusearch_amd.so USEARCH_AMD_PHASES=1
+              timeout 600 python scripts/sweep.py --n 20000000 --dim 128 --dtype b1 --ef 64 --queries 100000 --modes 2 1 --waves 0 --steps 1 > "$OUT/phases_b1.log" 2>&1
+              timeout 600 python scripts/sweep.py --n 20000000 --dim 96 --dtype i8 --ef 80 --queries 100000 --modes 2 --waves 0 --steps 1 > "$OUT/phases_i8.log" 2>&1
+              timeout 600 python scripts/sweep.py --n 10000000 --ef 608 --queries 10000 --modes 2 --waves 0 --variants 4 --frontiers 2 1 --steps 1 > "$OUT/phases_f16.log" 2>&1
+              unset USEARCH_AMD_LIBRARY USEARCH_AMD_PHASES
+              grep -h "phases ef=64 grid=6144\|phases ef=64 grid=1024\|phases ef=80 grid=4096\|phases ef=608 grid=2048\|^ef=" "$OUT"/phases_*.log | tail -30 ;;
+    hashcap)  timeout 600 python scripts/sweep.py --n 20000000 --dim 128 --dtype b1 --ef 64 --queries 100000 --modes 2 --waves 0 --steps 3 \
+                --env "" USEARCH_AMD_HASH_CAP=16384 USEARCH_AMD_HASH_CAP=32768 USEARCH_AMD_HASH_CAP=65536 > "$OUT/hashcap_b1.log" 2>&1; grep -v "wave exits\|amdgpu.ids" "$OUT/hashcap_b1.log"
+              timeout 600 python scripts/sweep.py --n 20000000 --dim 96 --dtype i8 --ef 80 --queries 100000 --modes 2 --waves 0 --steps 3 \
+                --env "" USEARCH_AMD_HASH_CAP=16384 USEARCH_AMD_HASH_CAP=32768 > "$OUT/hashcap_i8.log" 2>&1; grep -v "wave exits\|amdgpu.ids" "$OUT/hashcap_i8.log" ;;
     *) echo "unknown step $step" ;;
   esac
 done
