@@ -265,6 +265,7 @@ def main() -> None:
     parser.add_argument("--cpu-seconds", type=float, default=12.0)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-stress-rows", action="store_true")
+    parser.add_argument("--no-load-timing", action="store_true", help="skip timing the load of the serialized image")
     parser.add_argument("--no-host-api", action="store_true",
                         help="skip the host-buffer and single-query legs (profiled runs: every launch of the timed kernel is a timed batch)")
     parser.add_argument("--stress-n", type=int, default=1_000_000)
@@ -408,9 +409,11 @@ def main() -> None:
                 + (" (recall counted by distance: ties)" if by_distance else ""))
     sweep = [args.expansion] if args.expansion else [64, 96, 128, 192, 256, 320, 384, 448, 512, 576, 640, 704, 768, 896, 1024]
 
+    sweep_passes = {}
+
     def recall_at(ef: int):
         """Every rank runs the step (shards: it is a collective); rank 0 scores it."""
-        search_step(ef, False)
+        sweep_passes[ef] = int(search_step(ef, False).passes)  # 1 = every traversal fit the default scratch
         if rank != 0 or not sample:
             return None, None
         found = keys_dev[:sample].cpu().numpy().astype(np.uint64)
@@ -556,7 +559,28 @@ def main() -> None:
                          f"OpenMP static,32 loop of cpp/bench.cpp:352-377; serial (auto-vectorised) metrics, SimSIMD "
                          f"unavailable offline; {cpu_seconds:.1f}s; label agreement with the GPU {agree:.4f}; one query at a "
                          f"time on one core: {reference_single_us:.0f} us"}
-        del ref_index, image
+        # ---- loading the very same serialized image: the device flattener (upload of levels, tapes and vectors + prefix scans +
+        #      scatter kernel) next to the reference's `usearch_load_buffer` (index_dense.hpp:1102-1227)
+        load_seconds = None
+        if not args.no_load_timing:
+            del ref_index
+            t1 = time.perf_counter()
+            restored = usearch_amd.Index.restore(image, device=local_rank)
+            torch.cuda.synchronize()
+            ours = time.perf_counter() - t1
+            assert len(restored) == args.n
+            del restored
+            torch.cuda.empty_cache()
+            t1 = time.perf_counter()
+            loaded = refbind.RefIndex.from_buffer(image, view=False, dtype=args.dtype)
+            theirs = time.perf_counter() - t1
+            del loaded
+            load_seconds = {"image_bytes": int(image.nbytes), "device_flattener": round(ours, 2), "reference_load_buffer": round(theirs, 2)}
+            log(f"[bench] loading the {image.nbytes / 1e9:.1f} GB image: {ours:.1f}s into HBM (device flattener), {theirs:.1f}s for the "
+                f"reference's usearch_load_buffer")
+            ref_index = None
+        del image
+        cpu["load_seconds"] = load_seconds
 
     stress = None
     if rank == 0 and world == 1 and not sharded and not args.no_stress_rows:
@@ -619,6 +643,7 @@ def main() -> None:
                                      "exchanges_per_step": int(sharded_searcher.last_step.exchanges)} if sharded else None),
                        "index_builder": args.builder, "index_build_seconds": round(build_seconds, 1),
                        "index_build": build_stats, "kernel_passes": passes,
+                       "kernel_passes_by_expansion": {str(ef): n for ef, n in sorted(sweep_passes.items())},
                        "scratch_mode": {1: "lds", 2: "global-hash", 3: "global"}.get(stats.mode, "?"),
                        "frontier": {1: "heap", 2: "in-top"}.get(stats.frontier, "?"), "kernel_build": stats.variant,
                        "persistent_waves": stats.grid, "lds_bytes_per_wave": stats.lds_bytes,

@@ -61,6 +61,7 @@ for step in "$@"; do
                 --env "" USEARCH_AMD_HASH_CAP=16384 USEARCH_AMD_HASH_CAP=32768 USEARCH_AMD_HASH_CAP=65536 > "$OUT/hashcap_b1.log" 2>&1; grep -v "wave exits\|amdgpu.ids" "$OUT/hashcap_b1.log"
               timeout 600 python scripts/sweep.py --n 20000000 --dim 96 --dtype i8 --ef 80 --queries 100000 --modes 2 --waves 0 --steps 3 \
                 --env "" USEARCH_AMD_HASH_CAP=16384 USEARCH_AMD_HASH_CAP=32768 > "$OUT/hashcap_i8.log" 2>&1; grep -v "wave exits\|amdgpu.ids" "$OUT/hashcap_i8.log" ;;
+    c4)       timeout 900 python bench.py --vectors 100000000 --dim 96 --dtype i8 --queries 100000 --steps 10 --warmup 2 > "$OUT/c4.json" 2> "$OUT/c4.log"; grep -v "ef=" "$OUT/c4.log" | tail -8; cat "$OUT/c4.json" ;;
     *) echo "unknown step $step" ;;
   esac
 done
