@@ -72,6 +72,20 @@ def test_corrupt_images_are_rejected():
     cases["no magic"] = broken
     from tests import util
     cases["saved without vectors"] = util.without_vectors(image)  # index_dense.hpp:1004: nothing to search in there
+    # the variable-length part: levels and node tapes are validated when the image is opened (a later key lookup or `get`
+    # walks the tapes without looking back)
+    head = 8 + int(rows) * int(cols) + 64
+    size, max_level = (int(v) for v in np.frombuffer(image[head:head + 40].tobytes(), dtype=np.uint64)[[0, 3]])
+    levels_at = head + 40
+    negative = image.copy()
+    negative[levels_at:levels_at + 2] = np.frombuffer(np.int16(-3).tobytes(), dtype=np.uint8)
+    cases["negative level"] = negative
+    taller = image.copy()
+    taller[levels_at + 2:levels_at + 4] = np.frombuffer(np.int16(max_level + 5).tobytes(), dtype=np.uint8)
+    cases["level above the index's"] = taller
+    cases["last tape cut"] = image[: len(image) - 7]
+    cases["tapes missing"] = image[: levels_at + 2 * size + 5]
+    expected = {"negative level": b"nodes", "level above the index's": b"nodes", "last tape cut": b"nodes", "tapes missing": b"nodes"}
     for name, data in cases.items():
         data = np.ascontiguousarray(data)
         err = C.c_char_p()
@@ -79,6 +93,8 @@ def test_corrupt_images_are_rejected():
         assert not handle and err.value, name
         if name == "saved without vectors":
             assert b"exclude_vectors" in err.value
+        if name in expected:  # the reference's wording: "Failed to pull nodes from the stream"
+            assert expected[name] in err.value, (name, err.value)
 
 
 REFERENCE_C_ABI = [  # the 38 entry points of /root/reference/c/usearch.h:116-481 (verified with `nm -D`)
