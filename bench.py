@@ -294,9 +294,18 @@ def main() -> None:
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    # BENCH_REHEARSAL=1: every rank on cuda:0 with gloo collectives — the N > 1 control flow (decisions broadcast from rank 0,
+    # barriers, the max over ranks, the sharded step's exchange) on a box with ONE GPU. RCCL refuses two ranks on one device, so
+    # this is a rehearsal of the launcher path, never a measurement.
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -359,7 +368,8 @@ def main() -> None:
     sharded_searcher, exchange_ms = None, []
     if sharded:
         from usearch_amd.sharded import gpu_searcher
-        sharded_searcher = gpu_searcher(index, rank, world, local_rank, stream=stream.cuda_stream, prefer=args.transport)
+        sharded_searcher = gpu_searcher(index, rank, world, local_rank, stream=stream.cuda_stream,
+                                        prefer="gloo" if rehearsal else args.transport)
         if rank == 0:
             log(f"[bench] sharded step over the '{sharded_searcher.communicator.kind}' transport, {world} shard(s)")
 
@@ -625,7 +635,8 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
-            "data": "synthetic (seeded rank-32 latent + 0.05 noise, out-of-sample queries)",
+            "data": "synthetic (seeded rank-32 latent + 0.05 noise, out-of-sample queries)"
+                    + (" — REHEARSAL: all ranks share one GPU, not a measurement" if rehearsal else ""),
             "config": {"workload": workload,
                        "vectors": args.n * shards, "dimensions": args.dim, "expansion_search": expansion,
                        "recall_at_k": recall, "recall_queries": sample, "recall_ci": [recall - recall_half, recall + recall_half]

@@ -62,6 +62,10 @@ for step in "$@"; do
               timeout 600 python scripts/sweep.py --n 20000000 --dim 96 --dtype i8 --ef 80 --queries 100000 --modes 2 --waves 0 --steps 3 \
                 --env "" USEARCH_AMD_HASH_CAP=16384 USEARCH_AMD_HASH_CAP=32768 > "$OUT/hashcap_i8.log" 2>&1; grep -v "wave exits\|amdgpu.ids" "$OUT/hashcap_i8.log" ;;
     c4)       timeout 900 python bench.py --vectors 100000000 --dim 96 --dtype i8 --queries 100000 --steps 10 --warmup 2 > "$OUT/c4.json" 2> "$OUT/c4.log"; grep -v "ef=" "$OUT/c4.log" | tail -8; cat "$OUT/c4.json" ;;
+    rehearse) BENCH_REHEARSAL=1 timeout 600 python bench.py --gpus 2 --vectors 500000 --dim 768 --dtype f16 --queries 2000 --steps 3 --warmup 1 \
+                > "$OUT/rehearse_replicas.json" 2> "$OUT/rehearse_replicas.log"; tail -3 "$OUT/rehearse_replicas.log"; cat "$OUT/rehearse_replicas.json"
+              BENCH_REHEARSAL=1 timeout 600 python bench.py --gpus 2 --sharded --vectors 2000000 --dim 128 --dtype b1 --queries 20000 --steps 3 --warmup 1 \
+                > "$OUT/rehearse_sharded.json" 2> "$OUT/rehearse_sharded.log"; tail -3 "$OUT/rehearse_sharded.log"; cat "$OUT/rehearse_sharded.json" ;;
     *) echo "unknown step $step" ;;
   esac
 done

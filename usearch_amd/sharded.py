@@ -308,6 +308,16 @@ def gpu_searcher(index, rank: int, world: int, device: int, stream: int = 0, gro
         return box[0]
 
     communicator = None
+    if prefer == "gloo":  # host-side collectives of the launcher's (gloo) group: ranks may share a device — rehearsals, tests
+        import torch
+
+        def all_gather(send: np.ndarray, receive: np.ndarray):
+            dist.all_gather_into_tensor(torch.from_numpy(receive), torch.from_numpy(send), group=group)
+
+        def broadcast(buffer: np.ndarray, root: int):
+            dist.broadcast(torch.from_numpy(buffer), src=root, group=group)
+
+        return ShardedSearcher(index, Communicator.over_host_collectives(rank, world, device, all_gather, broadcast), stream)
     if prefer == "rccl":
         try:
             communicator = Communicator.rccl(rank, world, device, share_id)
