@@ -677,6 +677,13 @@ def main() -> None:
                          "distances_per_query": float(np.mean(computed)), "hops_per_query": float(np.mean(visited))},
             "cpu_baseline": cpu,
         }
+        # anything native libraries still hold in C stdio buffers (RCCL prints a version banner through printf) goes out BEFORE
+        # the line: the JSON is the last thing this process writes to stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except (OSError, AttributeError):
+            pass
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
