@@ -150,6 +150,16 @@ def relaunch_with_ranks(gpus: int) -> None:
     os.execv(sys.executable, command)
 
 
+def flush_native_stdio() -> None:
+    """What native libraries hold in C stdio buffers (RCCL prints a version banner through printf when a communicator is made)
+    goes out NOW — on every rank, long before rank 0 prints the one JSON line — instead of at process exit, after it."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except (OSError, AttributeError):
+        pass
+
+
 def recall_per_query(found: np.ndarray, truth: np.ndarray, k: int) -> np.ndarray:
     return np.array([len(np.intersect1d(found[i], truth[i])) / k for i in range(len(found))], dtype=np.float64)
 
@@ -468,6 +478,7 @@ def main() -> None:
     expansion = expansion or 64
 
     # ---- warmup, then EXACTLY `steps` timed steps between barriers
+    flush_native_stdio()
     for _ in range(args.warmup):
         search_step(expansion, False)
     torch.cuda.synchronize()
@@ -677,13 +688,7 @@ def main() -> None:
                          "distances_per_query": float(np.mean(computed)), "hops_per_query": float(np.mean(visited))},
             "cpu_baseline": cpu,
         }
-        # anything native libraries still hold in C stdio buffers (RCCL prints a version banner through printf) goes out BEFORE
-        # the line: the JSON is the last thing this process writes to stdout
-        import ctypes
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except (OSError, AttributeError):
-            pass
+        flush_native_stdio()  # the JSON is the last thing this process writes to stdout
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
