@@ -40,6 +40,18 @@ for step in "$@"; do
                 USEARCH_AMD_LIBRARY=$lib timeout 300 python bench.py --vectors 20000000 $shape --queries 100000 \
                   --recall-queries 1000 --no-stress-rows --no-cpu-baseline --steps 5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), 'QPS', d['config']['persistent_waves'], 'waves', d['roofline']['kernel_ms'], 'ms')"
               done; done ;;
+    order)    # files that load the engine / the drop-in BEFORE anything imports torch: one HIP runtime either way (index.py)
+              timeout 600 python -m pytest tests/test_gpu_search_parity.py tests/test_gpu_dropin.py tests/test_gpu_fullsize.py tests/test_gpu_build.py \
+                -m gpu -q --maxfail=5 > "$OUT/order_pytest.log" 2>&1; tail -4 "$OUT/order_pytest.log" ;;
+    bucketsab) L=$REPO/usearch_amd/lib_buckets/libusearch_amd.so
+              USEARCH_AMD_LIBRARY=$L timeout 600 python -m pytest tests/test_gpu_search_parity.py tests/test_gpu_fullsize.py tests/test_gpu_build.py \
+                tests/test_gpu_golden.py -m gpu -q --maxfail=5 > "$OUT/buckets_pytest.log" 2>&1; tail -6 "$OUT/buckets_pytest.log"
+              for shape in "--vectors 20000000 --dim 128 --dtype b1 --expansion 64 --queries 100000" "--vectors 20000000 --dim 96 --dtype i8 --expansion 80 --queries 100000" \
+                           "--vectors 10000000 --expansion 608"; do for lib in "" "$L"; do
+                echo "--- library ${lib:-product} $shape"
+                USEARCH_AMD_LIBRARY=$lib timeout 400 python bench.py $shape --recall-queries 1000 --no-stress-rows --no-cpu-baseline --no-host-api --steps 5 2>/dev/null \
+                  | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), 'QPS', d['roofline']['kernel_ms'], 'ms', 'recall', d['config'].get('recall_at_k'))"
+              done; done 2>&1 | tee "$OUT/buckets_ab.log" ;;
     exactcheck) timeout 900 python scripts/exact_check.py --vectors 1000000 20000000 40000000 100000000 --dim 96 --dtype i8 > "$OUT/exactcheck.log" 2>&1; cat "$OUT/exactcheck.log" ;;
     exact10m) timeout 900 python scripts/exact_check.py --vectors 10000000 --dim 768 --dtype f16 --queries 1000 > "$OUT/exact10m.log" 2>&1; cat "$OUT/exact10m.log" ;;
     c2)       timeout 600 python bench.py --vectors 1000000 --dim 768 --dtype f32 --steps 10 --warmup 2 > "$OUT/c2.json" 2> "$OUT/c2.log"; tail -6 "$OUT/c2.log"; cat "$OUT/c2.json" ;;

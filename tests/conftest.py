@@ -12,6 +12,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
+    # some tests open the drop-in library or the HIP runtime directly and others import torch later in the same process:
+    # whichever comes first, there must be one HIP runtime (usearch_amd/index.py `_share_hip_runtime`)
+    from usearch_amd.index import _share_hip_runtime
+    _share_hip_runtime()
 
 
 @pytest.fixture(scope="session")

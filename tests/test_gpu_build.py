@@ -148,7 +148,7 @@ def test_build_is_reproducible_and_takes_device_vectors():
     second = usearch_amd.build(vectors, "cos", "f16", max_batch=256, seed=99).save_buffer()
     assert np.array_equal(first, second)
     # rows already in HBM, with a pitch: plain HIP runtime calls (the runtime the engine itself has loaded)
-    hip = ctypes.CDLL("libamdhip64.so")
+    hip = ctypes.CDLL(util.mapped_hip_runtime())
     pitch = 208
     padded = np.zeros((len(vectors), pitch), dtype=np.uint8)
     padded[:, :192] = vectors.view(np.uint8).reshape(len(vectors), -1)

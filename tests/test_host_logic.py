@@ -124,3 +124,53 @@ def test_drop_in_library_exports_the_reference_c_abi():
         assert theirs == sorted(f"usearch_{name}" for name in REFERENCE_C_ABI)
     library.usearch_version.restype = C.c_char_p
     assert library.usearch_version() == b"2.21.0"
+
+
+def test_an_allocation_failure_is_an_error_string_not_an_exception_across_the_c_abi():
+    """Every drop-in entry point that can allocate runs inside `guarded` (dropin.hip): an impossible reservation comes back as
+    the reference's out-of-memory wording and the index stays usable. (Host-side only: no device is touched.)"""
+
+    class Options(C.Structure):  # usearch_init_options_t, c/usearch.h:64-110
+        _fields_ = [("metric_kind", C.c_int), ("metric", C.c_void_p), ("quantization", C.c_int),
+                    ("dimensions", C.c_size_t), ("connectivity", C.c_size_t), ("expansion_add", C.c_size_t),
+                    ("expansion_search", C.c_size_t), ("multi", C.c_bool)]
+
+    library = C.CDLL(os.path.join(ROOT, "usearch_amd", "lib", "libusearch_c.so"))
+    error_t = C.POINTER(C.c_char_p)
+    library.usearch_init.restype = C.c_void_p
+    library.usearch_init.argtypes = [C.POINTER(Options), error_t]
+    library.usearch_reserve.argtypes = [C.c_void_p, C.c_size_t, error_t]
+    library.usearch_size.restype = C.c_size_t
+    library.usearch_size.argtypes = [C.c_void_p, error_t]
+    library.usearch_contains.restype = C.c_bool
+    library.usearch_contains.argtypes = [C.c_void_p, C.c_uint64, error_t]
+    library.usearch_free.argtypes = [C.c_void_p, error_t]
+    options = Options(metric_kind=1, metric=None, quantization=1, dimensions=16, connectivity=16, expansion_add=128,
+                      expansion_search=64, multi=False)
+    error = C.c_char_p()
+    index = library.usearch_init(C.byref(options), C.byref(error))
+    assert index and not error.value
+    library.usearch_reserve(index, 1 << 60, C.byref(error))  # 2^60 keys of 8 bytes: beyond any allocator
+    assert error.value in (b"Out of memory!", b"Unexpected failure inside the index")
+    error = C.c_char_p()
+    library.usearch_capacity.restype = C.c_size_t
+    library.usearch_capacity.argtypes = [C.c_void_p, error_t]
+    assert library.usearch_capacity(index, C.byref(error)) == 0  # the failed reservation left nothing behind
+    assert library.usearch_size(index, C.byref(error)) == 0 and not error.value
+    assert library.usearch_contains(index, 42, C.byref(error)) is False and not error.value
+    library.usearch_free(index, C.byref(error))
+
+
+def test_one_hip_runtime_per_process_whichever_side_loads_first():
+    """`usearch_amd.index.library()` before `import torch` must not leave two HIP runtimes mapped (the second one would find
+    no device): the engine maps torch's bundled copy first when torch is installed (index.py `_share_hip_runtime`)."""
+    import subprocess
+    import sys
+    script = ("import sys; sys.path.insert(0, %r)\n"
+              "import usearch_amd.index as ix\n"
+              "ix.library()\n"
+              "import torch\n"
+              "print(len({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}))\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "1"

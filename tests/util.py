@@ -103,3 +103,14 @@ def without_vectors(image: np.ndarray) -> np.ndarray:
     """... and under `exclude_vectors` (index_dense.hpp:1004): the file starts with the 64-byte head."""
     rows, cols = np.frombuffer(image[:8].tobytes(), dtype=np.uint32)
     return image[8 + int(rows) * int(cols):].copy()
+
+
+def mapped_hip_runtime() -> str:
+    """Path of the HIP runtime this process has mapped (the engine's, shared with torch when torch is installed —
+    usearch_amd/index.py `_share_hip_runtime`): a test that calls the runtime directly must not pull in a second copy."""
+    import usearch_amd.index
+    usearch_amd.index.library()
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            return line.split()[-1]
+    raise RuntimeError("no HIP runtime is mapped")

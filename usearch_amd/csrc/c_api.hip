@@ -9,6 +9,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -112,6 +113,17 @@ void stats_to_c(const search_stats_t& s, usearch_amd_stats_t* out) {
 void fail(usearch_amd_error_t* error, const char* message) {
     if (error && message)
         *error = message;
+}
+
+/// What the function-try-block of an entry point ends in: an exception never crosses the C ABI, it becomes the error string.
+void fail_from_exception(usearch_amd_error_t* error) {
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        fail(error, "Out of memory!");
+    } catch (...) {
+        fail(error, "Unexpected failure inside the engine");
+    }
 }
 
 snapshot_t* as_snapshot(usearch_amd_snapshot_t handle) { return static_cast<snapshot_t*>(handle); }
@@ -277,27 +289,25 @@ int usearch_amd_device_count(usearch_amd_error_t* error) {
 }
 
 usearch_amd_snapshot_t usearch_amd_snapshot_from_buffer(void const* buffer, size_t length, int device,
-                                                        usearch_amd_error_t* error) {
+                                                        usearch_amd_error_t* error) try {
     image_t image;
     if (const char* e = image.open(buffer, length)) {
         fail(error, e);
         return nullptr;
     }
-    snapshot_t* snapshot = new (std::nothrow) snapshot_t();
-    if (!snapshot) {
-        fail(error, "Out of memory!");
-        return nullptr;
-    }
+    std::unique_ptr<snapshot_t> snapshot(new snapshot_t());
     if (const char* e = snapshot->build(image, device)) {
         fail(error, e);
-        delete snapshot;
         return nullptr;
     }
-    return snapshot;
+    return snapshot.release();
+} catch (...) {
+    fail_from_exception(error);
+    return nullptr;
 }
 
 usearch_amd_snapshot_t usearch_amd_snapshot_from_parts(void const* graph, size_t graph_length, void const* vectors,
-                                                       size_t vectors_stride, int device, usearch_amd_error_t* error) {
+                                                       size_t vectors_stride, int device, usearch_amd_error_t* error) try {
     if (!vectors) {
         fail(error, "No vectors");
         return nullptr;
@@ -309,17 +319,15 @@ usearch_amd_snapshot_t usearch_amd_snapshot_from_parts(void const* graph, size_t
         fail(error, e);
         return nullptr;
     }
-    snapshot_t* snapshot = new (std::nothrow) snapshot_t();
-    if (!snapshot) {
-        fail(error, "Out of memory!");
-        return nullptr;
-    }
+    std::unique_ptr<snapshot_t> snapshot(new snapshot_t());
     if (const char* e = snapshot->build(image, device)) {
         fail(error, e);
-        delete snapshot;
         return nullptr;
     }
-    return snapshot;
+    return snapshot.release();
+} catch (...) {
+    fail_from_exception(error);
+    return nullptr;
 }
 
 usearch_amd_snapshot_t usearch_amd_snapshot_from_file(char const* path, int device, usearch_amd_error_t* error) {
@@ -363,7 +371,7 @@ void usearch_amd_search_many(usearch_amd_snapshot_t snapshot, void const* querie
                              size_t queries_count, size_t queries_stride, size_t wanted, size_t expansion,
                              usearch_amd_key_t* keys, usearch_amd_distance_t* distances, uint64_t* counts,
                              uint64_t* visited, uint64_t* computed, usearch_amd_tuning_t const* tuning,
-                             usearch_amd_stats_t* stats, usearch_amd_error_t* error) {
+                             usearch_amd_stats_t* stats, usearch_amd_error_t* error) try {
     const scalar_kind_t kind = scalar_from_c(query_kind);
     if (kind == scalar_unknown_k)
         return fail(error, "Unknown scalar kind!"); // c/lib.cpp:120
@@ -373,13 +381,15 @@ void usearch_amd_search_many(usearch_amd_snapshot_t snapshot, void const* querie
                                                            tuning_from_c(tuning), &s))
         return fail(error, e);
     stats_to_c(s, stats);
+} catch (...) {
+    fail_from_exception(error);
 }
 
 void usearch_amd_search_many_device(usearch_amd_snapshot_t snapshot, void const* queries, size_t queries_count,
                                     size_t queries_stride, size_t wanted, size_t expansion, usearch_amd_key_t* keys,
                                     usearch_amd_distance_t* distances, uint64_t* counts, uint64_t* visited,
                                     uint64_t* computed, void* stream, usearch_amd_tuning_t const* tuning, int timed,
-                                    usearch_amd_stats_t* stats, usearch_amd_error_t* error) {
+                                    usearch_amd_stats_t* stats, usearch_amd_error_t* error) try {
     if (queries_count && wanted && (!queries || !keys || !distances || !counts || !visited || !computed))
         return fail(error, "Device entry point needs every buffer");
     search_stats_t s;
@@ -389,12 +399,14 @@ void usearch_amd_search_many_device(usearch_amd_snapshot_t snapshot, void const*
                                                              &s, timed != 0))
         return fail(error, e);
     stats_to_c(s, stats);
+} catch (...) {
+    fail_from_exception(error);
 }
 
 void usearch_amd_cluster_many(usearch_amd_snapshot_t snapshot, void const* queries, int query_kind, size_t queries_count,
                               size_t queries_stride, size_t level, usearch_amd_key_t* keys,
                               usearch_amd_distance_t* distances, uint64_t* visited, uint64_t* computed,
-                              usearch_amd_error_t* error) {
+                              usearch_amd_error_t* error) try {
     const scalar_kind_t kind = scalar_from_c(query_kind);
     if (kind == scalar_unknown_k)
         return fail(error, "Unknown scalar kind!");
@@ -403,42 +415,50 @@ void usearch_amd_cluster_many(usearch_amd_snapshot_t snapshot, void const* queri
     if (const char* e = as_snapshot(snapshot)->cluster_host(queries, kind, queries_count, queries_stride, level, keys,
                                                             distances, visited, computed))
         return fail(error, e);
+} catch (...) {
+    fail_from_exception(error);
 }
 
 void usearch_amd_exact_search_many(usearch_amd_snapshot_t snapshot, void const* queries, int query_kind,
                                    size_t queries_count, size_t queries_stride, size_t wanted, usearch_amd_key_t* keys,
                                    usearch_amd_distance_t* distances, uint64_t* counts, float* kernel_ms,
-                                   usearch_amd_error_t* error) {
+                                   usearch_amd_error_t* error) try {
     const scalar_kind_t kind = scalar_from_c(query_kind);
     if (kind == scalar_unknown_k)
         return fail(error, "Unknown scalar kind!");
     if (const char* e = as_snapshot(snapshot)->exact_host(queries, kind, queries_count, queries_stride, wanted, keys,
                                                           distances, counts, kernel_ms))
         fail(error, e);
+} catch (...) {
+    fail_from_exception(error);
 }
 
 void usearch_amd_exact_search_many_tiled(usearch_amd_snapshot_t snapshot, void const* queries, int query_kind,
                                          size_t queries_count, size_t queries_stride, size_t wanted,
                                          usearch_amd_key_t* keys, usearch_amd_distance_t* distances, uint64_t* counts,
-                                         float* kernel_ms, usearch_amd_error_t* error) {
+                                         float* kernel_ms, usearch_amd_error_t* error) try {
     const scalar_kind_t kind = scalar_from_c(query_kind);
     if (kind == scalar_unknown_k)
         return fail(error, "Unknown scalar kind!");
     if (const char* e = as_snapshot(snapshot)->exact_host(queries, kind, queries_count, queries_stride, wanted, keys,
                                                           distances, counts, kernel_ms, true))
         fail(error, e);
+} catch (...) {
+    fail_from_exception(error);
 }
 
 void usearch_amd_exact_search_dataset(void const* dataset, size_t dataset_count, size_t dataset_stride,
                                       void const* queries, size_t queries_count, size_t queries_stride,
                                       int scalar_kind, size_t dimensions, int metric_kind, size_t wanted,
                                       usearch_amd_key_t* keys, size_t keys_stride, usearch_amd_distance_t* distances,
-                                      size_t distances_stride, usearch_amd_error_t* error) {
+                                      size_t distances_stride, usearch_amd_error_t* error) try {
     if (const char* e = exact_search_dataset_host(metric_from_c(metric_kind), scalar_from_c(scalar_kind), dimensions,
                                                   dataset, dataset_count, dataset_stride, queries, queries_count,
                                                   queries_stride, wanted, keys, keys_stride, distances,
                                                   distances_stride))
         fail(error, e);
+} catch (...) {
+    fail_from_exception(error);
 }
 
 void usearch_amd_comm_unique_id(void* out, usearch_amd_error_t* error) {
@@ -447,31 +467,25 @@ void usearch_amd_comm_unique_id(void* out, usearch_amd_error_t* error) {
 }
 
 usearch_amd_comm_t usearch_amd_comm_init_rccl(void const* unique_id, int rank, int world, int device,
-                                              usearch_amd_error_t* error) {
-    comm_t* comm = new (std::nothrow) comm_t();
-    if (!comm) {
-        fail(error, "Out of memory");
-        return nullptr;
-    }
+                                              usearch_amd_error_t* error) try {
+    std::unique_ptr<comm_t> comm(new comm_t());
     if (const char* e = comm->init_rccl(unique_id, rank, world, device)) {
-        delete comm;
         fail(error, e);
         return nullptr;
     }
-    return comm;
+    return comm.release();
+} catch (...) {
+    fail_from_exception(error);
+    return nullptr;
 }
 
 usearch_amd_comm_t usearch_amd_comm_init_custom(usearch_amd_transport_t const* transport, int rank, int world, int device,
-                                                usearch_amd_error_t* error) {
+                                                usearch_amd_error_t* error) try {
     if (!transport) {
         fail(error, "No transport");
         return nullptr;
     }
-    comm_t* comm = new (std::nothrow) comm_t();
-    if (!comm) {
-        fail(error, "Out of memory");
-        return nullptr;
-    }
+    std::unique_ptr<comm_t> comm(new comm_t());
     transport_t inner;
     inner.context = transport->context;
     inner.all_gather = transport->all_gather;
@@ -479,11 +493,13 @@ usearch_amd_comm_t usearch_amd_comm_init_custom(usearch_amd_transport_t const* t
     inner.buffers_on_host = transport->buffers_on_host;
     inner.local_search = transport->local_search;
     if (const char* e = comm->init_custom(inner, rank, world, device)) {
-        delete comm;
         fail(error, e);
         return nullptr;
     }
-    return comm;
+    return comm.release();
+} catch (...) {
+    fail_from_exception(error);
+    return nullptr;
 }
 
 void usearch_amd_comm_free(usearch_amd_comm_t comm) { delete static_cast<comm_t*>(comm); }
@@ -491,11 +507,13 @@ int usearch_amd_comm_rank(usearch_amd_comm_t comm) { return comm ? static_cast<c
 int usearch_amd_comm_world(usearch_amd_comm_t comm) { return comm ? static_cast<comm_t*>(comm)->world() : 1; }
 
 void usearch_amd_comm_broadcast(usearch_amd_comm_t comm, void* buffer, size_t bytes, int root, void* stream,
-                                usearch_amd_error_t* error) {
+                                usearch_amd_error_t* error) try {
     if (!comm)
         return fail(error, "No communicator");
     if (const char* e = static_cast<comm_t*>(comm)->broadcast(buffer, bytes, root, static_cast<hipStream_t>(stream)))
         fail(error, e);
+} catch (...) {
+    fail_from_exception(error);
 }
 
 void usearch_amd_sharded_search_many(usearch_amd_snapshot_t snapshot, usearch_amd_comm_t comm, void* queries,
@@ -503,7 +521,7 @@ void usearch_amd_sharded_search_many(usearch_amd_snapshot_t snapshot, usearch_am
                                      int broadcast_root, usearch_amd_key_t* keys, usearch_amd_distance_t* distances,
                                      uint64_t* counts, uint64_t* visited, uint64_t* computed, void* stream,
                                      usearch_amd_tuning_t const* tuning, int timed, usearch_amd_stats_t* stats,
-                                     usearch_amd_sharded_stats_t* sharded_stats, usearch_amd_error_t* error) {
+                                     usearch_amd_sharded_stats_t* sharded_stats, usearch_amd_error_t* error) try {
     if (!comm)
         return fail(error, "No communicator");
     search_stats_t s;
@@ -520,21 +538,25 @@ void usearch_amd_sharded_search_many(usearch_amd_snapshot_t snapshot, usearch_am
         sharded_stats->exchange_ms = step.exchange_ms;
         sharded_stats->exchanges = step.exchanges;
     }
+} catch (...) {
+    fail_from_exception(error);
 }
 
 void usearch_amd_merge_many_device(usearch_amd_distance_t const* distances, usearch_amd_key_t const* keys,
                                    uint64_t const* counts, size_t shards, size_t queries_count, size_t wanted,
                                    usearch_amd_distance_t* out_distances, usearch_amd_key_t* out_keys,
-                                   uint64_t* out_counts, void* stream, usearch_amd_error_t* error) {
+                                   uint64_t* out_counts, void* stream, usearch_amd_error_t* error) try {
     if (const char* e = merge_shards_device(distances, keys, counts, shards, queries_count, wanted, out_distances,
                                             out_keys, out_counts, static_cast<hipStream_t>(stream)))
         fail(error, e);
+} catch (...) {
+    fail_from_exception(error);
 }
 
 void usearch_amd_merge_many(usearch_amd_distance_t const* distances, usearch_amd_key_t const* keys,
                             uint64_t const* counts, size_t shards, size_t queries_count, size_t wanted,
                             usearch_amd_distance_t* out_distances, usearch_amd_key_t* out_keys, uint64_t* out_counts,
-                            usearch_amd_error_t* error) {
+                            usearch_amd_error_t* error) try {
     const size_t cells = shards * queries_count * wanted, rows = shards * queries_count;
     if (!cells)
         return;
@@ -570,6 +592,8 @@ void usearch_amd_merge_many(usearch_amd_distance_t const* distances, usearch_amd
             (void)hipFree(p);
     if (e != hipSuccess)
         fail(error, hipGetErrorString(e));
+} catch (...) {
+    fail_from_exception(error);
 }
 
 void usearch_amd_last_peaks(usearch_amd_snapshot_t snapshot, uint32_t* out, size_t queries_count,
@@ -580,10 +604,12 @@ void usearch_amd_last_peaks(usearch_amd_snapshot_t snapshot, uint32_t* out, size
 
 void usearch_amd_distances(usearch_amd_snapshot_t snapshot, void const* queries, size_t queries_count,
                            size_t queries_stride, uint32_t const* slots, size_t slots_per_query,
-                           usearch_amd_distance_t* out, usearch_amd_error_t* error) {
+                           usearch_amd_distance_t* out, usearch_amd_error_t* error) try {
     if (const char* e = as_snapshot(snapshot)->distances_host(queries, queries_count, queries_stride, slots,
                                                               slots_per_query, out))
         fail(error, e);
+} catch (...) {
+    fail_from_exception(error);
 }
 
 float usearch_amd_last_distances_ms(usearch_amd_snapshot_t snapshot) { return as_snapshot(snapshot)->last_distances_ms(); }
@@ -635,7 +661,7 @@ void usearch_amd_test_containers(uint32_t const* kinds, float const* keys, uint3
 usearch_amd_builder_t usearch_amd_build(void const* vectors, size_t count, size_t stride, int scalar_kind,
                                         size_t dimensions, int metric_kind, usearch_amd_key_t const* keys,
                                         usearch_amd_build_config_t const* config, int device, int vectors_on_device,
-                                        usearch_amd_error_t* error) {
+                                        usearch_amd_error_t* error) try {
     build_config_t c;
     if (config) {
         if (config->connectivity)
@@ -650,18 +676,16 @@ usearch_amd_builder_t usearch_amd_build(void const* vectors, size_t count, size_
         if (config->seed)
             c.seed = config->seed;
     }
-    builder_t* builder = new (std::nothrow) builder_t();
-    if (!builder) {
-        fail(error, "Out of memory!");
-        return nullptr;
-    }
+    std::unique_ptr<builder_t> builder(new builder_t());
     if (const char* e = builder->build(metric_from_c(metric_kind), scalar_from_c(scalar_kind), dimensions, vectors, count,
                                        stride, vectors_on_device != 0, keys, c, device)) {
         fail(error, e);
-        delete builder;
         return nullptr;
     }
-    return builder;
+    return builder.release();
+} catch (...) {
+    fail_from_exception(error);
+    return nullptr;
 }
 
 void usearch_amd_build_free(usearch_amd_builder_t builder, usearch_amd_error_t*) { delete static_cast<builder_t*>(builder); }
@@ -675,9 +699,11 @@ size_t usearch_amd_build_serialized_length(usearch_amd_builder_t builder) {
 }
 
 void usearch_amd_build_save_buffer(usearch_amd_builder_t builder, void* buffer, size_t length,
-                                   usearch_amd_error_t* error) {
+                                   usearch_amd_error_t* error) try {
     if (const char* e = static_cast<builder_t*>(builder)->save_buffer(buffer, length))
         fail(error, e);
+} catch (...) {
+    fail_from_exception(error);
 }
 
 void usearch_amd_build_stats(usearch_amd_builder_t builder, usearch_amd_build_stats_t* out) {

@@ -110,6 +110,18 @@ template <typename body_at> void guarded(usearch_error_t* error, body_at&& body)
     }
 }
 
+/// Same for an entry point that returns something: `fallback` is what the caller gets next to the error string.
+template <typename result_at, typename body_at> result_at guarded(usearch_error_t* error, result_at fallback, body_at&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        fail(error, "Out of memory!");
+    } catch (const std::exception&) {
+        fail(error, "Unexpected failure inside the index");
+    }
+    return fallback;
+}
+
 using shared_lock_t = std::shared_lock<std::shared_mutex>;
 using unique_lock_t = std::unique_lock<std::shared_mutex>;
 
@@ -468,33 +480,39 @@ char const* usearch_hardware_acceleration(usearch_index_t, usearch_error_t* erro
 
 size_t usearch_serialized_length(usearch_index_t handle, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
-    std::size_t length = 0;
-    if (const char* e = serialize(index, nullptr, nullptr, 0, &length))
-        fail(error, e);
-    return length;
+    return guarded(error, std::size_t(0), [&] {
+        unique_lock_t lock(index.mutex);
+        std::size_t length = 0;
+        if (const char* e = serialize(index, nullptr, nullptr, 0, &length))
+            fail(error, e);
+        return length;
+    });
 }
 
 void usearch_save_buffer(usearch_index_t handle, void* buffer, size_t length, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
-    if (const char* e = serialize(index, nullptr, buffer, length, nullptr))
-        fail(error, e);
+    guarded(error, [&] {
+        unique_lock_t lock(index.mutex);
+        if (const char* e = serialize(index, nullptr, buffer, length, nullptr))
+            fail(error, e);
+    });
 }
 
 void usearch_save(usearch_index_t handle, char const* path, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
-    std::vector<std::uint8_t> bytes;
-    if (const char* e = serialize(index, &bytes, nullptr, 0, nullptr))
-        return fail(error, e);
-    std::FILE* file = std::fopen(path, "wb");
-    if (!file)
-        return fail(error, "Can't open file!");
-    const bool ok = std::fwrite(bytes.data(), 1, bytes.size(), file) == bytes.size();
-    std::fclose(file);
-    if (!ok)
-        fail(error, "Failed to write to file");
+    guarded(error, [&] {
+        unique_lock_t lock(index.mutex);
+        std::vector<std::uint8_t> bytes;
+        if (const char* e = serialize(index, &bytes, nullptr, 0, nullptr))
+            return fail(error, e);
+        std::FILE* file = std::fopen(path, "wb");
+        if (!file)
+            return fail(error, "Can't open file!");
+        const bool ok = std::fwrite(bytes.data(), 1, bytes.size(), file) == bytes.size();
+        std::fclose(file);
+        if (!ok)
+            fail(error, "Failed to write to file");
+    });
 }
 
 void usearch_load_buffer(usearch_index_t handle, void const* buffer, size_t length, usearch_error_t* error) {
@@ -513,11 +531,13 @@ void usearch_load_buffer(usearch_index_t handle, void const* buffer, size_t leng
 
 void usearch_view_buffer(usearch_index_t handle, void const* buffer, size_t length, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
-    index.drop_device();
-    index.drop_image();
-    if (const char* e = index.open_image(buffer, length)) // the caller's buffer is borrowed for the index lifetime
-        fail(error, e);
+    guarded(error, [&] {
+        unique_lock_t lock(index.mutex);
+        index.drop_device();
+        index.drop_image();
+        if (const char* e = index.open_image(buffer, length)) // the caller's buffer is borrowed for the index lifetime
+            fail(error, e);
+    });
 }
 
 static const char* map_file(char const* path, void** mapped, std::size_t* length) {
@@ -539,18 +559,20 @@ static const char* map_file(char const* path, void** mapped, std::size_t* length
 
 void usearch_view(usearch_index_t handle, char const* path, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
-    index.drop_device();
-    index.drop_image();
-    void* mapped = nullptr;
-    std::size_t length = 0;
-    if (const char* e = map_file(path, &mapped, &length))
-        return fail(error, e);
-    index.mapping = mapped, index.mapping_length = length;
-    if (const char* e = index.open_image(mapped, length)) {
+    guarded(error, [&] {
+        unique_lock_t lock(index.mutex);
+        index.drop_device();
         index.drop_image();
-        fail(error, e);
-    }
+        void* mapped = nullptr;
+        std::size_t length = 0;
+        if (const char* e = map_file(path, &mapped, &length))
+            return fail(error, e);
+        index.mapping = mapped, index.mapping_length = length;
+        if (const char* e = index.open_image(mapped, length)) {
+            index.drop_image();
+            fail(error, e);
+        }
+    });
 }
 
 void usearch_load(usearch_index_t handle, char const* path, usearch_error_t* error) {
@@ -563,10 +585,12 @@ void usearch_load(usearch_index_t handle, char const* path, usearch_error_t* err
 }
 
 void usearch_metadata_buffer(void const* buffer, size_t length, usearch_init_options_t* options, usearch_error_t* error) {
-    image_t image;
-    if (const char* e = image.open(buffer, length))
-        return fail(error, e);
-    fill_options(image, options);
+    guarded(error, [&] {
+        image_t image;
+        if (const char* e = image.open(buffer, length))
+            return fail(error, e);
+        fill_options(image, options);
+    });
 }
 
 void usearch_metadata(char const* path, usearch_init_options_t* options, usearch_error_t* error) {
@@ -598,14 +622,16 @@ size_t usearch_capacity(usearch_index_t handle, usearch_error_t*) {
 size_t usearch_dimensions(usearch_index_t handle, usearch_error_t*) { return as_index(handle)->dimensions; }
 size_t usearch_connectivity(usearch_index_t handle, usearch_error_t*) { return as_index(handle)->connectivity; }
 
-void usearch_reserve(usearch_index_t handle, size_t capacity, usearch_error_t*) {
+void usearch_reserve(usearch_index_t handle, size_t capacity, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
-    index.capacity = std::max(index.capacity, capacity);
-    if (index.staged || !index.has_image) { // the staging arrays are where `usearch_add` puts members
-        index.keys.reserve(capacity);
-        index.vectors.reserve(capacity * index.bpv());
-    }
+    guarded(error, [&] {
+        unique_lock_t lock(index.mutex);
+        if (index.staged || !index.has_image) { // the staging arrays are where `usearch_add` puts members
+            index.keys.reserve(capacity);
+            index.vectors.reserve(capacity * index.bpv());
+        }
+        index.capacity = std::max(index.capacity, capacity); // only once the memory is there
+    });
 }
 
 size_t usearch_expansion_add(usearch_index_t handle, usearch_error_t*) { return as_index(handle)->expansion_add; }
@@ -620,25 +646,29 @@ void usearch_change_expansion_search(usearch_index_t handle, size_t expansion, u
 void usearch_change_threads_add(usearch_index_t, size_t, usearch_error_t*) {}
 // Searches: the number of `usearch_search*` calls that may be in flight at once — the size of the engine's workspace pool,
 // the counterpart of the reference's per-thread contexts (index_dense.hpp:931-936, 1984-2000). More callers than that wait.
-void usearch_change_threads_search(usearch_index_t handle, size_t threads, usearch_error_t*) {
+void usearch_change_threads_search(usearch_index_t handle, size_t threads, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
-    index.threads_search = threads;
-    if (snapshot_t* device_index = index.device_index())
-        device_index->set_concurrency(threads ? threads : 16);
+    guarded(error, [&] {
+        unique_lock_t lock(index.mutex);
+        index.threads_search = threads;
+        if (snapshot_t* device_index = index.device_index())
+            device_index->set_concurrency(threads ? threads : 16);
+    });
 }
 
 void usearch_change_metric_kind(usearch_index_t handle, usearch_metric_kind_t kind, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
-    const metric_kind_t metric = metric_from_c(kind);
-    if (!kernel_available(metric, index.scalar))
-        return fail(error, "No MI355X kernel for this metric / scalar kind combination");
-    if (metric == index.metric)
-        return;
-    index.materialize(); // the graph was linked under the old metric
-    index.metric = metric;
-    index.drop_device();
+    guarded(error, [&] {
+        unique_lock_t lock(index.mutex);
+        const metric_kind_t metric = metric_from_c(kind);
+        if (!kernel_available(metric, index.scalar))
+            return fail(error, "No MI355X kernel for this metric / scalar kind combination");
+        if (metric == index.metric)
+            return;
+        index.materialize(); // the graph was linked under the old metric
+        index.metric = metric;
+        index.drop_device();
+    });
 }
 
 void usearch_change_metric(usearch_index_t, usearch_metric_t, void*, usearch_metric_kind_t, usearch_error_t* error) {
@@ -677,16 +707,20 @@ void usearch_add(usearch_index_t handle, usearch_key_t key, void const* vector, 
     });
 }
 
-bool usearch_contains(usearch_index_t handle, usearch_key_t key, usearch_error_t*) {
+bool usearch_contains(usearch_index_t handle, usearch_key_t key, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
-    return index.key_lookup().count(key) != 0;
+    return guarded(error, false, [&] { // the key table is filled on first use
+        unique_lock_t lock(index.mutex);
+        return index.key_lookup().count(key) != 0;
+    });
 }
 
-size_t usearch_count(usearch_index_t handle, usearch_key_t key, usearch_error_t*) {
+size_t usearch_count(usearch_index_t handle, usearch_key_t key, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
-    return index.key_lookup().count(key);
+    return guarded(error, std::size_t(0), [&] {
+        unique_lock_t lock(index.mutex);
+        return (std::size_t)index.key_lookup().count(key);
+    });
 }
 
 /// The search proper. Takes the index lock itself: shared while the device index is current (searches run side by side),
@@ -800,24 +834,26 @@ void usearch_cluster_many(usearch_index_t handle, void const* queries, usearch_s
                           size_t queries_count, size_t queries_stride, size_t level, usearch_key_t* keys,
                           usearch_distance_t* distances, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
-    const scalar_kind_t kind = scalar_from_c(query_kind);
-    if (kind == scalar_unknown_k)
-        return fail(error, "Unknown scalar kind!");
-    if (!queries_count)
-        return;
-    if (!queries || !keys || !distances)
-        return fail(error, "Cluster search needs the query, key and distance buffers");
-    snapshot_t* device_index = nullptr;
-    if (const char* e = index.ready(&device_index))
-        return fail(error, e);
-    if (!device_index) // index_gt::cluster on an empty index, index.hpp:3102-3103
-        return fail(error, "No clusters to identify");
-    std::vector<std::uint64_t> found(queries_count);
-    if (const char* e = device_index->cluster_host(queries, kind, queries_count, queries_stride, level, found.data(),
-                                                   distances, nullptr, nullptr))
-        return fail(error, e);
-    std::copy(found.begin(), found.end(), keys);
+    guarded(error, [&] {
+        unique_lock_t lock(index.mutex);
+        const scalar_kind_t kind = scalar_from_c(query_kind);
+        if (kind == scalar_unknown_k)
+            return fail(error, "Unknown scalar kind!");
+        if (!queries_count)
+            return;
+        if (!queries || !keys || !distances)
+            return fail(error, "Cluster search needs the query, key and distance buffers");
+        snapshot_t* device_index = nullptr;
+        if (const char* e = index.ready(&device_index))
+            return fail(error, e);
+        if (!device_index) // index_gt::cluster on an empty index, index.hpp:3102-3103
+            return fail(error, "No clusters to identify");
+        std::vector<std::uint64_t> found(queries_count);
+        if (const char* e = device_index->cluster_host(queries, kind, queries_count, queries_stride, level, found.data(),
+                                                       distances, nullptr, nullptr))
+            return fail(error, e);
+        std::copy(found.begin(), found.end(), keys);
+    });
 }
 
 size_t usearch_filtered_search(usearch_index_t handle, void const* query, usearch_scalar_kind_t query_kind, size_t count,
@@ -836,86 +872,95 @@ size_t usearch_filtered_search(usearch_index_t handle, void const* query, usearc
 size_t usearch_get(usearch_index_t handle, usearch_key_t key, size_t count, void* vector, usearch_scalar_kind_t vector_kind,
                    usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
     const scalar_kind_t kind = scalar_from_c(vector_kind);
     if (kind == scalar_unknown_k) {
         fail(error, "Unknown scalar kind!");
         return 0;
     }
-    const std::size_t out_bytes = bytes_per_vector(kind, index.dimensions);
-    auto range = index.key_lookup().equal_range(key);
-    std::vector<std::uint32_t> slots;
-    for (auto it = range.first; it != range.second; ++it)
-        slots.push_back(it->second);
-    std::sort(slots.begin(), slots.end()); // insertion order: the hash table's own order is unspecified
-    std::size_t exported = 0;
-    for (; exported < slots.size() && exported < count; ++exported) {
-        std::uint8_t* target = static_cast<std::uint8_t*>(vector) + exported * out_bytes;
-        const std::uint8_t* stored = index.vector_of(slots[exported]);
-        std::memset(target, 0, out_bytes);
-        if (!cast_vector(index.scalar, kind, stored, index.dimensions, target))
-            std::memcpy(target, stored, out_bytes);
-    }
-    return exported;
+    return guarded(error, std::size_t(0), [&] {
+        unique_lock_t lock(index.mutex);
+        const std::size_t out_bytes = bytes_per_vector(kind, index.dimensions);
+        auto range = index.key_lookup().equal_range(key);
+        std::vector<std::uint32_t> slots;
+        for (auto it = range.first; it != range.second; ++it)
+            slots.push_back(it->second);
+        std::sort(slots.begin(), slots.end()); // insertion order: the hash table's own order is unspecified
+        std::size_t exported = 0;
+        for (; exported < slots.size() && exported < count; ++exported) {
+            std::uint8_t* target = static_cast<std::uint8_t*>(vector) + exported * out_bytes;
+            const std::uint8_t* stored = index.vector_of(slots[exported]);
+            std::memset(target, 0, out_bytes);
+            if (!cast_vector(index.scalar, kind, stored, index.dimensions, target))
+                std::memcpy(target, stored, out_bytes);
+        }
+        return exported;
+    });
 }
 
 size_t usearch_remove(usearch_index_t handle, usearch_key_t key, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
-    if (!index.key_lookup().count(key))
-        return 0;
-    index.materialize();
-    auto range = index.key_lookup().equal_range(key);
-    std::size_t removed = 0;
-    for (auto it = range.first; it != range.second; ++it, ++removed) {
-        index.keys[it->second] = free_key_k; // a tombstone: the member keeps routing, stops matching (index_dense.hpp:1479-1511)
-        if (index.builder && it->second < index.builder->size()) // in place on the device too: nothing is relinked
-            if (const char* e = index.builder->set_key(it->second, free_key_k))
-                fail(error, e);
-    }
-    index.lookup.erase(key);
-    return removed;
+    return guarded(error, std::size_t(0), [&] {
+        unique_lock_t lock(index.mutex);
+        if (!index.key_lookup().count(key))
+            return std::size_t(0);
+        index.materialize();
+        auto range = index.key_lookup().equal_range(key);
+        std::size_t removed = 0;
+        for (auto it = range.first; it != range.second; ++it, ++removed) {
+            // a tombstone: the member keeps routing, stops matching (index_dense.hpp:1479-1511)
+            index.keys[it->second] = free_key_k;
+            if (index.builder && it->second < index.builder->size()) // in place on the device too: nothing is relinked
+                if (const char* e = index.builder->set_key(it->second, free_key_k))
+                    fail(error, e);
+        }
+        index.lookup.erase(key);
+        return removed;
+    });
 }
 
 size_t usearch_rename(usearch_index_t handle, usearch_key_t from, usearch_key_t to, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
     if (to == free_key_k) {
         fail(error, "Free key is reserved");
         return 0;
     }
-    if (!index.key_lookup().count(from))
-        return 0;
-    if (!index.multi && index.lookup.count(to)) {
-        fail(error, "Renaming impossible, the key is already in use");
-        return 0;
-    }
-    index.materialize();
-    std::vector<std::uint32_t> slots;
-    auto range = index.key_lookup().equal_range(from);
-    for (auto it = range.first; it != range.second; ++it)
-        slots.push_back(it->second);
-    index.lookup.erase(from);
-    for (std::uint32_t slot : slots) {
-        index.keys[slot] = to;
-        index.lookup.emplace(to, slot);
-        if (index.builder && slot < index.builder->size()) // keys live next to the graph in HBM: renamed in place
-            if (const char* e = index.builder->set_key(slot, to))
-                fail(error, e);
-    }
-    return slots.size();
+    return guarded(error, std::size_t(0), [&] {
+        unique_lock_t lock(index.mutex);
+        if (!index.key_lookup().count(from))
+            return std::size_t(0);
+        if (!index.multi && index.lookup.count(to)) {
+            fail(error, "Renaming impossible, the key is already in use");
+            return std::size_t(0);
+        }
+        index.materialize();
+        std::vector<std::uint32_t> slots;
+        auto range = index.key_lookup().equal_range(from);
+        for (auto it = range.first; it != range.second; ++it)
+            slots.push_back(it->second);
+        index.lookup.erase(from);
+        for (std::uint32_t slot : slots) {
+            index.keys[slot] = to;
+            index.lookup.emplace(to, slot);
+            if (index.builder && slot < index.builder->size()) // keys live next to the graph in HBM: renamed in place
+                if (const char* e = index.builder->set_key(slot, to))
+                    fail(error, e);
+        }
+        return slots.size();
+    });
 }
 
 usearch_distance_t usearch_distance(void const* first, void const* second, usearch_scalar_kind_t scalar_kind,
                                     size_t dimensions, usearch_metric_kind_t metric_kind, usearch_error_t* error) {
-    std::uint64_t key = 0;
-    float distance = 0.f;
-    const scalar_kind_t scalar = scalar_from_c(scalar_kind);
-    const std::size_t bpv = bytes_per_vector(scalar, dimensions);
-    if (const char* e = exact_search_dataset_host(metric_from_c(metric_kind), scalar, dimensions, second, 1, bpv, first, 1,
-                                                  bpv, 1, &key, 8, &distance, 4))
-        fail(error, e);
-    return distance;
+    return guarded(error, usearch_distance_t(0), [&] {
+        std::uint64_t key = 0;
+        float distance = 0.f;
+        const scalar_kind_t scalar = scalar_from_c(scalar_kind);
+        const std::size_t bpv = bytes_per_vector(scalar, dimensions);
+        if (const char* e = exact_search_dataset_host(metric_from_c(metric_kind), scalar, dimensions, second, 1, bpv, first, 1,
+                                                      bpv, 1, &key, 8, &distance, 4))
+            fail(error, e);
+        return usearch_distance_t(distance);
+    });
 }
 
 void usearch_exact_search(void const* dataset, size_t dataset_size, size_t dataset_stride, void const* queries,
@@ -923,28 +968,34 @@ void usearch_exact_search(void const* dataset, size_t dataset_size, size_t datas
                           usearch_metric_kind_t metric_kind, size_t count, size_t /*threads*/, usearch_key_t* keys,
                           size_t keys_stride, usearch_distance_t* distances, size_t distances_stride,
                           usearch_error_t* error) {
-    if (const char* e = exact_search_dataset_host(metric_from_c(metric_kind), scalar_from_c(scalar_kind), dimensions, dataset,
-                                                  dataset_size, dataset_stride, queries, queries_size, queries_stride, count,
-                                                  keys, keys_stride, distances, distances_stride))
-        fail(error, e);
+    guarded(error, [&] {
+        if (const char* e = exact_search_dataset_host(metric_from_c(metric_kind), scalar_from_c(scalar_kind), dimensions, dataset,
+                                                      dataset_size, dataset_stride, queries, queries_size, queries_stride, count,
+                                                      keys, keys_stride, distances, distances_stride))
+            fail(error, e);
+    });
 }
 
-void usearch_clear(usearch_index_t handle, usearch_error_t*) {
+void usearch_clear(usearch_index_t handle, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
-    index.drop_device();
-    index.drop_image();
-    index.keys.clear(), index.vectors.clear();
-    index.staged = false;
-    index.lookup.clear(), index.lookup_valid = false;
+    guarded(error, [&] {
+        unique_lock_t lock(index.mutex);
+        index.drop_device();
+        index.drop_image();
+        index.keys.clear(), index.vectors.clear();
+        index.staged = false;
+        index.lookup.clear(), index.lookup_valid = false;
+    });
 }
 
 void usearch_gpu_sync(usearch_index_t handle, usearch_error_t* error) {
     index_t& index = *as_index(handle);
-    unique_lock_t lock(index.mutex);
-    snapshot_t* device_index = nullptr;
-    if (const char* e = index.ready(&device_index))
-        fail(error, e);
+    guarded(error, [&] {
+        unique_lock_t lock(index.mutex);
+        snapshot_t* device_index = nullptr;
+        if (const char* e = index.ready(&device_index))
+            fail(error, e);
+    });
 }
 
 void usearch_gpu_release(usearch_index_t handle, usearch_error_t*) {

@@ -96,6 +96,30 @@ EXPORTED_SYMBOLS = [
 ]
 
 
+def _share_hip_runtime() -> None:
+    """One HIP runtime per process. PyTorch wheels bundle their own `libamdhip64.so` and `libtorch_hip.so` asks for it by that
+    unversioned file name, so the loader does not recognise a system runtime that is already mapped (its SONAME is
+    `libamdhip64.so.7`) and maps torch's copy as a second runtime — which then finds no device, the first one holding the
+    driver. Mapping torch's copy first makes both sides resolve to it: this library asks for the SONAME, and torch's copy
+    carries it. Only the path is looked up, torch is not imported; without torch there is nothing to share."""
+    try:
+        with open("/proc/self/maps") as maps:
+            if "libamdhip64" in maps.read():
+                return  # a runtime is mapped already (torch imported first, or the caller's own)
+    except OSError:
+        pass
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        C.CDLL(bundled, mode=os.RTLD_GLOBAL)
+
+
 def library() -> C.CDLL:
     """Loads `usearch_amd/lib/libusearch_amd.so` (built by `make -C usearch_amd/csrc` / `__graft_entry__.build()`)."""
     global _library
@@ -104,6 +128,7 @@ def library() -> C.CDLL:
     if not os.path.exists(LIBRARY_PATH):
         raise RuntimeError(f"{LIBRARY_PATH} is missing: build it with `make -C usearch_amd/csrc` "
                            "(hipcc, gfx950). The engine has no CPU fallback.")
+    _share_hip_runtime()
     L = C.CDLL(LIBRARY_PATH, mode=os.RTLD_LOCAL)
     err_p = C.POINTER(C.c_char_p)
     L.usearch_amd_device_count.restype = C.c_int
