@@ -40,6 +40,7 @@ for step in "$@"; do
                 USEARCH_AMD_LIBRARY=$lib timeout 300 python bench.py --vectors 20000000 $shape --queries 100000 \
                   --recall-queries 1000 --no-stress-rows --no-cpu-baseline --steps 5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), 'QPS', d['config']['persistent_waves'], 'waves', d['roofline']['kernel_ms'], 'ms')"
               done; done ;;
+    variance) for run in 1 2; do echo "--- process $run"; timeout 400 python scripts/variance_probe.py 2>&1 | grep -v "amdgpu.ids"; done | tee "$OUT/variance.log" ;;
     order)    # files that load the engine / the drop-in BEFORE anything imports torch: one HIP runtime either way (index.py)
               timeout 600 python -m pytest tests/test_gpu_search_parity.py tests/test_gpu_dropin.py tests/test_gpu_fullsize.py tests/test_gpu_build.py \
                 -m gpu -q --maxfail=5 > "$OUT/order_pytest.log" 2>&1; tail -4 "$OUT/order_pytest.log" ;;
