@@ -174,3 +174,47 @@ def test_one_hip_runtime_per_process_whichever_side_loads_first():
     out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] == "1"
+
+
+def test_placement_draws_keep_the_fastest_and_release_the_rest():
+    """`Index.restore_placed` (index.py): uploads `draws` times (or until one is `good_enough`), holds the losers while it draws
+    (so the next one lands elsewhere) when memory allows, keeps the fastest, releases every loser, never closes `first`."""
+    from usearch_amd.index import Index
+
+    class Stub(Index):
+        made, closed = [], []
+        memory_usage = 100
+
+        def __init__(self, number):
+            self.number, self._handle = number, None
+
+        @classmethod
+        def restore(cls, source, device=0, expansion_search=0, vectors=None):
+            stub = cls(len(cls.made))
+            cls.made.append(stub)
+            return stub
+
+        def close(self):
+            Stub.closed.append(self.number)
+
+        def __del__(self):
+            pass
+
+    def run(speeds, **options):
+        Stub.made, Stub.closed = [], []
+        return Stub.restore_placed(b"", lambda index: speeds[index.number], **options)
+
+    best, report = run([51.7, 51.8, 48.9, 45.4, 51.7], draws=5)
+    assert best.number == 3 and report == {"probe_ms": [51.7, 51.8, 48.9, 45.4, 51.7], "kept": 3}
+    assert sorted(Stub.closed) == [0, 1, 2, 4]
+    best, report = run([51.7, 51.8, 48.9, 45.4, 51.7], draws=5, good_enough=49.0)  # a caller that knows what fast is
+    assert best.number == 2 and report["probe_ms"] == [51.7, 51.8, 48.9] and sorted(Stub.closed) == [0, 1]
+    best, report = run([51.7, 51.8, 51.75, 51.72], draws=4)  # one speed only: all draws spent, the best of them kept
+    assert best.number == 0 and len(report["probe_ms"]) == 4 and sorted(Stub.closed) == [1, 2, 3]
+    best, report = run([51.7, 51.8], draws=4, free_bytes=lambda: 110)  # no room for a second one next to the first
+    assert best.number == 0 and report["probe_ms"] == [51.7] and Stub.closed == []
+    already_there = Stub(99)
+    best, report = run({99: 51.7, 0: 45.0}, draws=2, first=already_there)  # the resident index takes part and is never closed
+    assert best.number == 0 and report["kept"] == 1 and 99 not in Stub.closed
+    best, report = run({99: 45.0, 0: 51.7}, draws=2, first=already_there)
+    assert best is already_there and Stub.closed == [0]

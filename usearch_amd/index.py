@@ -280,6 +280,51 @@ class Index:
             raise RuntimeError("usearch_amd snapshot: failed without a message")
         return cls(handle, expansion_search)
 
+    @classmethod
+    def restore_placed(cls, source, probe, draws: int = 8, device: int = 0, expansion_search: int = 0,
+                       vectors: Optional[np.ndarray] = None, first: Optional["Index"] = None,
+                       good_enough: Optional[float] = None, free_bytes=None):
+        """`restore`, but choosing WHERE in HBM the index lands. The same index bytes at other physical addresses walk at one
+        of two speeds (headline batch: 45.4 or 51.7 ms; stable for the life of an allocation, profiles/r02_placement.log), and
+        the allocator decides which. So: upload the image up to `draws` times, time `probe(index) -> milliseconds` (a batch of
+        the caller's own queries) on each, keep the fastest. Candidates that lost stay allocated until the end — the next one
+        must land somewhere else — as long as `free_bytes()` (device memory still free) leaves room for one more; they are
+        released before returning. `good_enough` (milliseconds): stop drawing once a candidate is at least that fast (a deployment
+        that knows its fast speed). `first`: an index that is already resident (the builder's own) takes part as draw 0; it is
+        never closed here. Returns (index, {"probe_ms": [...], "kept": i}) — `index is first` when nothing beat it."""
+        candidates, timings = [], []
+        if first is not None:
+            candidates.append(first)
+            timings.append(float(probe(first)))
+        try:
+            while len(timings) < max(1, draws):
+                if timings and good_enough is not None and min(timings) <= good_enough:
+                    break
+                if candidates and free_bytes is not None and free_bytes() < 1.25 * candidates[0].memory_usage:
+                    # no room next to the ones held: let go of every loser, keep drawing
+                    keep = int(np.argmin(timings))
+                    for i, candidate in enumerate(candidates):
+                        if i != keep and candidate is not None and candidate is not first:
+                            candidate.close()
+                            candidates[i] = None
+                    if free_bytes() < 1.25 * candidates[keep].memory_usage:
+                        break
+                try:
+                    candidate = cls.restore(source, device, expansion_search, vectors)
+                except RuntimeError:
+                    if not candidates:
+                        raise
+                    break  # out of device memory next to the ones held: the best so far it is
+                candidates.append(candidate)
+                timings.append(float("inf"))  # in the list before the probe runs: a failing probe still gets it released
+                timings[-1] = float(probe(candidate))
+        finally:
+            kept = int(np.argmin(timings)) if timings else -1
+            for i, candidate in enumerate(candidates):
+                if i != kept and candidate is not None and candidate is not first:
+                    candidate.close()
+        return candidates[kept], {"probe_ms": [round(t, 3) for t in timings], "kept": kept}
+
     def close(self) -> None:
         if getattr(self, "_handle", None):
             if getattr(self, "_owner", None) is None:
