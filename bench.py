@@ -485,8 +485,15 @@ def main() -> None:
     #      placements and keeps the fastest, timed on this very batch. Index load policy, outside the timed region; each rank on
     #      its own (no collective involved).
     placement = None
-    if args.placement_draws > 1 and not sharded:
+    # ranks of one node take turns two at a time: each turn holds a serialized image (16.8 GB for the headline) in host memory
+    draw_turns = range(0, world, 2) if args.placement_draws > 1 and not sharded and not rehearsal else []
+    for turn in draw_turns:
+        if world > 1:
+            dist.barrier()
+        if rank // 2 != turn // 2:
+            continue
         t1 = time.time()
+        image_was_there = image is not None
         if image is None:
             image = built.save_buffer()
 
@@ -508,9 +515,13 @@ def main() -> None:
             else:
                 builders_own.close()
         placement["seconds"] = round(time.time() - t1, 1)
+        if world > 1 and not image_was_there:
+            image = None  # only the single-GPU run needs it again (for the reference)
         if rank == 0:
             log(f"[bench] placement: batch kernel {placement['probe_ms']} ms over {len(placement['probe_ms'])} draw(s), kept "
                 f"#{placement['kept']} ({placement['seconds']} s incl. serializing the image)")
+    if draw_turns and world > 1:
+        dist.barrier()
 
     # ---- warmup, then EXACTLY `steps` timed steps between barriers
     flush_native_stdio()
