@@ -22,7 +22,7 @@ def main(source: str, target: str) -> None:
         instantiation = line["roofline"]["kernel_instantiation"]
         out = os.path.join(target, workload)
         os.makedirs(out, exist_ok=True)
-        for name in ("bench.json", "bench.log", "pick.log", "kernel_stats.csv", "traffic.json"):
+        for name in ("bench.json", "bench.log", "pick.log", "kernel_stats.csv", "kernel_trace_timed.json", "traffic.json"):
             if os.path.isfile(os.path.join(directory, name)):
                 shutil.copyfile(os.path.join(directory, name), os.path.join(out, name))
         # the bench line of the very process the kernel trace was taken from: its HIP-event time is the one to hold against

@@ -19,6 +19,10 @@ EF=$(python -c "import json; print(json.load(open('$OUT/pick.json'))['config']['
 QUICK="$* --expansion $EF --recall-queries 0 --no-cpu-baseline --no-stress-rows --no-host-api --steps 5 --warmup 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python "$REPO/bench.py" $QUICK > "$OUT/stats_bench.json" 2> "$OUT/stats.log"
 find "$OUT/stats" -name "*kernel_stats.csv" | head -1 | while read f; do cp "$f" "$OUT/kernel_stats.csv"; done
+# the timed launches alone (the whole-process average above also covers the placement draws' candidates)
+find "$OUT/stats" -name "*kernel_trace.csv" | head -1 | while read f; do
+  python "$REPO/scripts/trace_timed.py" "$f" "$OUT/stats_bench.json" > "$OUT/kernel_trace_timed.json" || echo "trace_timed failed"
+done
 GROUPS_LIMIT=${PROFILE_TRAFFIC_ONLY:+2}
 PASS=0
 for counters in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS"; do
