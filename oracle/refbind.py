@@ -37,6 +37,9 @@ class InitOptions(C.Structure):
     ]
 
 
+FILTER_T = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_void_p)  # int (*)(usearch_key_t key, void* state), c/usearch.h:392-395
+
+
 def available() -> bool:
     return os.path.exists(REF_LIB_PATH)
 
@@ -218,6 +221,22 @@ class RefIndex:
                                      C.byref(err))
         _check(err, "usearch_search")
         return found, keys, dists
+
+    def filtered_search(self, query: np.ndarray, k: int, predicate, dtype: Optional[str] = None):
+        """`usearch_filtered_search` (`c/usearch.h:392-395`): `predicate(key) -> bool` decides what may be returned."""
+        dtype = dtype or self.dtype
+        query = np.ascontiguousarray(query)
+        keys = np.zeros(k, dtype=np.uint64)
+        dists = np.zeros(k, dtype=np.float32)
+        callback = FILTER_T(lambda key, _state: int(bool(predicate(int(key)))))
+        err = C.c_char_p()
+        call = lib().usearch_filtered_search
+        call.restype = C.c_size_t
+        call.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, FILTER_T, C.c_void_p, C.c_void_p, C.c_void_p,
+                         C.POINTER(C.c_char_p)]
+        found = call(self.handle, _ptr(query), SCALAR[dtype], k, callback, None, _ptr(keys), _ptr(dists), C.byref(err))
+        _check(err, "usearch_filtered_search")
+        return int(found), keys, dists
 
     def save_buffer(self) -> np.ndarray:
         err = C.c_char_p()

@@ -3,6 +3,7 @@ Skipped where neither the built library nor the reference sources are available.
 import numpy as np
 import pytest
 
+from oracle import oraclebind
 from tests import util
 
 CASES = [
@@ -108,3 +109,29 @@ def test_cluster_side_by_side(reference, metric, dtype, ndim, n, connectivity):
             assert util.same_float_bits(distances, rdistances)
         else:
             assert np.all(np.abs(distances - rdistances) <= 1e-5 * np.maximum(1, np.abs(rdistances)))
+
+
+@pytest.mark.parametrize("metric,dtype,ndim,n", [("l2sq", "i8", 48, 2500), ("hamming", "b1", 128, 3000), ("cos", "f32", 32, 2000)])
+def test_filtered_search_side_by_side(reference, metric, dtype, ndim, n):
+    """`usearch_filtered_search` (c/usearch.h:392-395 → index_dense.hpp:2053-2085 with a predicate → the two `allow` tests of
+    the traversal, index.hpp:4200-4205 and 4236-4240) against the oracle's restatement, for predicates of every selectivity:
+    members that fail the test still route, they just never enter the result."""
+    image, vectors, ref_index = util.build_image(n, ndim, metric, dtype, seed=41)
+    queries = util.make_vectors(40, ndim, dtype, seed=42, metric=metric)
+    queries[:5] = vectors[:5]
+    index = oraclebind.OracleIndex(image)
+    ref_index.expansion_search = 64
+    predicates = {"every third": lambda key: key % 3 == 0, "one in fifty": lambda key: key % 50 == 7,
+                  "the upper half": lambda key: key >= n // 2, "all": lambda key: True, "none": lambda key: False}
+    for name, predicate in predicates.items():
+        for query in queries:
+            rfound, rkeys, rdists = ref_index.filtered_search(query, 10, predicate, dtype=dtype)
+            found, keys, dists = index.filtered_search(query, 10, predicate, dtype=dtype, expansion=64)
+            assert found == rfound, name
+            assert all(predicate(int(key)) for key in rkeys[:rfound]), name
+            if util.exact_pair(metric, dtype):
+                assert np.array_equal(keys[:found], rkeys[:found]), name
+                assert util.same_float_bits(dists[:found], rdists[:found]), name
+            else:
+                assert np.all(np.abs(dists[:found] - rdists[:found]) <= util.tolerance(dtype) * np.maximum(1, np.abs(rdists[:found])))
+                assert (keys[:found] == rkeys[:found]).mean() > 0.9 if found else True
