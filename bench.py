@@ -317,6 +317,7 @@ def main() -> None:
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # every rank is on this box
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

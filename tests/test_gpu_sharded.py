@@ -20,6 +20,7 @@ CASES = [("hamming", "b1", 128, 30000, 400, 10, 64), ("cos", "f16", 96, 20000, 3
 
 def worker(rank: int, port: int, results):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # both ranks are here: never the interface the hostname resolves to
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     try:

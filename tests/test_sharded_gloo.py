@@ -41,6 +41,7 @@ def oracle_merge(parts):
 
 def worker(rank: int, port: int, results):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # both ranks are here: never the interface the hostname resolves to
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     try:
