@@ -8,7 +8,7 @@ import sys
 
 text = open(sys.argv[1]).read()
 needle = sys.argv[2] if len(sys.argv) > 2 else "search_kernel"
-for block in re.split(r"remark: Function Name: ", text)[1:]:
+for block in re.split(r"remark: (?:\S+: )?Function Name: ", text)[1:]:  # with or without a file:line prefix
     name = block.split(" [")[0].strip()
     pretty = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
     if needle not in pretty:
