@@ -495,8 +495,6 @@ def main() -> None:
             continue
         t1 = time.time()
         image_was_there = image is not None
-        if image is None:
-            image = built.save_buffer()
 
         def probe(candidate) -> float:
             for timed in (False, True):  # the first call sizes the candidate's workspace
@@ -507,9 +505,15 @@ def main() -> None:
             return stats.kernel_ms
 
         builders_own = index
-        index, placement = usearch_amd.Index.restore_placed(image, probe, draws=args.placement_draws, device=local_rank,
-                                                            first=builders_own,
-                                                            free_bytes=lambda: torch.cuda.mem_get_info(device)[0])
+        try:
+            if image is None:
+                image = built.save_buffer()
+            index, placement = usearch_amd.Index.restore_placed(image, probe, draws=args.placement_draws, device=local_rank,
+                                                                first=builders_own,
+                                                                free_bytes=lambda: torch.cuda.mem_get_info(device)[0])
+        except (RuntimeError, MemoryError) as error:  # no room for the image or a second copy: the first placement it is
+            log(f"[bench] rank {rank}: no placement draw ({error}); keeping the index where it was built")
+            index, placement = builders_own, {"probe_ms": [], "kept": 0, "error": str(error)[:200]}
         if index is not builders_own:  # the first placement lost: its memory goes back
             if built is not None:
                 built.close()
@@ -518,7 +522,7 @@ def main() -> None:
         placement["seconds"] = round(time.time() - t1, 1)
         if world > 1 and not image_was_there:
             image = None  # only the single-GPU run needs it again (for the reference)
-        if rank == 0:
+        if rank == 0 and placement["probe_ms"]:
             log(f"[bench] placement: batch kernel {placement['probe_ms']} ms over {len(placement['probe_ms'])} draw(s), kept "
                 f"#{placement['kept']} ({placement['seconds']} s incl. serializing the image)")
     if draw_turns and world > 1:
