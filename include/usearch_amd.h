@@ -260,6 +260,9 @@ USEARCH_AMD_EXPORT void usearch_amd_comm_broadcast(usearch_amd_comm_t comm, void
  *  keys / distances / counts receive the merged result (identical on every rank); visited / computed this rank's own
  *  traversal counters. With a transport that carries `local_search`, every buffer is host memory and `snapshot` may be
  *  NULL. Replaces `Indexes.search` (python/lib.cpp:321-402).
+ *  Errors are collective: a rank whose broadcast, search or retry fails still enters the all-gather, with an abort bit in
+ *  the flag word that closes its block, so EVERY rank returns an error for that step (the failing rank its own message,
+ *  the others "aborted by rank r in …") and none is left waiting inside the collective.
  */
 USEARCH_AMD_EXPORT void usearch_amd_sharded_search_many(usearch_amd_snapshot_t snapshot, usearch_amd_comm_t comm,
                                                         void* queries, size_t queries_count, size_t queries_stride,

@@ -83,6 +83,34 @@ def worker(rank: int, port: int, results):
         communicator.search_raw(None, queries.ctypes.data, Q, STRIDE, K, 64, -1, keys.ctypes.data, distances.ctypes.data,
                                 counts.ctypes.data, 0, 0)
         assert seen["checksum"] == Q * STRIDE * 3  # rank 1's buffer was overwritten by the first step's broadcast
+
+        # a rank whose local search FAILS still enters the collective (abort bit in its block's flag word): both ranks leave
+        # the step with an error — the failing one with its own message, the other naming it — and nobody hangs
+        failing = {"rank": 1}
+
+        def flaky_search(queries: np.ndarray, count: int, wanted: int, expansion: int):
+            if rank == failing["rank"]:
+                raise MemoryError("injected: this shard ran out of scratch")
+            return fake_shard_results(rank, 1)
+
+        flaky = Communicator.on_host(rank, WORLD, all_gather, broadcast, flaky_search)
+        for bad_rank in (1, 0):
+            failing["rank"] = bad_rank
+            try:
+                flaky.search_raw(None, queries.ctypes.data, Q, STRIDE, K, 64, 0, keys.ctypes.data, distances.ctypes.data,
+                                 counts.ctypes.data, 0, 0)
+                raise AssertionError("the step succeeded although a rank failed")
+            except RuntimeError as error:
+                text = str(error)
+                if rank == bad_rank:
+                    assert "injected" in text, text
+                else:
+                    assert f"aborted by rank {bad_rank} of {WORLD}" in text and "local search" in text, text
+        # and the communicator is still usable afterwards: the next step is a normal one
+        failing["rank"] = -1
+        stats, step = flaky.search_raw(None, queries.ctypes.data, Q, STRIDE, K, 64, 0, keys.ctypes.data,
+                                       distances.ctypes.data, counts.ctypes.data, 0, 0)
+        assert step.exchanges == 1
         results[rank] = True
     finally:
         dist.destroy_process_group()

@@ -48,6 +48,7 @@ struct rccl_api_t {
     int (*get_unique_id)(rccl_unique_id_t*) = nullptr;
     int (*comm_init_rank)(rccl_comm_t*, int, rccl_unique_id_t, int) = nullptr;
     int (*comm_destroy)(rccl_comm_t) = nullptr;
+    int (*comm_abort)(rccl_comm_t) = nullptr;
     int (*all_gather)(const void*, void*, std::size_t, int, rccl_comm_t, hipStream_t) = nullptr;
     int (*broadcast)(const void*, void*, std::size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
     const char* (*error_string)(int) = nullptr;
@@ -86,6 +87,7 @@ rccl_api_t& rccl() {
         api.all_gather = reinterpret_cast<decltype(api.all_gather)>(resolve("ncclAllGather"));
         api.broadcast = reinterpret_cast<decltype(api.broadcast)>(resolve("ncclBroadcast"));
         api.error_string = reinterpret_cast<decltype(api.error_string)>(resolve("ncclGetErrorString"));
+        api.comm_abort = reinterpret_cast<decltype(api.comm_abort)>(dlsym(api.handle, "ncclCommAbort")); // optional
     });
     return api;
 }
@@ -144,6 +146,15 @@ comm_t::~comm_t() {
     }
 }
 
+/// Last resort for a rank that cannot enter a collective any more: make the peers' pending collectives fail rather than wait.
+void comm_t::abort_transport() {
+    if (kind_ == transport_rccl_k && rccl_comm_ && rccl().comm_abort) {
+        (void)rccl().comm_abort(rccl_comm_);
+        rccl_comm_ = nullptr;
+    }
+    broken_ = true; // a caller's transport has no such call: its peers time out by its own rules
+}
+
 const char* comm_t::unique_id(void* out) {
     rccl_api_t& api = rccl();
     if (!api.failure.empty())
@@ -199,7 +210,7 @@ const char* comm_t::reserve(std::size_t block_bytes) {
         UA_HIP(hipMalloc((void**)&d_send_, room));
         UA_HIP(hipMalloc((void**)&d_gathered_, room * world_));
         if (!h_flags_)
-            UA_HIP(hipHostMalloc((void**)&h_flags_, 8 * (std::size_t)world_, hipHostMallocDefault));
+            UA_HIP(hipHostMalloc((void**)&h_flags_, 8 * ((std::size_t)world_ + 1), hipHostMallocDefault)); // + this rank's staging word
         if (kind_ == transport_custom_k && transport_.buffers_on_host) {
             UA_HIP(hipHostMalloc((void**)&h_send_, room, hipHostMallocDefault));
             UA_HIP(hipHostMalloc((void**)&h_gathered_, room * world_, hipHostMallocDefault));
@@ -297,6 +308,23 @@ static void merge_blocks_host(const std::uint8_t* gathered, std::size_t block_by
     }
 }
 
+/// Message for a step that some rank aborted: this rank's own failure if it is the one, else who it was and where.
+const char* comm_t::abort_message(const std::uint64_t* flags, const char* local) const {
+    for (int r = 0; r < world_; ++r)
+        if (flags[r] & flag_abort_k) {
+            if (r == rank_ && local)
+                return local;
+            const unsigned stage = (unsigned)((flags[r] >> 32) & 0xFFFFu);
+            const char* where = stage == stage_broadcast_k ? "the broadcast of the batch"
+                                : stage == stage_search_k  ? "its local search"
+                                : stage == stage_ladder_k  ? "the retry of its outgrown queries"
+                                                           : "an unknown stage";
+            return keep_message("Sharded step aborted by rank " + std::to_string(r) + " of " + std::to_string(world_) + " in " +
+                                where + (r == rank_ ? "" : " (that rank reports the cause)"));
+        }
+    return local;
+}
+
 const char* comm_t::search(snapshot_t* shard, void* queries, std::size_t count, std::size_t stride_bytes,
                            std::size_t wanted, std::size_t expansion, int broadcast_root, std::uint64_t* keys,
                            float* distances, std::uint64_t* counts, std::uint64_t* visited, std::uint64_t* computed,
@@ -309,37 +337,65 @@ const char* comm_t::search(snapshot_t* shard, void* queries, std::size_t count, 
     if (!count || !wanted)
         return nullptr;
     std::lock_guard<std::mutex> lock(mutex_); // the blocks below are one batch deep
+    if (broken_)
+        return "This communicator was torn down after a rank could not enter a collective: create a new one";
     const block_layout_t layout = block_layout(count, wanted);
-    if (const char* e = reserve(layout.bytes))
+    // The blocks are the one thing a rank cannot fail on quietly: without them it cannot enter the collective at all, so the
+    // communicator is torn down (RCCL: ncclCommAbort, the peers' pending collectives fail instead of waiting for ever).
+    if (const char* e = reserve(layout.bytes)) {
+        abort_transport();
         return e;
+    }
     if (step)
         step->block_bytes = layout.bytes, step->gathered_bytes = layout.bytes * world_;
+
+    // A rank-local failure from here on does NOT return before the exchange: the rank still enters the collective, with the
+    // abort bit set in its block's flag word, so that every rank leaves the step with an error instead of waiting in
+    // ncclAllGather for a peer that has gone home (`local` = this rank's message, `stage` = where it happened).
+    const char* local = nullptr;
+    unsigned stage = 0;
+    auto abort_word = [&]() -> std::uint64_t { return flag_abort_k | ((std::uint64_t)stage << 32); };
+    auto any = [&](const std::uint64_t* flags, std::uint64_t mask) {
+        bool hit = false;
+        for (int r = 0; r < world_; ++r)
+            hit |= (flags[r] & mask) != 0;
+        return hit;
+    };
 
     // ---- no device: the search is the transport's double, everything lives in host memory
     if (!on_device_) {
         if (broadcast_root >= 0 && world_ > 1) {
             if (!transport_.broadcast)
-                return "This transport cannot broadcast: hand every rank the batch";
-            if (const char* e = transport_.broadcast(transport_.context, queries, (count - 1) * stride_bytes + stride_bytes,
-                                                     broadcast_root, nullptr))
-                return e;
+                local = "This transport cannot broadcast: hand every rank the batch", stage = stage_broadcast_k;
+            else if (const char* e = transport_.broadcast(transport_.context, queries, count * stride_bytes, broadcast_root, nullptr))
+                local = keep_message(e), stage = stage_broadcast_k;
         }
-        if (const char* e = transport_.local_search(transport_.context, queries, count, stride_bytes, wanted, expansion,
-                                                    reinterpret_cast<std::uint64_t*>(h_send_ + layout.keys),
-                                                    reinterpret_cast<float*>(h_send_ + layout.distances),
-                                                    reinterpret_cast<std::uint64_t*>(h_send_ + layout.counts)))
-            return e;
+        if (!local)
+            if (const char* e = transport_.local_search(transport_.context, queries, count, stride_bytes, wanted, expansion,
+                                                        reinterpret_cast<std::uint64_t*>(h_send_ + layout.keys),
+                                                        reinterpret_cast<float*>(h_send_ + layout.distances),
+                                                        reinterpret_cast<std::uint64_t*>(h_send_ + layout.counts)))
+                local = keep_message(e), stage = stage_search_k;
+        const std::uint64_t word = local ? abort_word() : 0;
+        std::memcpy(h_send_ + layout.flags, &word, 8);
         if (world_ == 1)
             std::memcpy(h_gathered_, h_send_, layout.bytes);
         else if (const char* e = all_gather(layout.bytes, nullptr))
-            return e;
+            return local ? local : e; // the transport itself failed: nothing left to agree over
+        std::vector<std::uint64_t> flags((std::size_t)world_);
+        for (int r = 0; r < world_; ++r)
+            std::memcpy(&flags[(std::size_t)r], h_gathered_ + (std::size_t)r * layout.bytes + layout.flags, 8);
+        if (step)
+            step->exchanges = 1;
+        if (any(flags.data(), flag_abort_k))
+            return abort_message(flags.data(), local);
         merge_blocks_host(h_gathered_, layout.bytes, layout, (std::size_t)world_, count, wanted, keys, distances, counts);
         return nullptr;
     }
 
     // ---- device: one stream, one wait
     if (!shard)
-        return "No shard to search";
+        return "No shard to search"; // a caller's mistake, the same on every rank
     UA_HIP(hipSetDevice(shard->device()));
     if (!stream)
         stream = shard->stream();
@@ -360,29 +416,48 @@ const char* comm_t::search(snapshot_t* shard, void* queries, std::size_t count, 
 
     if (broadcast_root >= 0)
         if (const char* e = broadcast(queries, count * stride_bytes, broadcast_root, stream))
-            return e;
+            local = e, stage = stage_broadcast_k;
 
     snapshot_t::search_call_t call;
+    bool began = false;
     std::uint64_t* send_keys = reinterpret_cast<std::uint64_t*>(d_send_ + layout.keys);
     float* send_distances = reinterpret_cast<float*>(d_send_ + layout.distances);
     std::uint64_t* send_counts = reinterpret_cast<std::uint64_t*>(d_send_ + layout.counts);
-    if (const char* e = shard->search_begin(call, queries, count, stride_bytes, wanted, expansion, send_keys, send_distances,
-                                            send_counts, visited, computed, stream, tuning, timed)) {
-        if (call.workspace)
-            shard->give_back(call.workspace);
-        return e;
+    if (!local) {
+        if (const char* e = shard->search_begin(call, queries, count, stride_bytes, wanted, expansion, send_keys, send_distances,
+                                                send_counts, visited, computed, stream, tuning, timed)) {
+            if (call.workspace)
+                shard->give_back(call.workspace);
+            call.workspace = nullptr;
+            local = e, stage = stage_search_k;
+        } else {
+            began = true;
+        }
     }
-    // The block's last word tells the other ranks how many of this rank's queries outgrew their scratch (rare): their
-    // results are not in the block yet. It is copied device to device from the search's own counter, nobody waits.
-    const char* error = nullptr;
-    auto guard = [&](hipError_t e) {
-        if (e != hipSuccess && !error)
-            error = hip_message(e);
+    // The block's last word: the low half tells the other ranks how many of this rank's queries outgrew their scratch (rare;
+    // their results are not in the block yet) — copied device to device from the search's own counter, nobody waits — and the
+    // top bit that this rank has failed. A device that cannot even take these copies cannot enter the collective: tear down.
+    std::uint64_t* own_word = reinterpret_cast<std::uint64_t*>(h_flags_) + world_; // pinned staging word of this rank
+    auto device_failed = [&](hipError_t e) -> const char* {
+        if (began)
+            (void)shard->search_finish(call, nullptr);
+        abort_transport();
+        return local ? local : hip_message(e);
     };
-    guard(hipMemsetAsync(d_send_ + layout.flags, 0, 8, stream));
-    if (call.workspace && !call.done)
-        guard(hipMemcpyAsync(d_send_ + layout.flags, call.workspace->d_queue + 1, 4, hipMemcpyDeviceToDevice, stream));
+    auto post_own_word = [&](std::uint64_t word) -> hipError_t {
+        *own_word = word;
+        return hipMemcpyAsync(d_send_ + layout.flags, own_word, 8, hipMemcpyHostToDevice, stream);
+    };
+    if (hipError_t e = post_own_word(local ? abort_word() : 0); e != hipSuccess)
+        return device_failed(e);
+    if (began && call.workspace && !call.done)
+        if (hipError_t e = hipMemcpyAsync(d_send_ + layout.flags, call.workspace->d_queue + 1, 4, hipMemcpyDeviceToDevice, stream);
+            e != hipSuccess)
+            return device_failed(e);
     const std::uint8_t* gathered = world_ == 1 ? d_send_ : d_gathered_;
+    std::uint64_t* flags = reinterpret_cast<std::uint64_t*>(h_flags_);
+    // all-gather → merge → every rank's flag word strided out of the gathered blocks. An error in here is the transport's or
+    // the device's own: there is nothing left to agree over.
     auto exchange_and_merge = [&]() -> const char* {
         if (begin)
             UA_HIP(hipEventRecord(begin, stream));
@@ -397,36 +472,44 @@ const char* comm_t::search(snapshot_t* shard, void* queries, std::size_t count, 
             return e;
         if (end)
             UA_HIP(hipEventRecord(end, stream));
+        UA_HIP(hipMemcpy2DAsync(flags, 8, gathered + layout.flags, layout.bytes, 8, (std::size_t)world_, hipMemcpyDeviceToHost,
+                                stream));
         return nullptr;
     };
-    if (!error)
-        error = exchange_and_merge();
-    if (!error) // every rank's flag word, strided out of the gathered blocks
-        guard(hipMemcpy2DAsync(h_flags_, 8, gathered + layout.flags, layout.bytes, 8, (std::size_t)world_,
-                               hipMemcpyDeviceToHost, stream));
+    const char* transport_error = exchange_and_merge();
     // ---- the one wait of the step (inside search_finish), plus this rank's scratch ladder if it had overflows
-    search_stats_t local;
-    const char* finish_error = shard->search_finish(call, &local);
-    if (!error)
-        error = finish_error;
+    search_stats_t local_stats;
+    const char* finish_error = nullptr;
+    if (began)
+        finish_error = shard->search_finish(call, &local_stats);
+    else if (hipError_t e = hipStreamSynchronize(stream); e != hipSuccess && !transport_error)
+        transport_error = hip_message(e);
     if (stats)
-        *stats = local;
-    if (error)
-        return error;
-    // ---- rare: some rank's block was incomplete. All ranks saw the same flag words, so all of them repeat the exchange;
-    //      by now every ladder has run and every block is whole.
-    bool incomplete = false;
-    for (int r = 0; r < world_; ++r)
-        incomplete |= reinterpret_cast<const std::uint64_t*>(h_flags_)[r] != 0;
-    if (incomplete) {
+        *stats = local_stats;
+    if (transport_error)
+        return local ? local : transport_error;
+    if (step)
+        step->exchanges = 1;
+    if (any(flags, flag_abort_k))
+        return abort_message(flags, local);
+    // ---- rare: some rank's block was incomplete. All ranks saw the same flag words, so all of them repeat the exchange; by now
+    //      every ladder has run and every block is whole — or that rank's ladder failed, which the second flag word says.
+    if (any(flags, flag_overflow_mask_k)) {
         if (step)
             step->exchanges = 2;
-        UA_HIP(hipMemsetAsync(d_send_ + layout.flags, 0, 8, stream));
+        if (finish_error)
+            local = finish_error, stage = stage_ladder_k;
+        if (hipError_t e = post_own_word(finish_error ? abort_word() : 0); e != hipSuccess) {
+            abort_transport();
+            return local ? local : hip_message(e);
+        }
         if (const char* e = exchange_and_merge())
-            return e;
+            return local ? local : e;
         UA_HIP(hipStreamSynchronize(stream));
-    } else if (step) {
-        step->exchanges = 1;
+        if (any(flags, flag_abort_k))
+            return abort_message(flags, local);
+    } else if (finish_error) {
+        return finish_error; // this rank's own trouble after a complete exchange (the peers hold whole results)
     }
     if (step && begin) {
         UA_HIP(hipEventSynchronize(end));

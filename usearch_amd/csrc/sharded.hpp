@@ -40,6 +40,13 @@ struct sharded_stats_t {
     std::uint32_t exchanges = 0;      ///< 1, or 2 when some rank's scratch ladder ran after the first exchange
 };
 
+/// The flag word that closes a rank's block. Low half: how many of its queries outgrew their scratch (their results are not in
+/// the block yet — every rank then repeats the exchange once the retry ladders have run). Top bit: the rank has FAILED — it
+/// entered the collective only to say so, and every rank leaves the step with an error. Bits 32-47: where it failed.
+constexpr std::uint64_t flag_abort_k = 1ull << 63;
+constexpr std::uint64_t flag_overflow_mask_k = 0xFFFFFFFFull;
+enum abort_stage_t : unsigned { stage_broadcast_k = 1, stage_search_k = 2, stage_ladder_k = 3 };
+
 enum transport_kind_t : int { transport_none_k = 0, transport_rccl_k = 1, transport_custom_k = 2 };
 
 class comm_t {
@@ -75,10 +82,13 @@ class comm_t {
   private:
     const char* reserve(std::size_t block_bytes);
     const char* all_gather(std::size_t bytes, hipStream_t stream);
+    const char* abort_message(const std::uint64_t* flags, const char* local) const;
+    void abort_transport();
 
     int rank_ = 0, world_ = 1, device_ = 0;
     transport_kind_t kind_ = transport_none_k;
     bool on_device_ = true;
+    bool broken_ = false; ///< a rank-local failure made entering a collective impossible: the transport was aborted
     void* rccl_comm_ = nullptr;
     transport_t transport_{};
     std::mutex mutex_;

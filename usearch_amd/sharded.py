@@ -318,12 +318,39 @@ def gpu_searcher(index, rank: int, world: int, device: int, stream: int = 0, gro
             dist.broadcast(torch.from_numpy(buffer), src=root, group=group)
 
         return ShardedSearcher(index, Communicator.over_host_collectives(rank, world, device, all_gather, broadcast), stream)
+
+    def agree(ok: bool) -> bool:
+        """Every rank learns whether EVERY rank said yes: the choice of transport is collective, a rank that fell back on its
+        own would sit in torch.distributed's all-gather while its peers sit in RCCL's."""
+        if world == 1:
+            return ok
+        votes = [None] * world
+        dist.all_gather_object(votes, bool(ok), group=group)
+        return all(votes)
+
     if prefer == "rccl":
+        import sys
+        # 1. can every rank reach RCCL at all (the library resolves at run time)? Asked BEFORE the collective initialisation,
+        #    which a rank without the library would never enter
+        available, why = True, ""
         try:
-            communicator = Communicator.rccl(rank, world, device, share_id)
-        except RuntimeError as error:
-            import sys
-            print(f"[usearch_amd] native RCCL unavailable on rank {rank} ({error}); using torch.distributed", file=sys.stderr)
+            probe, err = (C.c_uint8 * 128)(), C.c_char_p()
+            _bind(binding.library()).usearch_amd_comm_unique_id(probe, C.byref(err))
+            available, why = not err.value, (err.value or b"").decode()
+        except Exception as error:  # noqa: BLE001 — the binding itself is missing: same answer
+            available, why = False, str(error)
+        if not agree(available):
+            print(f"[usearch_amd] native RCCL unavailable on some rank (rank {rank}: {why or 'ok'}); every rank uses "
+                  f"torch.distributed", file=sys.stderr)
+        else:
+            # 2. the initialisation itself, then agreement again: one rank's failure moves everyone to the fallback
+            try:
+                communicator = Communicator.rccl(rank, world, device, share_id)
+            except RuntimeError as error:
+                print(f"[usearch_amd] native RCCL failed to initialise on rank {rank} ({error})", file=sys.stderr)
+            if not agree(communicator is not None):
+                communicator = None
+                print(f"[usearch_amd] rank {rank}: every rank uses torch.distributed", file=sys.stderr)
     if communicator is None:
         communicator = Communicator.over_torch(rank, world, device, group)
     return ShardedSearcher(index, communicator, stream)
