@@ -25,7 +25,8 @@ struct search_tuning_t {
     std::uint32_t hash_cap = 0;     ///< visited-set cells per query (power of two)
     std::uint32_t next_cap = 0;     ///< frontier capacity per query
     std::uint32_t variant = 0;      ///< 0 = auto, else 1 + kernel_variant_t (loads in flight per lane vs waves per SIMD)
-    std::uint32_t mode = 0;         ///< 0 = auto, 1 = visited set in LDS, 2 = visited set in a global hash, 3 = all-global fallback
+    std::uint32_t mode = 0;         ///< 0 = auto, 1 = visited set in LDS, 2 = visited set in a global hash, 3 = all-global fallback,
+                                    ///< 4 = the two-queries-per-wave short-row walk (pair_kernels.hpp; refused where it does not apply)
     std::uint32_t waves_per_cu = 0; ///< persistent waves per compute unit (0 = as many as LDS / registers admit)
     std::uint32_t top_in_memory = 0; ///< 1 = keep `top` in scratch memory even when it would fit registers
     std::uint32_t frontier = 0;     ///< 0 = auto, 1 = the reference's heap (its pop order among equal distances), 2 = the open
@@ -38,7 +39,8 @@ struct search_stats_t {
     std::uint32_t retried_lds = 0;       ///< queries rerun with the enlarged LDS scratch
     std::uint32_t retried_global = 0;    ///< queries rerun with the global-memory scratch
     float kernel_ms = 0.f;               ///< HIP-event time of the search launches of this call (when `timed`)
-    std::uint32_t mode = 0;              ///< scratch mode of the last launch (1 = LDS, 2 = global hash, 3 = all global)
+    std::uint32_t mode = 0;              ///< scratch mode of the last launch (1 = LDS, 2 = global hash, 3 = all global; 4 = the
+                                         ///< two-queries-per-wave walk, visited set in LDS)
     std::uint32_t grid = 0;              ///< persistent waves of the last launch
     std::uint32_t lds_bytes = 0;         ///< LDS per wave of the last launch
     std::uint32_t frontier = 0;          ///< 1 = heap, 2 = open cells of `top` (first launch)
@@ -70,6 +72,8 @@ struct launch_params_t {
     std::uint32_t grid;
     std::uint32_t lds_bytes;
     hipStream_t stream;
+    std::uint32_t pair = 0;       ///< 0 = one query per wave; 1 = two (pair_kernels.hpp)
+    std::uint32_t pair_cells = 0; ///< register cells of `top` per lane in that kernel (2 or 4)
 };
 
 /**
@@ -148,6 +152,7 @@ class snapshot_t {
         std::size_t count = 0;
         std::uint32_t ef = 0, hash_cap = 0, next_cap = 0, query_lds = 0, entries_per_lane = 0, waves_cap = 0;
         int mode = 0;
+        std::uint32_t pair = 0; ///< 1 = the first rung runs the two-queries-per-wave walk
         bool timed = false, want_phases = false, want_clock = false, done = false, reran = false;
         bool keep_workspace = false; ///< search_finish leaves the workspace with the caller (who gives it back)
         float total_ms = 0.f;

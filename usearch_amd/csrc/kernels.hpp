@@ -1509,6 +1509,8 @@ constexpr int kernel_waves(int variant, int epl, int frontier = 0, int lanes = 8
         return 2;
     if (variant == variant_u4_w4_k && epl == 1 && lanes <= 2)
         return lanes == 1 ? USEARCH_AMD_TINY_ROW_WAVES : USEARCH_AMD_SHORT_ROW_WAVES;
+    if (variant == variant_u4_w4_k && epl == 2 && lanes <= 2) // expansion 65 … 128 on short rows (C4 needs 80)
+        return USEARCH_AMD_SHORT_ROW_WAVES;
     if (frontier) // without the heap's bookkeeping the 4-deep build fits 128 registers with any `top`
         return variant == variant_u4_w4_k ? 4 : variant == variant_u8_w3_k ? 3 : 2;
     return variant == variant_u4_w4_k ? (epl >= 8 ? 3 : 4) : variant == variant_u8_w3_k ? (epl >= 16 ? 2 : 3) : 2;

@@ -6,6 +6,7 @@
 #include "build_kernels.hpp"
 #include "engine.hpp"
 #include "kernels.hpp"
+#include "pair_kernels.hpp"
 
 namespace usearch_amd {
 
@@ -40,12 +41,18 @@ hipError_t launch_search_frontier(const launch_params_t& p, const snapshot_view_
         return launch_search_one<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, epl_ak, frontier_heap_k>(p, view, args);
 }
 
-/// `top` in registers with 1 / 4 / 8 / 16 entries per lane (expansion ≤ 64 / 256 / 512 / 1024), or in scratch memory (0).
+/// `top` in registers with 1 / 2 / 4 / 8 / 16 entries per lane (expansion ≤ 64 / 128 (short rows) / 256 / 512 / 1024), or in scratch
+/// memory (0).
 template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak>
 hipError_t launch_search_epl(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
     switch (p.entries_per_lane) {
     case 0: return launch_search_frontier<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 0>(p, view, args);
     case 1: return launch_search_frontier<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 1>(p, view, args);
+    case 2: // rows of ≤ 128 bytes at 64 < expansion ≤ 128: two cells per lane keep the build inside the short-row register budget
+        if constexpr (lanes_ak <= 2 && variant_ak == variant_u4_w4_k)
+            return launch_search_frontier<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 2>(p, view, args);
+        else
+            return hipErrorInvalidValue;
     case 4: return launch_search_frontier<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 4>(p, view, args);
     case 8: return launch_search_frontier<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 8>(p, view, args);
     case 16: return launch_search_frontier<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, 16>(p, view, args);
@@ -84,8 +91,45 @@ hipError_t launch_search_lanes(const launch_params_t& p, const snapshot_view_t& 
     return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u4_w4_k>(p, view, args);
 }
 
+/// The two-queries-per-wave walk (pair_kernels.hpp): integer-valued pairs only.
+template <int metric_ak, int scalar_ak, int cells_ak, bool inline_ak>
+hipError_t launch_pair_one(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
+    auto kernel = pair_search_kernel<metric_ak, scalar_ak, cells_ak, inline_ak>;
+    if (p.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+        if (e != hipSuccess)
+            return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(p.grid), dim3(64), p.lds_bytes, p.stream, view, args);
+    return hipGetLastError();
+}
+
+template <int metric_ak, int scalar_ak, int cells_ak>
+hipError_t launch_pair_rows(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
+    // rows that travel with the lists exist for one-chunk rows only; among the integer-valued pairs that is b1 (≤ 128 bits)
+    if constexpr (scalar_ak == scalar_b1x8_k) {
+        if (view.nbr0_rows && view.chunks == 1)
+            return launch_pair_one<metric_ak, scalar_ak, cells_ak, true>(p, view, args);
+    }
+    return launch_pair_one<metric_ak, scalar_ak, cells_ak, false>(p, view, args);
+}
+
+template <int metric_ak, int scalar_ak>
+hipError_t launch_pair_metric(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
+    if constexpr (scalar_ak == scalar_b1x8_k || scalar_ak == scalar_i8_k) {
+        if (p.pair_cells == 2)
+            return launch_pair_rows<metric_ak, scalar_ak, 2>(p, view, args);
+        if (p.pair_cells == 4)
+            return launch_pair_rows<metric_ak, scalar_ak, 4>(p, view, args);
+    }
+    return hipErrorInvalidValue;
+}
+
 template <int metric_ak, int scalar_ak>
 hipError_t launch_search_metric(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
+    if (p.pair)
+        return launch_pair_metric<metric_ak, scalar_ak>(p, view, args);
     switch (p.lanes) {
     case 1: return launch_search_lanes<metric_ak, scalar_ak, 1>(p, view, args);
     case 2: return launch_search_lanes<metric_ak, scalar_ak, 2>(p, view, args);
