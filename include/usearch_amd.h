@@ -112,6 +112,19 @@ USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_bytes_per_vector(usearch_amd_snap
 USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_row_stride(usearch_amd_snapshot_t snapshot);
 /** Bytes of HBM the snapshot occupies (cf. `usearch_memory_usage`, c/usearch.h:139). */
 USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_device_bytes(usearch_amd_snapshot_t snapshot);
+/** How the matrix of stored rows was placed in HBM. Where a multi-gigabyte array lands decides how fast random rows can be
+ *  gathered from it (the headline walk: 45.4 … 51.9 ms for the same bytes), so the loader and the builder draw a few placements,
+ *  time a dependency-free gather on each and keep the fastest (csrc/placement.hpp; USEARCH_AMD_PLACEMENT_DRAWS, default 6; arrays
+ *  under USEARCH_AMD_PLACEMENT_MIN_BYTES = 1 GiB take the first). `gather_gbps` receives up to 8 rates, `*kept` which draw won. */
+USEARCH_AMD_EXPORT void usearch_amd_snapshot_placement(usearch_amd_snapshot_t snapshot, uint32_t* draws, uint32_t* kept,
+                                                       float* gather_gbps, float* probe_ms);
+/** The placement probe alone, on the resident matrix or a part of it: GB/s of a dependency-free gather of random stored rows
+ *  among rows [first_row, first_row + rows) (`rows` = 0: to the end). Diagnostics (scripts/placement_study.py). */
+USEARCH_AMD_EXPORT float usearch_amd_snapshot_gather_probe(usearch_amd_snapshot_t snapshot, uint64_t first_row, uint64_t rows,
+                                                           usearch_amd_error_t* error);
+/** A probe of the address-translation path over the resident matrix: million touches per second of random 4-KB pages, 16 bytes
+ *  each (csrc/placement.hpp `translation_probe`). Diagnostics. */
+USEARCH_AMD_EXPORT float usearch_amd_snapshot_translation_probe(usearch_amd_snapshot_t snapshot, usearch_amd_error_t* error);
 /** Storage scalar kind (C enumerator) and metric kind (`usearch_metric_kind_t` value, c/usearch.h:40-52). */
 USEARCH_AMD_EXPORT int usearch_amd_snapshot_scalar_kind(usearch_amd_snapshot_t snapshot);
 USEARCH_AMD_EXPORT int usearch_amd_snapshot_metric_kind(usearch_amd_snapshot_t snapshot);
@@ -357,15 +370,6 @@ USEARCH_AMD_EXPORT void usearch_amd_distances(usearch_amd_snapshot_t snapshot, v
 /** HIP-event duration of the kernel of the most recent `usearch_amd_distances` call: the dependency-free row-gather rate,
  *  i.e. the ceiling the search kernel's distance phase is measured against. */
 USEARCH_AMD_EXPORT float usearch_amd_last_distances_ms(usearch_amd_snapshot_t snapshot);
-
-/**
- *  Self-test hook: replays `count` scripted operations on the device-side containers (kind 0 = frontier push of
- *  {keys[i], slots[i]}, 1 = frontier pop, 2 = insert {keys[i], slots[i]} into the result buffer limited to `limit`) and
- *  returns what was popped and the final result buffer, each entry packed as (slot << 32 | float bits).
- */
-USEARCH_AMD_EXPORT void usearch_amd_test_containers(uint32_t const* kinds, float const* keys, uint32_t const* slots,
-                                                    size_t count, size_t limit, uint64_t* popped, size_t* popped_count,
-                                                    uint64_t* top, size_t* top_count, usearch_amd_error_t* error);
 
 /**
  *  Host-side query cast used by `usearch_amd_search_many` (index_plugins.hpp:1105-1224). Returns 0 when the kinds are

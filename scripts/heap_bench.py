@@ -10,7 +10,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import usearch_amd  # noqa: E402
 
-L = usearch_amd.library()
+import usearch_amd.index
+L = usearch_amd.index.test_hooks()  # the containers' micro-benchmarks live in their own library (csrc/test_hooks.hip)
 L.usearch_amd_bench_heap.argtypes = [C.c_uint32] * 4 + [C.c_void_p] * 3 + [C.POINTER(C.c_char_p)]
 for fill in (200, 1000, 2000):
     for waves in (1, 2048):

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""scripts/placement_study.py — does the engine's millisecond gather probe predict the speed of the real walk, and where inside a
+slow placement does the time go? One GPU, the headline index (10M x 768 f16) built once, its image restored several times with
+the earlier copies still held (so that every copy lands elsewhere).
+
+    for each copy:  probe GB/s of the whole matrix · of each eighth of it · the headline batch (10 000 queries, ef 608) in ms
+
+Development tool (profiles/r03_placement/ keeps its output)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--n", type=int, default=10_000_000)
+    p.add_argument("--dim", type=int, default=768)
+    p.add_argument("--dtype", default="f16")
+    p.add_argument("--queries", type=int, default=10_000)
+    p.add_argument("--ef", type=int, default=608)
+    p.add_argument("--copies", type=int, default=6)
+    p.add_argument("--parts", type=int, default=8)
+    p.add_argument("--no-engine-draws", action="store_true")
+    p.add_argument("--chunks-mb", type=int, nargs="+", default=[0],
+                   help="also place the matrix through the virtual-memory API in physical chunks of this many MB (0 = hipMalloc)")
+    args = p.parse_args()
+    metric = "hamming" if args.dtype == "b1" else "l2sq" if args.dtype == "i8" else "cos"
+
+    import torch
+    import usearch_amd
+
+    device = torch.device("cuda", 0)
+    data = bench.synthetic_vectors_device(args.n, args.dim, args.dtype, 42, device)
+    t0 = time.time()
+    os.environ["USEARCH_AMD_PLACEMENT_DRAWS"] = "1"
+    built = usearch_amd.build(None, metric, args.dtype, device_pointer=data.data_ptr(), count=args.n, stride=data.stride(0),
+                              ndim=args.dim)
+    print(f"GPU-built {args.n} in {time.time() - t0:.1f}s", flush=True)
+    del data
+    image = built.save_buffer()
+    del built
+    torch.cuda.empty_cache()
+
+    queries = bench.synthetic_vectors_device(args.queries, args.dim, args.dtype, 43, device)
+    keys = torch.zeros((args.queries, 10), dtype=torch.int64, device=device)
+    dists = torch.zeros((args.queries, 10), dtype=torch.float32, device=device)
+    counts = torch.zeros(args.queries, dtype=torch.int64, device=device)
+    visited = torch.zeros(args.queries, dtype=torch.int64, device=device)
+    computed = torch.zeros(args.queries, dtype=torch.int64, device=device)
+
+    def batch_ms(index) -> float:
+        times = []
+        for step in range(4):
+            stats = index.search_device(queries.data_ptr(), args.queries, queries.stride(0), 10, args.ef, keys.data_ptr(),
+                                        dists.data_ptr(), counts.data_ptr(), visited.data_ptr(), computed.data_ptr(), timed=True)
+            if step:
+                times.append(stats.kernel_ms)
+        return min(times)
+
+    rows_per_part = args.n // args.parts
+    for chunk_mb in args.chunks_mb:
+        os.environ["USEARCH_AMD_VMM_CHUNK_MB"] = str(chunk_mb)
+        held = []
+        print(f"--- matrix placed by {'hipMalloc' if not chunk_mb else f'hipMemCreate chunks of {chunk_mb} MB'}", flush=True)
+        print("copy  load s  gather GB/s (x2)  pages M/s   batch ms   gather GB/s of each part", flush=True)
+        for copy in range(args.copies):
+            t0 = time.time()
+            try:
+                index = usearch_amd.Index.restore(image)
+            except RuntimeError as error:
+                print(f"{copy:4d}  restore failed: {error}", flush=True)
+                break
+            load_s = time.time() - t0
+            held.append(index)
+            whole = index.gather_probe()
+            pages = index.translation_probe()
+            parts = [index.gather_probe(i * rows_per_part, rows_per_part) for i in range(args.parts)] if args.parts > 1 else []
+            ms = batch_ms(index)
+            whole_again = index.gather_probe()
+            print(f"{copy:4d}  {load_s:6.2f}  {whole:8.0f} {whole_again:8.0f}  {pages:9.0f}   {ms:8.3f}   " +
+                  " ".join(f"{r:6.0f}" for r in parts), flush=True)
+        for index in held:
+            index.close()
+        held.clear()
+        torch.cuda.empty_cache()
+    os.environ["USEARCH_AMD_VMM_CHUNK_MB"] = "0"
+    # the engine's own choice
+    for draws in (() if args.no_engine_draws else (6, 6, 1, 1)):
+        os.environ["USEARCH_AMD_PLACEMENT_DRAWS"] = str(draws)
+        t0 = time.time()
+        index = usearch_amd.Index.restore(image)
+        load_s = time.time() - t0
+        print(f"draws={draws}: placement {index.placement}  load {load_s:.2f}s  batch {batch_ms(index):.3f} ms", flush=True)
+        index.close()
+
+
+if __name__ == "__main__":
+    main()

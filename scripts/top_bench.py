@@ -9,7 +9,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import usearch_amd  # noqa: E402
 
-L = usearch_amd.library()
+import usearch_amd.index
+L = usearch_amd.index.test_hooks()  # the containers' micro-benchmarks live in their own library (csrc/test_hooks.hip)
 L.usearch_amd_bench_top.argtypes = [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p)]
 for epl, limit in ((4, 256), (8, 512), (16, 640), (16, 1024)):
     for waves in (1, 256, 2048, 4096):

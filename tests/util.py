@@ -79,6 +79,46 @@ def tolerance(dtype: str) -> float:
     return 2e-3 if dtype in ("f16", "bf16") else 1e-5
 
 
+def separated_positions(reference_distances: np.ndarray, reference_counts: np.ndarray, k: int, dtype: str) -> np.ndarray:
+    """SURVEY §8(d)'s label rule made checkable. `reference_distances` are the reference's k + 1 nearest per query (one more
+    than asked, so that the k-th result has a right-hand neighbour). → bool [Q, k]: position i is SEPARATED when the
+    reference's own neighbouring distances (i - 1 and i + 1, as far as they exist) are farther from distance i than twice the
+    stated tolerance — both sides' rounding together cannot reorder such a position, so its label must be identical."""
+    rd = np.asarray(reference_distances, dtype=np.float64)
+    q, width = rd.shape
+    assert width >= k + 1 or width == k, "pass the reference's k + 1 nearest"
+    found = np.arange(width)[None, :] < np.asarray(reference_counts)[:, None]
+    gap = 2.0 * tolerance(dtype) * np.maximum(1.0, np.abs(np.where(found, rd, 0.0)))
+    separated = found.copy()
+    left = np.abs(rd[:, 1:] - rd[:, :-1])  # |d[i+1] - d[i]|
+    both = found[:, 1:] & found[:, :-1]
+    close = both & ~(left > np.maximum(gap[:, 1:], gap[:, :-1]))
+    separated[:, 1:] &= ~close   # too close to its left neighbour
+    separated[:, :-1] &= ~close  # too close to its right neighbour
+    return separated[:, :k]
+
+
+def assert_float_parity(got_keys, got_distances, got_counts, reference_search, queries, k: int, dtype: str, what: str = ""):
+    """The float-pair bar against the REAL reference: counts equal; every distance within the stated tolerance; labels
+    IDENTICAL at every separated position (see `separated_positions`). `reference_search(queries, k)` → the reference's
+    (keys, distances, counts, …). Returns (share of positions that are separated, label agreement on ALL positions)."""
+    rkeys1, rdists1, rcounts1 = reference_search(queries, k + 1)[:3]
+    rkeys, rdists, rcounts = reference_search(queries, k)[:3]
+    assert np.array_equal(got_counts, rcounts), f"{what}: counts differ from the reference's"
+    found = np.arange(k)[None, :] < np.asarray(rcounts)[:, None]
+    scale = np.maximum(1.0, np.abs(np.where(found, rdists, 0)))
+    error = np.abs(np.where(found, np.asarray(got_distances, dtype=np.float64) - rdists, 0))
+    assert np.all(error <= tolerance(dtype) * scale), f"{what}: a distance is off by {error.max():.3g}"
+    separated = separated_positions(rdists1, rcounts1, k, dtype) & found
+    # the reference's k and k + 1 searches agree on the first k wherever THEY are separated (same traversal, same ef >= k + 1
+    # or not — if they did not, the position says nothing about the GPU)
+    separated &= rkeys1[:, :k] == rkeys
+    wrong = separated & (np.asarray(got_keys) != rkeys)
+    assert not wrong.any(), (f"{what}: {int(wrong.sum())} of {int(separated.sum())} separated positions carry another label than "
+                             f"the reference's; first at query {np.argwhere(wrong)[0][0]} position {np.argwhere(wrong)[0][1]}")
+    return float(separated.sum() / max(1, found.sum())), float(((np.asarray(got_keys) == rkeys) | ~found).mean())
+
+
 def same_float_bits(a: np.ndarray, b: np.ndarray) -> bool:
     return np.array_equal(np.asarray(a, dtype=np.float32).view(np.uint32), np.asarray(b, dtype=np.float32).view(np.uint32))
 

@@ -115,13 +115,22 @@ const char* snapshot_t::grow_for_build(std::uint64_t capacity, std::uint64_t lis
         if (array.new_bytes == array.old_bytes && *array.pointer)
             continue;
         void* fresh = nullptr;
-        UA_HIP(hipMalloc(&fresh, std::max<std::size_t>(array.new_bytes, 16)));
+        if (array.pointer == &d_vectors_) // the arrays the walk gathers from are placed with care (placement.hpp)
+            UA_HIP(placed_malloc(&fresh, array.new_bytes, row_stride, &placement_));
+        else if (array.pointer == &d_nbr0_)
+            UA_HIP(placed_malloc(&fresh, array.new_bytes, (std::size_t)m0 * 4, nullptr));
+        else
+            UA_HIP(hipMalloc(&fresh, std::max<std::size_t>(array.new_bytes, 16)));
         if (array.old_bytes && *array.pointer)
             UA_HIP(hipMemcpy(fresh, *array.pointer, array.old_bytes, hipMemcpyDeviceToDevice));
         if (array.new_bytes > array.old_bytes)
             UA_HIP(hipMemset(static_cast<std::uint8_t*>(fresh) + array.old_bytes, array.fill, array.new_bytes - array.old_bytes));
-        if (*array.pointer)
-            (void)hipFree(*array.pointer);
+        if (*array.pointer) {
+            if (array.pointer == &d_vectors_ || array.pointer == &d_nbr0_)
+                placed_free(*array.pointer);
+            else
+                (void)hipFree(*array.pointer);
+        }
         *array.pointer = fresh;
         device_bytes_ += std::max<std::size_t>(array.new_bytes, 16) - (array.old_bytes ? std::max<std::size_t>(array.old_bytes, 16) : 0);
     }

@@ -221,7 +221,11 @@ void snapshot_t::release() {
     if (!d_vectors_ && !d_nbr0_ && workspaces_.empty() && !stream_)
         return;
     (void)hipSetDevice(device_);
-    for (void* p : {d_vectors_, d_nbr0_, d_upper_ref_, d_upper_, d_keys_, d_nbr0_rows_})
+    for (void** p : {&d_vectors_, &d_nbr0_, &d_nbr0_rows_}) { // the gathered arrays may be mapped memory (placement.hpp)
+        placed_free(*p);
+        *p = nullptr;
+    }
+    for (void* p : {d_upper_ref_, d_upper_, d_keys_})
         if (p)
             (void)hipFree(p);
     {
@@ -253,7 +257,7 @@ __global__ void inline_rows_kernel(const std::uint8_t* vectors, const std::uint3
 
 const char* snapshot_t::finalize_layout() {
     if (d_nbr0_rows_) {
-        (void)hipFree(d_nbr0_rows_);
+        placed_free(d_nbr0_rows_);
         device_bytes_ -= std::min<std::size_t>(device_bytes_, (std::size_t)view_.size * view_.m0 * 16);
         d_nbr0_rows_ = nullptr;
         view_.nbr0_rows = nullptr;
@@ -262,7 +266,7 @@ const char* snapshot_t::finalize_layout() {
         return nullptr;
     UA_HIP(hipSetDevice(device_));
     const std::uint64_t cells = view_.size * view_.m0;
-    UA_HIP(hipMalloc(&d_nbr0_rows_, cells * 16));
+    UA_HIP(placed_malloc(&d_nbr0_rows_, cells * 16, (std::size_t)view_.m0 * 16, nullptr)); // what a hop gathers: one block
     device_bytes_ += cells * 16;
     const std::uint64_t blocks = std::min<std::uint64_t>((cells + 255) / 256, 1u << 22);
     hipLaunchKernelGGL(inline_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream_, view_.vectors, view_.nbr0,
@@ -384,7 +388,7 @@ const char* snapshot_t::build(const image_t& image, int device) {
     const std::uint32_t bpv = (std::uint32_t)image.cols;
     std::uint32_t row_stride = 0, row_chunks = 0;
     row_geometry(bpv, lanes_, row_stride, row_chunks);
-    if (n && image.level(image.entry_slot) < (std::int16_t)image.max_level)
+    if (n && (image.max_level > 0x7FFF || (std::int64_t)image.level(image.entry_slot) < (std::int64_t)image.max_level))
         return "Failed to pull the header from the stream";
 
     // ---- scratch that lives for the load only: levels, tape bytes, the two prefix sums
@@ -449,8 +453,11 @@ const char* snapshot_t::build(const image_t& image, int device) {
         return hipMalloc(p, std::max<std::size_t>(bytes, 16));
     };
     device_bytes_ = 0;
-    UA_HIP(allocate(&d_vectors_, vectors_bytes));
-    UA_HIP(allocate(&d_nbr0_, (std::size_t)n * m0 * 4));
+    // the matrix the walk gathers rows from takes the best of a few placements (placement.hpp); its size makes it THE array
+    device_bytes_ += std::max<std::size_t>(vectors_bytes, 16);
+    UA_HIP(placed_malloc(&d_vectors_, vectors_bytes, row_stride, &placement_));
+    device_bytes_ += std::max<std::size_t>((std::size_t)n * m0 * 4, 16);
+    UA_HIP(placed_malloc(&d_nbr0_, (std::size_t)n * m0 * 4, (std::size_t)m0 * 4, nullptr));
     UA_HIP(allocate(&d_upper_ref_, (std::size_t)n * 4));
     UA_HIP(allocate(&d_upper_, (std::size_t)std::max<std::uint64_t>(lists, 1) * m * 4));
     UA_HIP(allocate(&d_keys_, (std::size_t)n * 8));
@@ -790,8 +797,10 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         return (std::uint32_t)std::max<std::uint64_t>(
             1, std::min<std::uint64_t>(call.waves_cap, lds_budget / std::max<std::uint64_t>(granule, 1)));
     };
-    auto timed_launch = [&]() -> const char* {
-        UA_HIP(hipMemsetAsync(ws.d_queue, 0, 8, stream));
+    auto timed_launch = [&](bool keep_overflows = false) -> const char* {
+        // [0] the ticket counter, [1] how many queries outgrew their scratch — the latter is read once per rung, so the chunks of
+        // the global rung must not erase what an earlier chunk counted
+        UA_HIP(hipMemsetAsync(ws.d_queue, 0, keep_overflows ? 4 : 8, stream));
         if (call.timed)
             UA_HIP(hipEventRecord(ws.event_begin, stream));
         UA_HIP(launch_search(metric_, scalar_, params, view_, args));
@@ -909,7 +918,7 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         params.frontier = frontier_heap_k;
         params.grid = (std::uint32_t)chunk;
         params.lds_bytes = call.query_lds;
-        if (const char* e = timed_launch())
+        if (const char* e = timed_launch(/*keep_overflows=*/begin != 0))
             return e;
         ++call.passes;
         UA_HIP(hipStreamSynchronize(stream)); // the todo block is reused by the next chunk
@@ -1115,10 +1124,19 @@ const char* snapshot_t::search_host(const void* queries, scalar_kind_t query_kin
     if (const char* e = take(call.workspace))
         return e;
     workspace_t& ws = *call.workspace;
-    if (const char* e = ws.reserve_stage(total, o_allow)) {
-        give_back(call.workspace);
+    // every way out of this function drains the workspace's stream and hands the workspace back to the pool: a kernel must not
+    // outlive the lease of the scratch it runs on, and a lease that is never returned starves `take` for good
+    struct return_lease_t {
+        snapshot_t& owner;
+        workspace_t* workspace;
+        ~return_lease_t() {
+            (void)hipStreamSynchronize(workspace->stream);
+            owner.give_back(workspace);
+        }
+    } return_lease{*this, call.workspace};
+    call.keep_workspace = true; // search_finish leaves it to the guard above
+    if (const char* e = ws.reserve_stage(total, o_allow))
         return e;
-    }
 
     // cast (or gather strided rows) straight into the pinned block, in the storage kind — index_dense.hpp:2058-2064
     const std::uint8_t* source = static_cast<const std::uint8_t*>(queries);
@@ -1149,10 +1167,8 @@ const char* snapshot_t::search_host(const void* queries, scalar_kind_t query_kin
 
     // `call` already holds the workspace: search_begin uses it instead of leasing another one
     if (const char* e = search_begin(call, ws.d_stage, count, bpv, wanted, expansion, d_keys, d_distances, d_counts, d_visited,
-                                     d_computed, stream, tuning, false, &extras)) {
-        give_back(call.workspace);
+                                     d_computed, stream, tuning, false, &extras))
         return e;
-    }
     // results ride home behind the first launch; if a rung of the ladder re-runs queries they are fetched again
     auto download = [&]() -> const char* {
         UA_HIP(hipMemcpyAsync(ws.h_stage + o_keys, ws.d_stage + o_keys, o_allow - o_keys, hipMemcpyDeviceToHost, stream));
@@ -1160,28 +1176,19 @@ const char* snapshot_t::search_host(const void* queries, scalar_kind_t query_kin
     };
     if (const char* e = download())
         return e;
-    workspace_t* leased = call.workspace;
     {
-        // keep the workspace across search_finish (which gives it back): the pinned block is still to be read. Finish
-        // works on a call without a workspace of its own only when nothing was launched, so take the lease over here.
+        // the pinned block is read after search_finish (wait + retry ladder): the workspace stays leased until the copies are out
         search_stats_t local;
-        // search_finish returns the workspace to the pool; copying out of the pinned block must happen before that, so the
-        // finish is split: wait + ladder first (workspace retained), hand-back last.
-        call.keep_workspace = true;
-        if (const char* e = search_finish(call, &local)) {
-            give_back(leased);
+        if (const char* e = search_finish(call, &local))
             return e;
-        }
         if (stats)
             *stats = local;
         if (call.reran) {
             const char* e = download();
             if (!e && hipStreamSynchronize(stream) != hipSuccess)
                 e = "Failed to fetch the results";
-            if (e) {
-                give_back(leased);
+            if (e)
                 return e;
-            }
         }
     }
     if (keys)
@@ -1194,7 +1201,6 @@ const char* snapshot_t::search_host(const void* queries, scalar_kind_t query_kin
         std::memcpy(visited, ws.h_stage + o_visited, count * 8);
     if (computed)
         std::memcpy(computed, ws.h_stage + o_computed, count * 8);
-    give_back(leased);
     return nullptr;
 }
 

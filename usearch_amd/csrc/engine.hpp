@@ -17,6 +17,7 @@
 
 #include "common.hpp"
 #include "image.hpp"
+#include "placement.hpp"
 
 namespace usearch_amd {
 
@@ -126,6 +127,8 @@ class snapshot_t {
     std::uint64_t count_present() const { return count_present_; }
     std::uint64_t upper_lists() const { return upper_lists_; }
     float last_distances_ms() const { return last_distances_ms_; }
+    /// How the matrix of stored rows was placed in HBM (placement.hpp): draws, their gather rates, which one was kept.
+    const placement_t& placement() const { return placement_; }
 
     /**
      *  Batched search, all pointers device-resident, queries already in the storage scalar kind.
@@ -269,6 +272,7 @@ class snapshot_t {
     void* d_nbr0_rows_ = nullptr;
     std::uint64_t build_capacity_ = 0, build_lists_capacity_ = 0; ///< room in the arrays above while an index is under construction
 
+    placement_t placement_{};
     int compute_units_ = 256;
     float last_distances_ms_ = 0.f;
     hipStream_t stream_ = nullptr; ///< the snapshot's own stream: construction and one-off kernels

@@ -80,14 +80,15 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_snapshot_from_parts",
     "usearch_amd_snapshot_free", "usearch_amd_snapshot_size", "usearch_amd_snapshot_dimensions",
     "usearch_amd_snapshot_connectivity", "usearch_amd_snapshot_max_level", "usearch_amd_snapshot_bytes_per_vector",
-    "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_scalar_kind",
+    "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_placement", "usearch_amd_snapshot_gather_probe", "usearch_amd_snapshot_translation_probe",
+    "usearch_amd_snapshot_scalar_kind",
     "usearch_amd_snapshot_metric_kind", "usearch_amd_snapshot_lanes_per_row", "usearch_amd_snapshot_inline_rows",
     "usearch_amd_search_many",
     "usearch_amd_search_many_device", "usearch_amd_last_peaks", "usearch_amd_distances",
     "usearch_amd_last_distances_ms", "usearch_amd_merge_many", "usearch_amd_merge_many_device",
     "usearch_amd_exact_search_many", "usearch_amd_exact_search_many_tiled", "usearch_amd_exact_search_dataset",
     "usearch_amd_cluster_many",
-    "usearch_amd_test_containers", "usearch_amd_cast",
+    "usearch_amd_cast",
     "usearch_amd_build", "usearch_amd_build_free", "usearch_amd_build_snapshot",
     "usearch_amd_build_serialized_length", "usearch_amd_build_save_buffer", "usearch_amd_build_stats",
     # sharded search across GPUs (usearch_amd/sharded.py binds these)
@@ -145,6 +146,13 @@ def library() -> C.CDLL:
         f = getattr(L, f"usearch_amd_snapshot_{name}")
         f.restype = C.c_size_t
         f.argtypes = [C.c_void_p]
+    L.usearch_amd_snapshot_placement.restype = None
+    L.usearch_amd_snapshot_placement.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                                 C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.usearch_amd_snapshot_translation_probe.restype = C.c_float
+    L.usearch_amd_snapshot_translation_probe.argtypes = [C.c_void_p, err_p]
+    L.usearch_amd_snapshot_gather_probe.restype = C.c_float
+    L.usearch_amd_snapshot_gather_probe.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, err_p]
     for name in ("scalar_kind", "metric_kind"):
         f = getattr(L, f"usearch_amd_snapshot_{name}")
         f.restype = C.c_int
@@ -171,8 +179,6 @@ def library() -> C.CDLL:
                                         C.c_void_p, err_p]
     L.usearch_amd_last_distances_ms.restype = C.c_float
     L.usearch_amd_last_distances_ms.argtypes = [C.c_void_p]
-    L.usearch_amd_test_containers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
-                                              C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), err_p]
     L.usearch_amd_cast.restype = C.c_int
     L.usearch_amd_cast.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     L.usearch_amd_build.restype = C.c_void_p
@@ -262,6 +268,8 @@ class Index:
         L = library()
         err = C.c_char_p()
         if vectors is not None:
+            if isinstance(source, (str, os.PathLike)):  # the graph alone sits in the file: map it for the call
+                source = np.memmap(os.fspath(source), dtype=np.uint8, mode="r")
             image = np.ascontiguousarray(np.frombuffer(source, dtype=np.uint8)
                                          if not isinstance(source, np.ndarray) else source, dtype=np.uint8)
             vectors = np.asarray(vectors)
@@ -318,11 +326,15 @@ class Index:
                 candidates.append(candidate)
                 timings.append(float("inf"))  # in the list before the probe runs: a failing probe still gets it released
                 timings[-1] = float(probe(candidate))
-        finally:
-            kept = int(np.argmin(timings)) if timings else -1
-            for i, candidate in enumerate(candidates):
-                if i != kept and candidate is not None and candidate is not first:
+        except BaseException:
+            for candidate in candidates:  # nothing is handed out on this path: every copy made here goes, `first` stays the caller's
+                if candidate is not None and candidate is not first:
                     candidate.close()
+            raise
+        kept = int(np.argmin(timings))
+        for i, candidate in enumerate(candidates):
+            if i != kept and candidate is not None and candidate is not first:
+                candidate.close()
         return candidates[kept], {"probe_ms": [round(t, 3) for t in timings], "kept": kept}
 
     def close(self) -> None:
@@ -338,6 +350,30 @@ class Index:
             self.close()
         except Exception:
             pass
+
+    @property
+    def placement(self) -> dict:
+        """How the engine placed the matrix of stored rows in HBM (csrc/placement.hpp): the gather rate of every draw and which
+        one was kept; `draws == 0` for arrays too small to bother."""
+        draws, kept, probe_ms = C.c_uint32(), C.c_uint32(), C.c_float()
+        rates = (C.c_float * 8)()
+        library().usearch_amd_snapshot_placement(self._handle, C.byref(draws), C.byref(kept), rates, C.byref(probe_ms))
+        return {"draws": int(draws.value), "kept": int(kept.value), "probe_ms": round(float(probe_ms.value), 2),
+                "gather_gbps": [round(float(rates[i]), 1) for i in range(draws.value)]}
+
+    def translation_probe(self) -> float:
+        """Million random 4-KB pages of the resident matrix touched per second (16 bytes each): the address-translation path."""
+        err = C.c_char_p()
+        rate = library().usearch_amd_snapshot_translation_probe(self._handle, C.byref(err))
+        _raise(err, "usearch_amd_snapshot_translation_probe")
+        return float(rate)
+
+    def gather_probe(self, first_row: int = 0, rows: int = 0) -> float:
+        """GB/s of the engine's placement probe — random stored rows, no dependencies — over rows [first_row, first_row + rows)."""
+        err = C.c_char_p()
+        rate = library().usearch_amd_snapshot_gather_probe(self._handle, first_row, rows, C.byref(err))
+        _raise(err, "usearch_amd_snapshot_gather_probe")
+        return float(rate)
 
     # ---- introspection (names of usearch.index.Index properties, index.py:1180-1300)
     def __len__(self) -> int:
@@ -650,6 +686,25 @@ def cast(vector: np.ndarray, from_dtype: str, to_dtype: str, ndim: int) -> Optio
     return out if done else None
 
 
+TEST_HOOKS_PATH = os.path.join(os.path.dirname(LIBRARY_PATH), "libusearch_amd_testhooks.so")
+_test_hooks = None
+
+
+def test_hooks() -> C.CDLL:
+    """The self-test / micro-benchmark entry points of the device containers: their own library (csrc/test_hooks.hip), which the
+    product library does not carry."""
+    global _test_hooks
+    if _test_hooks is None:
+        library()  # one HIP runtime per process, mapped by the product library's loader
+        if not os.path.exists(TEST_HOOKS_PATH):
+            raise RuntimeError(f"{TEST_HOOKS_PATH} is missing: build it with `make -C usearch_amd/csrc`")
+        _test_hooks = C.CDLL(TEST_HOOKS_PATH, mode=os.RTLD_LOCAL)
+        _test_hooks.usearch_amd_test_containers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                                            C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t),
+                                                            C.POINTER(C.c_char_p)]
+    return _test_hooks
+
+
 def test_containers(kinds: np.ndarray, keys: np.ndarray, slots: np.ndarray, limit: int):
     """Device container self-test hook → (popped[(key, slot)], top[(distance, slot)])."""
     kinds = np.ascontiguousarray(kinds, dtype=np.uint32)
@@ -660,7 +715,7 @@ def test_containers(kinds: np.ndarray, keys: np.ndarray, slots: np.ndarray, limi
     top = np.zeros(limit + 1, dtype=np.uint64)
     popped_count, top_count = C.c_size_t(), C.c_size_t()
     err = C.c_char_p()
-    library().usearch_amd_test_containers(_pointer(kinds), _pointer(keys), _pointer(slots), n, limit, _pointer(popped),
+    test_hooks().usearch_amd_test_containers(_pointer(kinds), _pointer(keys), _pointer(slots), n, limit, _pointer(popped),
                                           C.byref(popped_count), _pointer(top), C.byref(top_count), C.byref(err))
     _raise(err, "usearch_amd_test_containers")
 
