@@ -125,6 +125,10 @@ USEARCH_AMD_EXPORT float usearch_amd_snapshot_gather_probe(usearch_amd_snapshot_
 /** A probe of the address-translation path over the resident matrix: million touches per second of random 4-KB pages, 16 bytes
  *  each (csrc/placement.hpp `translation_probe`). Diagnostics. */
 USEARCH_AMD_EXPORT float usearch_amd_snapshot_translation_probe(usearch_amd_snapshot_t snapshot, usearch_amd_error_t* error);
+/** Nanoseconds per dependent read of a random stored row (`which` = 0) or of a random level-0 neighbour list (1): chains of reads
+ *  in which the next address depends on the bytes just read, few enough in flight that nothing queues (csrc/placement.hpp
+ *  `latency_probe`). Diagnostics. */
+USEARCH_AMD_EXPORT float usearch_amd_snapshot_latency_probe(usearch_amd_snapshot_t snapshot, int which, usearch_amd_error_t* error);
 /** Storage scalar kind (C enumerator) and metric kind (`usearch_metric_kind_t` value, c/usearch.h:40-52). */
 USEARCH_AMD_EXPORT int usearch_amd_snapshot_scalar_kind(usearch_amd_snapshot_t snapshot);
 USEARCH_AMD_EXPORT int usearch_amd_snapshot_metric_kind(usearch_amd_snapshot_t snapshot);

@@ -45,6 +45,12 @@ extern "C" {
 #define USEARCH_EXPORT __attribute__((visibility("default")))
 #endif
 
+/* The 38 entry points and their types are the reference's own ABI. A translation unit that also includes the reference's
+ * `c/usearch.h` (its `c/lib.cpp` does, after `include/usearch/index_dense.hpp` pulled this header in) must see them once:
+ * whichever of the two headers comes first declares them, under the reference's own include guard. */
+#ifndef UNUM_USEARCH_H
+#define UNUM_USEARCH_H
+
 typedef void* usearch_index_t;       /* c/usearch.h:20 */
 typedef uint64_t usearch_key_t;      /* c/usearch.h:21 */
 typedef float usearch_distance_t;    /* c/usearch.h:22 */
@@ -144,6 +150,8 @@ USEARCH_EXPORT void usearch_exact_search(void const* dataset, size_t dataset_siz
                                          size_t distances_stride, usearch_error_t* error);                    /* 467 */
 USEARCH_EXPORT void usearch_clear(usearch_index_t index, usearch_error_t* error);                             /* 481 */
 
+#endif /* UNUM_USEARCH_H */
+
 /* ---- additive, MI355X-specific ---- */
 
 /**
@@ -165,10 +173,84 @@ USEARCH_EXPORT void usearch_search_many(usearch_index_t index, void const* queri
 USEARCH_EXPORT void usearch_cluster_many(usearch_index_t index, void const* queries, usearch_scalar_kind_t query_kind,
                                          size_t queries_count, size_t queries_stride, size_t level,
                                          usearch_key_t* keys, usearch_distance_t* distances, usearch_error_t* error);
+/**
+ *  `index_dense_gt::search(query, count, thread, exact = true)` (index_dense.hpp:767-772 → `search_exact_`, index.hpp:4252-4268)
+ *  for a batch: brute force over every member of the index, top-`count` under (distance, slot descending). The reference's C ABI
+ *  only offers exact search over raw datasets (`usearch_exact_search`); its C++ class offers this one. Layout as
+ *  `usearch_search_many`.
+ */
+USEARCH_EXPORT void usearch_search_exact_many(usearch_index_t index, void const* queries, usearch_scalar_kind_t query_kind,
+                                              size_t queries_count, size_t queries_stride, size_t count, usearch_key_t* keys,
+                                              size_t keys_stride, usearch_distance_t* distances, size_t distances_stride,
+                                              size_t* counts, usearch_error_t* error);
+/** Threads `usearch_change_threads_add / _search` recorded (the reference's `index_limits_t`, index.hpp:1338-1357). */
+USEARCH_EXPORT size_t usearch_threads_search(usearch_index_t index, usearch_error_t* error);
 /** Takes (or refreshes) the HBM snapshot now instead of at the next search. */
 USEARCH_EXPORT void usearch_gpu_sync(usearch_index_t index, usearch_error_t* error);
 /** Drops the HBM snapshot (it is re-taken on demand). */
 USEARCH_EXPORT void usearch_gpu_release(usearch_index_t index, usearch_error_t* error);
+
+/**
+ *  Every entry point above as one table of function pointers. For code that must call THIS library while defining functions
+ *  of the same names itself: `include/usearch/index_dense.hpp` — the `unum::usearch::index_dense_gt` surface over this
+ *  library — is what the reference's own `c/lib.cpp` is compiled against in the tests, and that file defines `usearch_*`.
+ */
+typedef struct usearch_amd_c_api_t {
+    size_t entries; /**< number of pointers below (append-only) */
+    char const* (*version)(void);
+    usearch_index_t (*init)(usearch_init_options_t*, usearch_error_t*);
+    void (*free)(usearch_index_t, usearch_error_t*);
+    size_t (*memory_usage)(usearch_index_t, usearch_error_t*);
+    char const* (*hardware_acceleration)(usearch_index_t, usearch_error_t*);
+    size_t (*serialized_length)(usearch_index_t, usearch_error_t*);
+    void (*save)(usearch_index_t, char const*, usearch_error_t*);
+    void (*load)(usearch_index_t, char const*, usearch_error_t*);
+    void (*view)(usearch_index_t, char const*, usearch_error_t*);
+    void (*metadata)(char const*, usearch_init_options_t*, usearch_error_t*);
+    void (*save_buffer)(usearch_index_t, void*, size_t, usearch_error_t*);
+    void (*load_buffer)(usearch_index_t, void const*, size_t, usearch_error_t*);
+    void (*view_buffer)(usearch_index_t, void const*, size_t, usearch_error_t*);
+    void (*metadata_buffer)(void const*, size_t, usearch_init_options_t*, usearch_error_t*);
+    size_t (*size)(usearch_index_t, usearch_error_t*);
+    size_t (*capacity)(usearch_index_t, usearch_error_t*);
+    size_t (*dimensions)(usearch_index_t, usearch_error_t*);
+    size_t (*connectivity)(usearch_index_t, usearch_error_t*);
+    void (*reserve)(usearch_index_t, size_t, usearch_error_t*);
+    size_t (*expansion_add)(usearch_index_t, usearch_error_t*);
+    size_t (*expansion_search)(usearch_index_t, usearch_error_t*);
+    void (*change_expansion_add)(usearch_index_t, size_t, usearch_error_t*);
+    void (*change_expansion_search)(usearch_index_t, size_t, usearch_error_t*);
+    void (*change_threads_add)(usearch_index_t, size_t, usearch_error_t*);
+    void (*change_threads_search)(usearch_index_t, size_t, usearch_error_t*);
+    void (*change_metric_kind)(usearch_index_t, usearch_metric_kind_t, usearch_error_t*);
+    void (*change_metric)(usearch_index_t, usearch_metric_t, void*, usearch_metric_kind_t, usearch_error_t*);
+    void (*add)(usearch_index_t, usearch_key_t, void const*, usearch_scalar_kind_t, usearch_error_t*);
+    bool (*contains)(usearch_index_t, usearch_key_t, usearch_error_t*);
+    size_t (*count)(usearch_index_t, usearch_key_t, usearch_error_t*);
+    size_t (*search)(usearch_index_t, void const*, usearch_scalar_kind_t, size_t, usearch_key_t*, usearch_distance_t*,
+                     usearch_error_t*);
+    size_t (*filtered_search)(usearch_index_t, void const*, usearch_scalar_kind_t, size_t, int (*)(usearch_key_t, void*), void*,
+                              usearch_key_t*, usearch_distance_t*, usearch_error_t*);
+    size_t (*get)(usearch_index_t, usearch_key_t, size_t, void*, usearch_scalar_kind_t, usearch_error_t*);
+    size_t (*remove)(usearch_index_t, usearch_key_t, usearch_error_t*);
+    size_t (*rename)(usearch_index_t, usearch_key_t, usearch_key_t, usearch_error_t*);
+    usearch_distance_t (*distance)(void const*, void const*, usearch_scalar_kind_t, size_t, usearch_metric_kind_t,
+                                   usearch_error_t*);
+    void (*exact_search)(void const*, size_t, size_t, void const*, size_t, size_t, usearch_scalar_kind_t, size_t,
+                         usearch_metric_kind_t, size_t, size_t, usearch_key_t*, size_t, usearch_distance_t*, size_t,
+                         usearch_error_t*);
+    void (*clear)(usearch_index_t, usearch_error_t*);
+    void (*search_many)(usearch_index_t, void const*, usearch_scalar_kind_t, size_t, size_t, size_t, usearch_key_t*, size_t,
+                        usearch_distance_t*, size_t, size_t*, size_t*, size_t*, usearch_error_t*);
+    void (*cluster_many)(usearch_index_t, void const*, usearch_scalar_kind_t, size_t, size_t, size_t, usearch_key_t*,
+                         usearch_distance_t*, usearch_error_t*);
+    void (*search_exact_many)(usearch_index_t, void const*, usearch_scalar_kind_t, size_t, size_t, size_t, usearch_key_t*, size_t,
+                              usearch_distance_t*, size_t, size_t*, usearch_error_t*);
+    size_t (*threads_search)(usearch_index_t, usearch_error_t*);
+    void (*gpu_sync)(usearch_index_t, usearch_error_t*);
+    void (*gpu_release)(usearch_index_t, usearch_error_t*);
+} usearch_amd_c_api_t;
+USEARCH_EXPORT usearch_amd_c_api_t const* usearch_amd_c_api(void);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,8 @@ def main():
     p.add_argument("--copies", type=int, default=6)
     p.add_argument("--parts", type=int, default=8)
     p.add_argument("--no-engine-draws", action="store_true")
+    p.add_argument("--scratch-redraws", type=int, default=0,
+                   help="on ONE resident copy: this many launches, each with a freshly allocated visited-set scratch block")
     p.add_argument("--chunks-mb", type=int, nargs="+", default=[0],
                    help="also place the matrix through the virtual-memory API in physical chunks of this many MB (0 = hipMalloc)")
     args = p.parse_args()
@@ -39,7 +41,6 @@ def main():
     device = torch.device("cuda", 0)
     data = bench.synthetic_vectors_device(args.n, args.dim, args.dtype, 42, device)
     t0 = time.time()
-    os.environ["USEARCH_AMD_PLACEMENT_DRAWS"] = "1"
     built = usearch_amd.build(None, metric, args.dtype, device_pointer=data.data_ptr(), count=args.n, stride=data.stride(0),
                               ndim=args.dim)
     print(f"GPU-built {args.n} in {time.time() - t0:.1f}s", flush=True)
@@ -64,12 +65,36 @@ def main():
                 times.append(stats.kernel_ms)
         return min(times)
 
+    if args.scratch_redraws:
+        index = usearch_amd.Index.restore(image)
+
+        def launches(count):
+            out = []
+            for _ in range(count):
+                stats = index.search_device(queries.data_ptr(), args.queries, queries.stride(0), 10, args.ef, keys.data_ptr(),
+                                            dists.data_ptr(), counts.data_ptr(), visited.data_ptr(), computed.data_ptr(), timed=True)
+                out.append(round(stats.kernel_ms, 2))
+            return out
+
+        launches(3)
+        print("same scratch block, launch after launch :", launches(args.scratch_redraws), flush=True)
+        os.environ["USEARCH_AMD_SCRATCH_REDRAW"] = "1"
+        print("a fresh scratch block for every launch  :", launches(args.scratch_redraws), flush=True)
+        os.environ.pop("USEARCH_AMD_SCRATCH_REDRAW")
+        print("same scratch block again                :", launches(args.scratch_redraws), flush=True)
+        index.close()
+        torch.cuda.empty_cache()
     rows_per_part = args.n // args.parts
     for chunk_mb in args.chunks_mb:
-        os.environ["USEARCH_AMD_VMM_CHUNK_MB"] = str(chunk_mb)
+        if chunk_mb < 0:  # the engine's default: ONE physical allocation of the whole array, mapped
+            os.environ.pop("USEARCH_AMD_VMM_CHUNK_MB", None)
+        else:
+            os.environ["USEARCH_AMD_VMM_CHUNK_MB"] = str(chunk_mb)
         held = []
-        print(f"--- matrix placed by {'hipMalloc' if not chunk_mb else f'hipMemCreate chunks of {chunk_mb} MB'}", flush=True)
-        print("copy  load s  gather GB/s (x2)  pages M/s   batch ms   gather GB/s of each part", flush=True)
+        how = "the engine's default (one mapped physical allocation)" if chunk_mb < 0 else "hipMalloc" if not chunk_mb \
+            else f"hipMemCreate chunks of {chunk_mb} MB"
+        print(f"--- matrix placed by {how}", flush=True)
+        print("copy  load s  gather GB/s (x2)  pages M/s  latency ns rows / lists   batch ms   gather GB/s of each part", flush=True)
         for copy in range(args.copies):
             t0 = time.time()
             try:
@@ -81,16 +106,19 @@ def main():
             held.append(index)
             whole = index.gather_probe()
             pages = index.translation_probe()
+            latency = (index.latency_probe(), index.latency_probe(lists=True))
             parts = [index.gather_probe(i * rows_per_part, rows_per_part) for i in range(args.parts)] if args.parts > 1 else []
             ms = batch_ms(index)
             whole_again = index.gather_probe()
-            print(f"{copy:4d}  {load_s:6.2f}  {whole:8.0f} {whole_again:8.0f}  {pages:9.0f}   {ms:8.3f}   " +
+            latency_again = (index.latency_probe(), index.latency_probe(lists=True))
+            print(f"{copy:4d}  {load_s:6.2f}  {whole:8.0f} {whole_again:8.0f}  {pages:9.0f}  {latency[0]:6.0f} {latency_again[0]:6.0f} / "
+                  f"{latency[1]:6.0f} {latency_again[1]:6.0f}   {ms:8.3f}   " +
                   " ".join(f"{r:6.0f}" for r in parts), flush=True)
         for index in held:
             index.close()
         held.clear()
         torch.cuda.empty_cache()
-    os.environ["USEARCH_AMD_VMM_CHUNK_MB"] = "0"
+    os.environ.pop("USEARCH_AMD_VMM_CHUNK_MB", None)
     # the engine's own choice
     for draws in (() if args.no_engine_draws else (6, 6, 1, 1)):
         os.environ["USEARCH_AMD_PLACEMENT_DRAWS"] = str(draws)

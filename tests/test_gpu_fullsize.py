@@ -58,7 +58,7 @@ def test_baseline_shapes_at_scale_match_the_reference(reference, n, dim, dtype, 
             got.keys, got.distances, got.counts,
             lambda queries_, wanted: reference_index.search(queries_, wanted, dtype=dtype, threads=0), batch, k, dtype,
             what=f"{n} x {dim} {dtype}")
-        assert separated > 0.5
+        assert separated > 0.5 and agreement > 0.98
         okeys, odists, ocounts, ovisited, ocomputed = oraclebind.OracleIndex(image).search(
             batch, k, dtype=dtype, expansion=expansion, lanes=index.lanes_per_row, frontier_in_top=got.stats.frontier == 2)
         assert np.array_equal(got.keys, okeys) and util.same_float_bits(got.distances, odists)

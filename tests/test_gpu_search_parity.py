@@ -125,7 +125,9 @@ def test_search_matches_oracle_and_reference(reference, metric, dtype, ndim, n, 
         separated, agreement = util.assert_float_parity(
             got.keys, got.distances, got.counts, lambda batch, wanted: ref_index.search(batch, wanted, dtype=dtype, threads=1),
             queries, k, dtype, what=f"{metric}/{dtype}")
-        assert separated > 0.5, f"only {separated:.2f} of the positions are separated: the rule would be vacuous"
+        # (the 16-bit kinds' tolerance of 2e-3 leaves a fifth to a half of these clustered rows separated; f32 / f64 nearly all)
+        assert separated > (0.1 if dtype in ("f16", "bf16") else 0.5), f"only {separated:.2f} of the positions are separated"
+        assert agreement > 0.98, f"label agreement with the reference over ALL positions {agreement:.4f}"
     # monotone distances (cpp/test.cpp:499-503) and self-hit for in-sample queries
     for qi in range(nq):
         c = int(got.counts[qi])

@@ -115,12 +115,14 @@ const char* snapshot_t::grow_for_build(std::uint64_t capacity, std::uint64_t lis
         if (array.new_bytes == array.old_bytes && *array.pointer)
             continue;
         void* fresh = nullptr;
-        if (array.pointer == &d_vectors_) // the arrays the walk gathers from are placed with care (placement.hpp)
+        if (array.pointer == &d_vectors_) { // the matrix the walk gathers rows from (placement.hpp)
             UA_HIP(placed_malloc(&fresh, array.new_bytes, row_stride, &placement_));
-        else if (array.pointer == &d_nbr0_)
+            vectors_bytes_ = array.new_bytes;
+        } else if (array.pointer == &d_nbr0_) {
             UA_HIP(placed_malloc(&fresh, array.new_bytes, (std::size_t)m0 * 4, nullptr));
-        else
+        } else {
             UA_HIP(hipMalloc(&fresh, std::max<std::size_t>(array.new_bytes, 16)));
+        }
         if (array.old_bytes && *array.pointer)
             UA_HIP(hipMemcpy(fresh, *array.pointer, array.old_bytes, hipMemcpyDeviceToDevice));
         if (array.new_bytes > array.old_bytes)

@@ -243,6 +243,17 @@ float usearch_amd_snapshot_translation_probe(usearch_amd_snapshot_t s, usearch_a
         fail(error, hipGetErrorString(e));
     return rate;
 }
+float usearch_amd_snapshot_latency_probe(usearch_amd_snapshot_t s, int which, usearch_amd_error_t* error) {
+    const snapshot_view_t& view = as_snapshot(s)->view();
+    float nanoseconds = 0.f;
+    if (hipSetDevice(as_snapshot(s)->device()) != hipSuccess)
+        return 0.f;
+    const hipError_t e = which ? latency_probe(view.nbr0, (std::size_t)view.size * view.m0 * 4, (std::size_t)view.m0 * 4, &nanoseconds)
+                               : latency_probe(view.vectors, (std::size_t)view.size * view.row_stride, view.row_stride, &nanoseconds);
+    if (e != hipSuccess)
+        fail(error, hipGetErrorString(e));
+    return nanoseconds;
+}
 void usearch_amd_snapshot_placement(usearch_amd_snapshot_t s, uint32_t* draws, uint32_t* kept, float* gather_gbps, float* probe_ms) {
     const placement_t& placement = as_snapshot(s)->placement();
     if (draws)

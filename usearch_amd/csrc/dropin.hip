@@ -988,6 +988,41 @@ void usearch_clear(usearch_index_t handle, usearch_error_t* error) {
     });
 }
 
+void usearch_search_exact_many(usearch_index_t handle, void const* queries, usearch_scalar_kind_t query_kind, size_t queries_count,
+                               size_t queries_stride, size_t count, usearch_key_t* keys, size_t keys_stride,
+                               usearch_distance_t* distances, size_t distances_stride, size_t* counts, usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    guarded(error, [&] {
+        const scalar_kind_t kind = scalar_from_c(query_kind);
+        if (kind == scalar_unknown_k)
+            return fail(error, "Unknown scalar kind!");
+        if (!queries_count || !count)
+            return;
+        unique_lock_t lock(index.mutex);
+        snapshot_t* device_index = nullptr;
+        if (const char* e = index.ready(&device_index))
+            return fail(error, e);
+        std::vector<std::uint64_t> dense_keys(queries_count * count), found(queries_count, 0);
+        std::vector<float> dense_distances(queries_count * count);
+        if (!device_index) // nothing indexed yet
+            pad_results(reinterpret_cast<usearch_key_t*>(dense_keys.data()), dense_distances.data(), queries_count * count);
+        else if (const char* e = device_index->exact_host(queries, kind, queries_count, queries_stride, count, dense_keys.data(),
+                                                          dense_distances.data(), found.data(), nullptr))
+            return fail(error, e);
+        for (std::size_t q = 0; q < queries_count; ++q) {
+            if (keys)
+                std::memcpy(reinterpret_cast<std::uint8_t*>(keys) + q * keys_stride, dense_keys.data() + q * count, count * 8);
+            if (distances)
+                std::memcpy(reinterpret_cast<std::uint8_t*>(distances) + q * distances_stride, dense_distances.data() + q * count,
+                            count * 4);
+            if (counts)
+                counts[q] = (std::size_t)found[q];
+        }
+    });
+}
+
+size_t usearch_threads_search(usearch_index_t handle, usearch_error_t*) { return as_index(handle)->threads_search; }
+
 void usearch_gpu_sync(usearch_index_t handle, usearch_error_t* error) {
     index_t& index = *as_index(handle);
     guarded(error, [&] {
@@ -1002,6 +1037,22 @@ void usearch_gpu_release(usearch_index_t handle, usearch_error_t*) {
     index_t& index = *as_index(handle);
     unique_lock_t lock(index.mutex);
     index.drop_device();
+}
+
+usearch_amd_c_api_t const* usearch_amd_c_api(void) {
+    static const usearch_amd_c_api_t table = {
+        44,
+        &usearch_version, &usearch_init, &usearch_free, &usearch_memory_usage, &usearch_hardware_acceleration,
+        &usearch_serialized_length, &usearch_save, &usearch_load, &usearch_view, &usearch_metadata, &usearch_save_buffer,
+        &usearch_load_buffer, &usearch_view_buffer, &usearch_metadata_buffer, &usearch_size, &usearch_capacity,
+        &usearch_dimensions, &usearch_connectivity, &usearch_reserve, &usearch_expansion_add, &usearch_expansion_search,
+        &usearch_change_expansion_add, &usearch_change_expansion_search, &usearch_change_threads_add,
+        &usearch_change_threads_search, &usearch_change_metric_kind, &usearch_change_metric, &usearch_add, &usearch_contains,
+        &usearch_count, &usearch_search, &usearch_filtered_search, &usearch_get, &usearch_remove, &usearch_rename,
+        &usearch_distance, &usearch_exact_search, &usearch_clear, &usearch_search_many, &usearch_cluster_many,
+        &usearch_search_exact_many, &usearch_threads_search, &usearch_gpu_sync, &usearch_gpu_release,
+    };
+    return &table;
 }
 
 } // extern "C"

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -117,12 +118,26 @@ const char* workspace_t::reserve(std::size_t queries_wanted, std::size_t scratch
         UA_HIP(hipHostMalloc((void**)&h_status, (room + 16) * 4, hipHostMallocDefault));
         queries = room;
     }
+    // experiment switch (scripts/placement_study.py --scratch-redraws): a FRESH scratch block for every launch, the old ones parked
+    // so that each new one lands elsewhere — does where the visited-set slabs sit decide the speed of the walk?
+    if (scratch_wanted && env_size("USEARCH_AMD_SCRATCH_REDRAW", 0)) {
+        static std::vector<void*> parked;
+        if (d_scratch)
+            parked.push_back(d_scratch);
+        if (parked.size() > 12) {
+            for (void* p : parked)
+                (void)hipFree(p);
+            parked.clear();
+        }
+        d_scratch = nullptr;
+        scratch_bytes = 0;
+    }
     if (scratch_wanted > scratch_bytes) {
         if (d_scratch)
             (void)hipFree(d_scratch);
         d_scratch = nullptr;
         scratch_bytes = 0;
-        UA_HIP(hipMalloc((void**)&d_scratch, scratch_wanted));
+        UA_HIP(hipMalloc((void**)&d_scratch, scratch_wanted)); // big blocks for chip-filling launches are drawn by run_ladder
         scratch_bytes = scratch_wanted;
     }
     return nullptr;
@@ -255,6 +270,110 @@ __global__ void inline_rows_kernel(const std::uint8_t* vectors, const std::uint3
     }
 }
 
+const char* snapshot_t::tune_placement() {
+    const std::size_t draws = std::min<std::size_t>(placement_max_draws_k, env_size("USEARCH_AMD_PLACEMENT_DRAWS", 4));
+    if (draws <= 1 || !d_vectors_ || tuned_vectors_ == d_vectors_ || view_.size < 65536 ||
+        vectors_bytes_ < env_size("USEARCH_AMD_PLACEMENT_MIN_BYTES", (std::size_t)1 << 30))
+        return nullptr;
+    const auto started = std::chrono::steady_clock::now();
+    if (hipSetDevice(device_) != hipSuccess)
+        return nullptr;
+    // the judge: 4 096 stored rows searched for their 10 nearest at expansion 128 — a few milliseconds of the real walk
+    const std::size_t queries = 4096, wanted = 10, expansion = 128;
+    struct buffers_t {
+        std::vector<void*> pointers;
+        ~buffers_t() {
+            for (void* p : pointers)
+                (void)hipFree(p);
+        }
+        void* take(std::size_t bytes) {
+            void* p = nullptr;
+            if (hipMalloc(&p, bytes) != hipSuccess)
+                return nullptr;
+            pointers.push_back(p);
+            return p;
+        }
+    } buffers;
+    auto* d_ids = static_cast<std::uint32_t*>(buffers.take(queries * 4));
+    auto* d_keys = static_cast<std::uint64_t*>(buffers.take(queries * wanted * 8));
+    auto* d_distances = static_cast<float*>(buffers.take(queries * wanted * 4));
+    auto* d_counts = static_cast<std::uint64_t*>(buffers.take(queries * 8 * 3));
+    if (!d_ids || !d_keys || !d_distances || !d_counts)
+        return (void)hipGetLastError(), nullptr;
+    std::vector<std::uint32_t> ids(queries);
+    std::uint64_t state = 0x9E3779B97F4A7C15ull;
+    for (std::uint32_t& id : ids) {
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        id = (std::uint32_t)(((state >> 33) * view_.size) >> 31);
+        id = id < view_.size ? id : (std::uint32_t)(view_.size - 1);
+    }
+    if (hipMemcpy(d_ids, ids.data(), queries * 4, hipMemcpyHostToDevice) != hipSuccess)
+        return (void)hipGetLastError(), nullptr;
+    search_extras_t extras;
+    extras.query_ids = d_ids;
+    auto judge = [&](float& ms) -> bool {
+        for (int repeat = 0; repeat < 2; ++repeat) { // the first run also draws the scratch block and warms the code
+            search_stats_t stats;
+            if (search_device(view_.vectors, queries, view_.row_stride, wanted, expansion, d_keys, d_distances, d_counts,
+                              d_counts + queries, d_counts + 2 * queries, nullptr, search_tuning_t{}, &stats, true, &extras))
+                return false;
+            ms = stats.kernel_ms;
+        }
+        return true;
+    };
+    placement_ = placement_t{};
+    float best_ms = 0.f;
+    if (!judge(best_ms))
+        return nullptr; // cannot judge: the matrix stays where it is
+    placement_.gather_gbps[0] = best_ms;
+    placement_.draws = 1, placement_.kept = 0;
+    std::vector<void*> losers; // held until the end, so that every further draw has to land somewhere else
+    for (std::size_t d = 1; d < draws; ++d) {
+        std::size_t free_bytes = 0, total_bytes = 0;
+        if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess || free_bytes < vectors_bytes_ + ((std::size_t)4 << 30))
+            break;
+        void* candidate = nullptr;
+        if (placed_malloc(&candidate, vectors_bytes_, view_.row_stride, nullptr) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        if (hipMemcpy(candidate, d_vectors_, vectors_bytes_, hipMemcpyDeviceToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            placed_free(candidate);
+            break;
+        }
+        void* previous = d_vectors_;
+        d_vectors_ = candidate;
+        view_.vectors = static_cast<const std::uint8_t*>(candidate);
+        float ms = 0.f;
+        const bool judged = judge(ms);
+        placement_.gather_gbps[d] = ms;
+        placement_.draws = (std::uint32_t)d + 1;
+        if (judged && ms < best_ms) {
+            best_ms = ms;
+            placement_.kept = (std::uint32_t)d;
+            losers.push_back(previous);
+        } else {
+            d_vectors_ = previous;
+            view_.vectors = static_cast<const std::uint8_t*>(previous);
+            losers.push_back(candidate);
+        }
+        if (!judged)
+            break;
+    }
+    for (void* p : losers)
+        placed_free(p);
+    tuned_vectors_ = d_vectors_;
+    placement_.probe_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - started).count();
+    if (env_size("USEARCH_AMD_PLACEMENT_LOG", 0)) {
+        std::fprintf(stderr, "[usearch_amd] matrix placement of %.2f GB, judged by a self-search of %zu stored rows: ", vectors_bytes_ / 1e9, queries);
+        for (std::uint32_t i = 0; i < placement_.draws; ++i)
+            std::fprintf(stderr, "%s%.3f%s", i ? " " : "", placement_.gather_gbps[i], i == placement_.kept ? "*" : "");
+        std::fprintf(stderr, " ms, %.0f ms in all\n", placement_.probe_ms);
+    }
+    return nullptr;
+}
+
 const char* snapshot_t::finalize_layout() {
     if (d_nbr0_rows_) {
         placed_free(d_nbr0_rows_);
@@ -263,7 +382,7 @@ const char* snapshot_t::finalize_layout() {
         view_.nbr0_rows = nullptr;
     }
     if (lanes_ != 1 || view_.chunks != 1 || view_.m0 > 64 || !view_.size || !env_size("USEARCH_AMD_INLINE_ROWS", 1))
-        return nullptr;
+        return tune_placement();
     UA_HIP(hipSetDevice(device_));
     const std::uint64_t cells = view_.size * view_.m0;
     UA_HIP(placed_malloc(&d_nbr0_rows_, cells * 16, (std::size_t)view_.m0 * 16, nullptr)); // what a hop gathers: one block
@@ -274,7 +393,7 @@ const char* snapshot_t::finalize_layout() {
     UA_HIP(hipGetLastError());
     UA_HIP(hipStreamSynchronize(stream_));
     view_.nbr0_rows = static_cast<const std::uint8_t*>(d_nbr0_rows_);
-    return nullptr;
+    return tune_placement();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -456,6 +575,7 @@ const char* snapshot_t::build(const image_t& image, int device) {
     // the matrix the walk gathers rows from takes the best of a few placements (placement.hpp); its size makes it THE array
     device_bytes_ += std::max<std::size_t>(vectors_bytes, 16);
     UA_HIP(placed_malloc(&d_vectors_, vectors_bytes, row_stride, &placement_));
+    vectors_bytes_ = vectors_bytes;
     device_bytes_ += std::max<std::size_t>((std::size_t)n * m0 * 4, 16);
     UA_HIP(placed_malloc(&d_nbr0_, (std::size_t)n * m0 * 4, (std::size_t)m0 * 4, nullptr));
     UA_HIP(allocate(&d_upper_ref_, (std::size_t)n * 4));
@@ -858,7 +978,16 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         const std::uint64_t lds_bytes = lds_bytes_for(call.mode, call.next_cap, call.hash_cap);
         const std::uint32_t grid = (std::uint32_t)std::min<std::uint64_t>(pending, (std::uint64_t)waves_for(lds_bytes) * compute_units_);
         const std::uint64_t slab = call.mode == scratch_hash_k ? (std::uint64_t)call.hash_cap * 4 : 0;
-        if (const char* e = ws.reserve(call.count, slab * grid))
+        // WHERE the block of visited-set slabs lands decides which of the walk's speeds this batch runs at (with the index arrays
+        // untouched, a fresh 268-MB block flips the headline batch between 45.5 and 51.6 ms; profiles/r03_placement/), and no
+        // synthetic probe tells the placements apart — only the walk itself does. So when a new block is needed for a launch that
+        // fills the chip, a few placements are drawn side by side and each is timed by THIS launch over its first queries (one per
+        // wave; their results are simply computed again by the launch proper); the fastest block stays with the workspace.
+        const std::size_t scratch_draws = std::min<std::size_t>(8, env_size("USEARCH_AMD_SCRATCH_DRAWS", 6));
+        const bool draw_scratch = slab * grid > ws.scratch_bytes && slab * grid >= ((std::uint64_t)8 << 20) && scratch_draws > 1 &&
+                                  pending >= 2ull * grid && grid >= 2u * (std::uint32_t)compute_units_ &&
+                                  !env_size("USEARCH_AMD_SCRATCH_REDRAW", 0);
+        if (const char* e = ws.reserve(call.count, draw_scratch ? 0 : slab * grid))
             return e;
         args.status = ws.d_status, args.peaks = ws.d_peaks;
         args.hash_cap = call.hash_cap;
@@ -868,6 +997,68 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         args.scratch = ws.d_scratch;
         args.scratch_stride = slab;
         args.wave_clock = nullptr;
+        if (draw_scratch) {
+            params.mode = call.mode;
+            params.entries_per_lane = call.entries_per_lane;
+            params.grid = grid;
+            params.lds_bytes = (std::uint32_t)lds_bytes;
+            hipEvent_t begin = nullptr, end = nullptr;
+            UA_HIP(hipEventCreate(&begin));
+            UA_HIP(hipEventCreate(&end));
+            void* candidates[8] = {nullptr};
+            float trial_ms[8] = {0};
+            std::size_t drawn = 0;
+            const char* failure = nullptr;
+            for (; drawn < scratch_draws && !failure; ++drawn) {
+                if (hipMalloc(&candidates[drawn], slab * grid) != hipSuccess) {
+                    (void)hipGetLastError();
+                    candidates[drawn] = nullptr;
+                    break;
+                }
+                args.scratch = static_cast<std::uint8_t*>(candidates[drawn]);
+                args.count = grid; // one query per wave: the launch's steady state, a single query's latency long
+                for (int repeat = 0; repeat < 2 && !failure; ++repeat) { // the first run of a block also pays its first touch
+                    hipError_t e = hipMemsetAsync(ws.d_queue, 0, 8, stream);
+                    if (e == hipSuccess)
+                        e = hipEventRecord(begin, stream);
+                    if (e == hipSuccess)
+                        e = launch_search(metric_, scalar_, params, view_, args);
+                    if (e == hipSuccess)
+                        e = hipEventRecord(end, stream);
+                    if (e == hipSuccess)
+                        e = hipEventSynchronize(end);
+                    if (e == hipSuccess)
+                        e = hipEventElapsedTime(&trial_ms[drawn], begin, end);
+                    if (e != hipSuccess)
+                        failure = hip_message(e);
+                }
+            }
+            (void)hipEventDestroy(begin);
+            (void)hipEventDestroy(end);
+            std::size_t kept = 0;
+            for (std::size_t i = 1; i < drawn; ++i)
+                if (trial_ms[i] < trial_ms[kept])
+                    kept = i;
+            for (std::size_t i = 0; i < drawn; ++i)
+                if (i != kept || failure || !drawn)
+                    (void)hipFree(candidates[i]);
+            if (failure)
+                return failure;
+            if (!drawn)
+                return hip_message(hipErrorOutOfMemory);
+            if (ws.d_scratch)
+                (void)hipFree(ws.d_scratch);
+            ws.d_scratch = static_cast<std::uint8_t*>(candidates[kept]);
+            ws.scratch_bytes = slab * grid;
+            args.scratch = ws.d_scratch;
+            args.count = pending;
+            if (env_size("USEARCH_AMD_PLACEMENT_LOG", 0)) {
+                std::fprintf(stderr, "[usearch_amd] scratch placement of %.0f MB, timed by the launch's first %u queries: ", slab * grid / 1e6, grid);
+                for (std::size_t i = 0; i < drawn; ++i)
+                    std::fprintf(stderr, "%s%.3f%s", i ? " " : "", trial_ms[i], i == kept ? "*" : "");
+                std::fprintf(stderr, " ms\n");
+            }
+        }
         if (call.want_clock && call.passes == 0) {
             if (const char* e = ws.reserve_wave_clock(grid))
                 return e;

@@ -119,7 +119,7 @@ struct image_t {
         max_level = load<std::uint64_t>(p + 24);
         entry_slot = load<std::uint64_t>(p + 32);
         p += 40;
-        if (max_level > 0x7FFF) // levels are i16 on the tapes (index.hpp:2116-2137): nothing larger can be a node's level
+        if (size && max_level > 0x7FFF) // levels are i16 on the tapes (index.hpp:2116-2137): nothing larger can be a node's level
             return "Failed to pull the header from the stream";
         if (without_vectors) { // the matrix is the caller's: one row of the head's scalar kind and dimensions per slot
             rows = size;

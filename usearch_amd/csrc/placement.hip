@@ -65,6 +65,19 @@ __global__ __launch_bounds__(64) void translation_probe_kernel(const std::uint8_
         *sink = folded;
 }
 
+/// Every lane follows its own chain: the next row is a function of the bytes just read (whatever they are) and a counter.
+__global__ __launch_bounds__(64) void latency_probe_kernel(const std::uint8_t* base, std::uint64_t rows, std::uint64_t row_bytes,
+                                                           std::uint32_t steps, std::uint32_t* sink) {
+    std::uint32_t state = (blockIdx.x * 64u + threadIdx.x) * 2654435761u + 0x9E3779B9u;
+    for (std::uint32_t s = 0; s < steps; ++s) {
+        const std::uint64_t row = ((std::uint64_t)(state ^ (state >> 15)) * rows) >> 32;
+        const uint4 v = *reinterpret_cast<const uint4*>(base + row * row_bytes);
+        state = (state + (v.x ^ v.y ^ v.z ^ v.w)) * 1664525u + 1013904223u + s;
+    }
+    if (state == 0x5EED5EEDu)
+        *sink = state;
+}
+
 /// Arrays mapped through the virtual-memory API (USEARCH_AMD_VMM_CHUNK_MB): what it takes to release them.
 struct mapped_t {
     void* base;
@@ -124,16 +137,13 @@ hipError_t mapped_malloc(void** out, std::size_t bytes, std::size_t chunk) {
     return hipSuccess;
 }
 
-/// One placement. By default ONE physical allocation of the whole size, mapped into a reserved range (`mapped_malloc` with a
-/// single chunk): five restores out of five walk at the fast speed that way, against two out of five for `hipMalloc` blocks and
-/// for mappings made of 2-MB … 1-GB chunks (profiles/r03_placement/). USEARCH_AMD_VMM_CHUNK_MB: 0 = plain `hipMalloc`, n = chunks
-/// of n MB. Falls back to `hipMalloc` when the mapping cannot be made.
+/// One placement: a `hipMalloc` block, or — USEARCH_AMD_VMM_CHUNK_MB = n — physical chunks of n MB mapped back to back into a
+/// reserved range (n larger than the array: one chunk). An experiment switch: which flavour an array is made of turned out not to
+/// decide its speed (profiles/r03_placement/README.md).
 hipError_t draw(void** out, std::size_t bytes) {
-    const char* setting = std::getenv("USEARCH_AMD_VMM_CHUNK_MB");
-    const std::size_t chunk_mb = setting && *setting ? (std::size_t)std::strtoull(setting, nullptr, 10) : ~(std::size_t)0;
+    const std::size_t chunk_mb = env_size("USEARCH_AMD_VMM_CHUNK_MB", 0);
     if (chunk_mb) {
-        const std::size_t chunk = chunk_mb == ~(std::size_t)0 ? bytes : chunk_mb << 20;
-        if (mapped_malloc(out, bytes, chunk) == hipSuccess)
+        if (mapped_malloc(out, bytes, chunk_mb << 20) == hipSuccess)
             return hipSuccess;
         (void)hipGetLastError();
     }
@@ -199,6 +209,45 @@ hipError_t translation_probe(const void* base, std::size_t bytes, float* rate) {
     return result;
 }
 
+hipError_t latency_probe(const void* base, std::size_t bytes, std::size_t row_bytes, float* nanoseconds) {
+    *nanoseconds = 0.f;
+    row_bytes = std::max<std::size_t>(16, row_bytes / 16 * 16);
+    const std::uint64_t rows = bytes / row_bytes;
+    if (rows < 1024)
+        return hipSuccess;
+    static thread_local std::uint32_t* sink = nullptr;
+    if (!sink)
+        if (hipError_t e = hipMalloc((void**)&sink, 4); e != hipSuccess)
+            return e;
+    const std::uint32_t waves = 512, steps = 512; // two waves per compute unit: nothing queues behind anything
+    hipEvent_t begin = nullptr, end = nullptr;
+    if (hipError_t e = hipEventCreate(&begin); e != hipSuccess)
+        return e;
+    if (hipError_t e = hipEventCreate(&end); e != hipSuccess) {
+        (void)hipEventDestroy(begin);
+        return e;
+    }
+    float best_ms = 0.f;
+    hipError_t result = hipSuccess;
+    for (int repeat = 0; repeat < 4 && result == hipSuccess; ++repeat) {
+        (void)hipEventRecord(begin, nullptr);
+        hipLaunchKernelGGL(latency_probe_kernel, dim3(waves), dim3(64), 0, nullptr, static_cast<const std::uint8_t*>(base), rows,
+                           (std::uint64_t)row_bytes, steps, sink);
+        (void)hipEventRecord(end, nullptr);
+        result = hipEventSynchronize(end);
+        float ms = 0.f;
+        if (result == hipSuccess)
+            result = hipEventElapsedTime(&ms, begin, end);
+        if (repeat && (best_ms == 0.f || ms < best_ms))
+            best_ms = ms;
+    }
+    (void)hipEventDestroy(begin);
+    (void)hipEventDestroy(end);
+    if (result == hipSuccess && best_ms > 0.f)
+        *nanoseconds = best_ms * 1e6f / steps;
+    return result;
+}
+
 hipError_t gather_probe(const void* base, std::size_t bytes, std::size_t row_bytes, float* gbps) {
     *gbps = 0.f;
     const std::uint32_t chunks = (std::uint32_t)std::max<std::size_t>(1, row_bytes / 16);
@@ -241,62 +290,14 @@ hipError_t gather_probe(const void* base, std::size_t bytes, std::size_t row_byt
     return result;
 }
 
-hipError_t placed_malloc(void** out, std::size_t bytes, std::size_t row_bytes, placement_t* report) {
-    placement_t local;
-    placement_t& stats = report ? *report : local;
-    stats = placement_t{};
+hipError_t placed_malloc(void** out, std::size_t bytes, std::size_t, placement_t* report) {
+    if (report)
+        *report = placement_t{};
     *out = nullptr;
     bytes = std::max<std::size_t>(bytes, 16);
-    const std::size_t threshold = env_size("USEARCH_AMD_PLACEMENT_MIN_BYTES", (std::size_t)1 << 30);
-    const int wanted = (int)std::min<std::size_t>(placement_max_draws_k, env_size("USEARCH_AMD_PLACEMENT_DRAWS", 1));
-    if (bytes < threshold || wanted <= 1 || row_bytes < 16)
-        return bytes < threshold ? hipMalloc(out, bytes) : draw(out, bytes);
-
-    const auto started = std::chrono::steady_clock::now();
-    void* candidates[placement_max_draws_k] = {nullptr};
-    int drawn = 0;
-    hipError_t result = hipSuccess;
-    for (; drawn < wanted; ++drawn) {
-        if (drawn) { // a further draw must fit NEXT to the ones held, with room to spare for the index's other arrays
-            std::size_t free_bytes = 0, total_bytes = 0;
-            if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess || free_bytes < bytes + bytes / 2 + ((std::size_t)8 << 30))
-                break;
-        }
-        void* p = nullptr;
-        const hipError_t e = draw(&p, bytes);
-        if (e != hipSuccess) {
-            if (!drawn)
-                result = e;
-            else
-                (void)hipGetLastError(); // out of room for one more: keep what there is
-            break;
-        }
-        candidates[drawn] = p;
-        float gbps = 0.f;
-        if (gather_probe(p, bytes, row_bytes, &gbps) != hipSuccess)
-            (void)hipGetLastError();
-        stats.gather_gbps[drawn] = gbps;
-    }
-    if (result != hipSuccess)
-        return result;
-    int kept = 0;
-    for (int i = 1; i < drawn; ++i)
-        if (stats.gather_gbps[i] > stats.gather_gbps[kept])
-            kept = i;
-    for (int i = 0; i < drawn; ++i)
-        if (i != kept)
-            placed_free(candidates[i]);
-    *out = candidates[kept];
-    stats.draws = (std::uint32_t)drawn;
-    stats.kept = (std::uint32_t)kept;
-    stats.probe_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - started).count();
-    if (std::getenv("USEARCH_AMD_PLACEMENT_LOG")) {
-        std::fprintf(stderr, "[usearch_amd] placement of %.2f GB (rows of %zu B): ", bytes / 1e9, row_bytes);
-        for (int i = 0; i < drawn; ++i)
-            std::fprintf(stderr, "%s%.0f%s", i ? " " : "", stats.gather_gbps[i], i == kept ? "*" : "");
-        std::fprintf(stderr, " GB/s, %.0f ms\n", stats.probe_ms);
-    }
-    return hipSuccess;
+    if (bytes < env_size("USEARCH_AMD_PLACEMENT_MIN_BYTES", (std::size_t)1 << 30))
+        return hipMalloc(out, bytes);
+    return draw(out, bytes);
 }
 
 } // namespace usearch_amd

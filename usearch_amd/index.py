@@ -80,7 +80,7 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_snapshot_from_parts",
     "usearch_amd_snapshot_free", "usearch_amd_snapshot_size", "usearch_amd_snapshot_dimensions",
     "usearch_amd_snapshot_connectivity", "usearch_amd_snapshot_max_level", "usearch_amd_snapshot_bytes_per_vector",
-    "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_placement", "usearch_amd_snapshot_gather_probe", "usearch_amd_snapshot_translation_probe",
+    "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_placement", "usearch_amd_snapshot_gather_probe", "usearch_amd_snapshot_translation_probe", "usearch_amd_snapshot_latency_probe",
     "usearch_amd_snapshot_scalar_kind",
     "usearch_amd_snapshot_metric_kind", "usearch_amd_snapshot_lanes_per_row", "usearch_amd_snapshot_inline_rows",
     "usearch_amd_search_many",
@@ -149,6 +149,8 @@ def library() -> C.CDLL:
     L.usearch_amd_snapshot_placement.restype = None
     L.usearch_amd_snapshot_placement.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                                  C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.usearch_amd_snapshot_latency_probe.restype = C.c_float
+    L.usearch_amd_snapshot_latency_probe.argtypes = [C.c_void_p, C.c_int, err_p]
     L.usearch_amd_snapshot_translation_probe.restype = C.c_float
     L.usearch_amd_snapshot_translation_probe.argtypes = [C.c_void_p, err_p]
     L.usearch_amd_snapshot_gather_probe.restype = C.c_float
@@ -360,6 +362,13 @@ class Index:
         library().usearch_amd_snapshot_placement(self._handle, C.byref(draws), C.byref(kept), rates, C.byref(probe_ms))
         return {"draws": int(draws.value), "kept": int(kept.value), "probe_ms": round(float(probe_ms.value), 2),
                 "gather_gbps": [round(float(rates[i]), 1) for i in range(draws.value)]}
+
+    def latency_probe(self, lists: bool = False) -> float:
+        """Nanoseconds per DEPENDENT read of a random stored row (or, `lists`, of a random level-0 neighbour list)."""
+        err = C.c_char_p()
+        value = library().usearch_amd_snapshot_latency_probe(self._handle, 1 if lists else 0, C.byref(err))
+        _raise(err, "usearch_amd_snapshot_latency_probe")
+        return float(value)
 
     def translation_probe(self) -> float:
         """Million random 4-KB pages of the resident matrix touched per second (16 bytes each): the address-translation path."""
