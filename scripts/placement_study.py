@@ -28,6 +28,8 @@ def main():
     p.add_argument("--copies", type=int, default=6)
     p.add_argument("--parts", type=int, default=8)
     p.add_argument("--no-engine-draws", action="store_true")
+    p.add_argument("--ballast-steps", type=int, default=0)
+    p.add_argument("--ballast-gb", type=int, default=8)
     p.add_argument("--scratch-redraws", type=int, default=0,
                    help="on ONE resident copy: this many launches, each with a freshly allocated visited-set scratch block")
     p.add_argument("--chunks-mb", type=int, nargs="+", default=[0],
@@ -82,6 +84,29 @@ def main():
         print("a fresh scratch block for every launch  :", launches(args.scratch_redraws), flush=True)
         os.environ.pop("USEARCH_AMD_SCRATCH_REDRAW")
         print("same scratch block again                :", launches(args.scratch_redraws), flush=True)
+        index.close()
+        torch.cuda.empty_cache()
+    if args.ballast_steps:
+        # map the device's memory: park `ballast_gb` more gigabytes before every fresh scratch block, so that the blocks walk through
+        # the whole physical space; the index stays where it is
+        os.environ["USEARCH_AMD_PLACEMENT_DRAWS"] = "1"
+        index = usearch_amd.Index.restore(image)
+        os.environ["USEARCH_AMD_SCRATCH_REDRAW"] = "1"
+        parked = []
+        print(f"ballast GB  batch ms with a fresh scratch block (x3)   free GB", flush=True)
+        for step in range(args.ballast_steps):
+            times = []
+            for _ in range(3):
+                stats = index.search_device(queries.data_ptr(), args.queries, queries.stride(0), 10, args.ef, keys.data_ptr(),
+                                            dists.data_ptr(), counts.data_ptr(), visited.data_ptr(), computed.data_ptr(), timed=True)
+                times.append(round(stats.kernel_ms, 2))
+            free_gb = torch.cuda.mem_get_info(device)[0] / 1e9
+            print(f"{step * args.ballast_gb:8d}    {times}   {free_gb:6.1f}", flush=True)
+            if free_gb < args.ballast_gb + 6:
+                break
+            parked.append(torch.empty(args.ballast_gb << 30, dtype=torch.uint8, device=device))
+        os.environ.pop("USEARCH_AMD_SCRATCH_REDRAW")
+        del parked
         index.close()
         torch.cuda.empty_cache()
     rows_per_part = args.n // args.parts

@@ -983,7 +983,7 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         // synthetic probe tells the placements apart — only the walk itself does. So when a new block is needed for a launch that
         // fills the chip, a few placements are drawn side by side and each is timed by THIS launch over its first queries (one per
         // wave; their results are simply computed again by the launch proper); the fastest block stays with the workspace.
-        const std::size_t scratch_draws = std::min<std::size_t>(8, env_size("USEARCH_AMD_SCRATCH_DRAWS", 6));
+        const std::size_t scratch_draws = std::min<std::size_t>(8, env_size("USEARCH_AMD_SCRATCH_DRAWS", 8));
         const bool draw_scratch = slab * grid > ws.scratch_bytes && slab * grid >= ((std::uint64_t)8 << 20) && scratch_draws > 1 &&
                                   pending >= 2ull * grid && grid >= 2u * (std::uint32_t)compute_units_ &&
                                   !env_size("USEARCH_AMD_SCRATCH_REDRAW", 0);
@@ -1055,7 +1055,7 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
             if (env_size("USEARCH_AMD_PLACEMENT_LOG", 0)) {
                 std::fprintf(stderr, "[usearch_amd] scratch placement of %.0f MB, timed by the launch's first %u queries: ", slab * grid / 1e6, grid);
                 for (std::size_t i = 0; i < drawn; ++i)
-                    std::fprintf(stderr, "%s%.3f%s", i ? " " : "", trial_ms[i], i == kept ? "*" : "");
+                    std::fprintf(stderr, "%s%.3f%s@%p", i ? " " : "", trial_ms[i], i == kept ? "*" : "", candidates[i]);
                 std::fprintf(stderr, " ms\n");
             }
         }
