@@ -252,6 +252,18 @@ def stress_rows(args, metric: str, device, local_rank: int, expansion: int) -> d
     return rows
 
 
+# BASELINE.json `configs`, as single-GPU command lines (c5: one 125M shard of the 1B index; `--gpus 8 --sharded` makes it the whole)
+PRESETS = {
+    "c1": {"what": "100k x 128 f32 cos, k = 10, ef = 64 (the reference's own CPU-runnable case, cpp/bench.cpp)",
+           "set": {"n": 100_000, "dim": 128, "dtype": "f32", "queries": 10_000, "expansion": 64}},
+    "c2": {"what": "1M x 768 f32 cos, batch 10k", "set": {"n": 1_000_000, "dim": 768, "dtype": "f32", "queries": 10_000}},
+    "c3": {"what": "10M x 768 f16 cos, batch 10k (the headline)", "set": {"n": 10_000_000, "dim": 768, "dtype": "f16", "queries": 10_000}},
+    "c4": {"what": "100M x 96 i8 l2sq, batch 100k", "set": {"n": 100_000_000, "dim": 96, "dtype": "i8", "queries": 100_000}},
+    "c5": {"what": "125M x 128 b1 hamming, batch 100k: one shard of the 1B index",
+           "set": {"n": 125_000_000, "dim": 128, "dtype": "b1", "queries": 100_000}},
+}
+
+
 def main() -> None:
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -290,11 +302,15 @@ def main() -> None:
                         help="PMC-derived HBM bytes per launch of this workload (scripts/pmc_traffic.py), copied into "
                              "roofline.traffic when it was measured with the same sources")
     parser.add_argument("--wave-clock", action="store_true", help="record the batch-tail telemetry of the timed steps")
-    parser.add_argument("--placement-draws", type=int, default=8,
-                        help="upload the index up to this many times and keep the placement in HBM that walks fastest "
-                             "(usearch_amd.Index.restore_placed; the same bytes run at one of two speeds by where they land, "
-                             "profiles/r02_placement.log); 1 = take the first. Replicas only")
+    parser.add_argument("--no-placement-check", action="store_true",
+                        help="skip re-timing the batch with the engine's placement draws switched off (roofline.frac_first_placement)")
+    parser.add_argument("--config", default=None, choices=sorted(PRESETS),
+                        help="one of BASELINE.json's configurations by name: " + "; ".join(f"{k} = {v['what']}" for k, v in sorted(PRESETS.items())))
     args = parser.parse_args()
+    if args.config:  # a preset fills in what the command line left at its default
+        for name, value in PRESETS[args.config]["set"].items():
+            if getattr(args, name) == parser.get_default(name):
+                setattr(args, name, value)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_with_ranks(args.gpus)
     metric = args.metric or ("hamming" if args.dtype == "b1" else "l2sq" if args.dtype == "i8" else "cos")
@@ -323,6 +339,19 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # preflight of an N > 1 run: N ranks on N DIFFERENT devices, and the launcher's world is what `--gpus` said
+    preflight = {"world": world, "devices": 1}
+    if world > 1:
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+        identity = torch.cuda.get_device_properties(device)
+        mine = (local_rank, str(getattr(identity, "uuid", "")) or f"{identity.name}#{local_rank}")
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        preflight["devices"] = len({uuid for _, uuid in everyone})
+        preflight["local_ranks"] = [r for r, _ in everyone]
+        if not rehearsal and preflight["devices"] != world:
+            raise SystemExit(f"{world} ranks share {preflight['devices']} device(s): one process per GPU is the contract")
 
     import usearch_amd
 
@@ -482,51 +511,11 @@ def main() -> None:
         expansion = int(chosen.item())
     expansion = expansion or 64
 
-    # ---- where the index sits in HBM decides which of two speeds the walk runs at: the loader draws a few
-    #      placements and keeps the fastest, timed on this very batch. Index load policy, outside the timed region; each rank on
-    #      its own (no collective involved).
-    placement = None
-    # ranks of one node take turns two at a time: each turn holds a serialized image (16.8 GB for the headline) in host memory
-    draw_turns = range(0, world, 2) if args.placement_draws > 1 and not sharded and not rehearsal else []
-    for turn in draw_turns:
-        if world > 1:
-            dist.barrier()
-        if rank // 2 != turn // 2:
-            continue
-        t1 = time.time()
-        image_was_there = image is not None
-
-        def probe(candidate) -> float:
-            for timed in (False, True):  # the first call sizes the candidate's workspace
-                stats = candidate.search_device(queries_dev.data_ptr(), args.queries, queries_dev.stride(0), args.k, expansion,
-                                                keys_dev.data_ptr(), dist_dev.data_ptr(), counts_dev.data_ptr(),
-                                                visited_dev.data_ptr(), computed_dev.data_ptr(), stream=stream.cuda_stream,
-                                                timed=timed, tuning=tuning)
-            return stats.kernel_ms
-
-        builders_own = index
-        try:
-            if image is None:
-                image = built.save_buffer()
-            index, placement = usearch_amd.Index.restore_placed(image, probe, draws=args.placement_draws, device=local_rank,
-                                                                first=builders_own,
-                                                                free_bytes=lambda: torch.cuda.mem_get_info(device)[0])
-        except (RuntimeError, MemoryError) as error:  # no room for the image or a second copy: the first placement it is
-            log(f"[bench] rank {rank}: no placement draw ({error}); keeping the index where it was built")
-            index, placement = builders_own, {"probe_ms": [], "kept": 0, "error": str(error)[:200]}
-        if index is not builders_own:  # the first placement lost: its memory goes back
-            if built is not None:
-                built.close()
-            else:
-                builders_own.close()
-        placement["seconds"] = round(time.time() - t1, 1)
-        if world > 1 and not image_was_there:
-            image = None  # only the single-GPU run needs it again (for the reference)
-        if rank == 0 and placement["probe_ms"]:
-            log(f"[bench] placement: batch kernel {placement['probe_ms']} ms over {len(placement['probe_ms'])} draw(s), kept "
-                f"#{placement['kept']} ({placement['seconds']} s incl. serializing the image)")
-    if draw_turns and world > 1:
-        dist.barrier()
+    # ---- placement: where the workspace's scratch block and the matrix land in HBM decides which of four speeds the walk runs at
+    #      (profiles/r03_placement/README.md). The ENGINE draws both and lets the walk judge them (csrc/placement.hpp): nothing to do
+    #      here but to report what it drew.
+    placement = {"matrix": index.placement, "policy": "engine: scratch block drawn by run_ladder (<= 8 candidates timed by the launch's "
+                 "first queries), matrix by snapshot_t::tune_placement (<= 4 copies judged by a self-search)"}
 
     # ---- warmup, then EXACTLY `steps` timed steps between barriers
     flush_native_stdio()
@@ -628,13 +617,36 @@ def main() -> None:
             agree = float(np.mean(found_keys[:folded] == merged_keys))
         else:
             agree = float(np.mean(found_keys == rkeys))
+        # float-valued pairs walk with the frontier as the open cells of `top` (no heap): the same batch once more with the
+        # reference's heap, so that the line says how often the two differ and how both agree with the reference
+        frontier_check = None
+        if stats.frontier == 2 and not sharded:
+            default_counters = (computed_dev.cpu().numpy().copy(), visited_dev.cpu().numpy().copy())
+            default_bits = dist_dev.cpu().numpy().view(np.uint32).copy()
+            heap_tuning = usearch_amd.Tuning(frontier=1)
+            index.search_device(queries_dev.data_ptr(), args.queries, queries_dev.stride(0), args.k, expansion, keys_dev.data_ptr(),
+                                dist_dev.data_ptr(), counts_dev.data_ptr(), visited_dev.data_ptr(), computed_dev.data_ptr(),
+                                stream=stream.cuda_stream, timed=False, tuning=heap_tuning)
+            torch.cuda.synchronize()
+            heap_keys = keys_dev.cpu().numpy().astype(np.uint64)
+            other_counters = int(np.sum((computed_dev.cpu().numpy() != default_counters[0]) | (visited_dev.cpu().numpy() != default_counters[1])))
+            other_keys = int(np.sum((heap_keys[:sample_q] != found_keys).any(axis=1)))
+            other_bits = int(np.sum((dist_dev.cpu().numpy().view(np.uint32)[:sample_q] != default_bits[:sample_q]).any(axis=1)))
+            frontier_check = {"queries": int(args.queries), "queries_whose_counters_differ_between_frontiers": other_counters,
+                              "queries_whose_keys_differ": other_keys, "queries_whose_distance_bits_differ": other_bits,
+                              "of_the_first": int(sample_q),
+                              "label_agreement_with_reference": {"in_top_frontier": agree,
+                                                                 "heap_frontier": float(np.mean(heap_keys[:sample_q] == rkeys))}}
+            log(f"[bench] frontier check: {other_counters} of {args.queries} queries walk differently under the reference's heap "
+                f"(counters), {other_keys} of the first {sample_q} return other keys; label agreement with the reference "
+                f"{agree:.4f} (in-top) / {frontier_check['label_agreement_with_reference']['heap_frontier']:.4f} (heap)")
         # one query at a time on one core: what a `usearch_search` loop sees from the reference (latency, not throughput)
         t1 = time.perf_counter()
         for i in range(32):
             ref_index.search(queries_host[i:i + 1], args.k, dtype=args.dtype, threads=1)
         reference_single_us = (time.perf_counter() - t1) / 32 * 1e6
         cpu = {"value": sample_q / cpu_seconds, "unit": "shard-queries/s" if sharded else "queries/s", "cores": threads,
-               "kind": "reference",
+               "kind": "reference", "frontier_check": frontier_check,
                "sample": f"{sample_q} of the step's {args.queries} queries, same index, same ef={expansion}, "
                          f"OpenMP static,32 loop of cpp/bench.cpp:352-377; serial (auto-vectorised) metrics, SimSIMD "
                          f"unavailable offline; {cpu_seconds:.1f}s; label agreement with the GPU {agree:.4f}; one query at a "
@@ -661,6 +673,36 @@ def main() -> None:
             ref_index = None
         del image
         cpu["load_seconds"] = load_seconds
+
+    # ---- the same batch with the engine's placement draws switched off (a fresh copy of the index, first placement of everything):
+    #      what a caller would get without them. Outside the timed region; `roofline.frac_first_placement`.
+    first_placement = None
+    if rank == 0 and world == 1 and not sharded and not args.no_placement_check and built is not None:
+        saved = {name: os.environ.get(name) for name in ("USEARCH_AMD_SCRATCH_DRAWS", "USEARCH_AMD_PLACEMENT_DRAWS")}
+        os.environ["USEARCH_AMD_SCRATCH_DRAWS"] = os.environ["USEARCH_AMD_PLACEMENT_DRAWS"] = "1"
+        try:
+            undrawn = usearch_amd.Index.restore(built.save_buffer(), device=local_rank)
+            times = []
+            for step in range(6):
+                stats_first = undrawn.search_device(queries_dev.data_ptr(), args.queries, queries_dev.stride(0), args.k, expansion,
+                                                    keys_dev.data_ptr(), dist_dev.data_ptr(), counts_dev.data_ptr(),
+                                                    visited_dev.data_ptr(), computed_dev.data_ptr(), stream=stream.cuda_stream, timed=True)
+                if step:
+                    times.append(stats_first.kernel_ms)
+            first_placement = {"kernel_ms": float(np.mean(times)), "frac": step_bytes / (float(np.mean(times)) / 1e3) / 1e9 / HBM_PEAK_GBPS}
+            log(f"[bench] with the placement draws off (a fresh copy, first placement of everything): kernel {first_placement['kernel_ms']:.2f} ms "
+                f"against {kernel_s * 1e3:.2f} ms drawn")
+            undrawn.close()
+            del undrawn
+        except (RuntimeError, MemoryError) as error:
+            log(f"[bench] no first-placement check: {error}")
+        finally:
+            for name, value in saved.items():
+                if value is None:
+                    os.environ.pop(name, None)
+                else:
+                    os.environ[name] = value
+        torch.cuda.empty_cache()
 
     stress = None
     if rank == 0 and world == 1 and not sharded and not args.no_stress_rows:
@@ -712,7 +754,7 @@ def main() -> None:
                        "recall_at_k": recall, "recall_queries": sample, "recall_ci": [recall - recall_half, recall + recall_half]
                        if recall is not None else None,
                        "parallelism": ("shards" if sharded else "replicas") + str(world),
-                       "placement": placement,
+                       "placement": placement, "preset": args.config, "preflight": preflight,
                        "queries_per_second": queries_per_second,
                        "scaling_definition": ("weak: every GPU holds one shard of --vectors vectors and searches the whole batch; value = "
                                               "batch x shards / time (shard-queries/s), the 1-GPU point is one shard; "
@@ -726,7 +768,7 @@ def main() -> None:
                        "index_builder": args.builder, "index_build_seconds": round(build_seconds, 1),
                        "index_build": build_stats, "kernel_passes": passes,
                        "kernel_passes_by_expansion": {str(ef): n for ef, n in sorted(sweep_passes.items())},
-                       "scratch_mode": {1: "lds", 2: "global-hash", 3: "global"}.get(stats.mode, "?"),
+                       "scratch_mode": {1: "lds", 2: "global-hash", 3: "global", 4: "pair-lds"}.get(stats.mode, "?"),
                        "frontier": {1: "heap", 2: "in-top"}.get(stats.frontier, "?"), "kernel_build": stats.variant,
                        "persistent_waves": stats.grid, "lds_bytes_per_wave": stats.lds_bytes,
                        "rows_inline_with_lists": bool(index.inline_rows),
@@ -735,7 +777,10 @@ def main() -> None:
                        "single_query_latency_us_host_api": single_query_us,
                        "sources": sources, "stress_rows": stress},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "frac_first_placement": first_placement["frac"] if first_placement else None,
+                         "kernel_ms_first_placement": first_placement["kernel_ms"] if first_placement else None,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "search_kernel", "kernel_ms": kernel_s * 1e3,
                          # template arguments of the timed instantiation as rocprofv3 prints them: metric and scalar codes, lanes
                          # per row, build, scratch mode, `top` cells per lane, frontier

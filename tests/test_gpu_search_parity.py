@@ -135,6 +135,20 @@ def test_search_matches_oracle_and_reference(reference, metric, dtype, ndim, n, 
         assert np.all(got.keys[qi, c:] == 0) and np.all(np.isnan(got.distances[qi, c:]))
 
 
+@pytest.mark.parametrize("metric,dtype,ndim,n,connectivity", [("cos", "f16", 96, 3000, 16), ("hamming", "b1", 128, 2500, 7)])
+def test_images_with_40_bit_slots_load_and_search_the_same(reference, metric, dtype, ndim, n, connectivity):
+    """`uint40_t` compressed slots on the node tapes (index.hpp:969-1031; connectivity 7 makes every list and most nodes an odd
+    number of bytes): the device flattener reads them byte by byte and the index it builds is the one the 32-bit image gives."""
+    from usearch_amd import Index
+    image, vectors, _ = util.build_image(n, ndim, metric, dtype, seed=21, connectivity=connectivity)
+    queries = util.make_vectors(120, ndim, dtype, seed=22, metric=metric)
+    narrow, wide = Index.restore(image), Index.restore(util.with_40_bit_slots(image))
+    assert len(wide) == n and wide.connectivity == connectivity
+    a, b = narrow.search(queries, 10, dtype=dtype), wide.search(queries, 10, dtype=dtype)
+    assert np.array_equal(a.keys, b.keys) and util.same_float_bits(a.distances, b.distances)
+    assert np.array_equal(a.computed_per_query, b.computed_per_query) and np.array_equal(a.visited_per_query, b.visited_per_query)
+
+
 def test_empty_index_and_zero_wanted(reference):
     from usearch_amd import Index
     image, _, _ = util.build_image(0, 16, "cos", "f32")

@@ -83,9 +83,12 @@ def test_corrupt_images_are_rejected():
     taller = image.copy()
     taller[levels_at + 2:levels_at + 4] = np.frombuffer(np.int16(max_level + 5).tobytes(), dtype=np.uint8)
     cases["level above the index's"] = taller
+    cases["128-bit keys"] = util.with_uuid_keys_announced(image)  # index_dense_big_t's uuid_t: refused by name
+    wide = util.with_40_bit_slots(image)  # uint40_t slots load (tests/test_gpu_dropin.py); cut short they fail like any tape
+    cases["40-bit slots, last tape cut"] = wide[: len(wide) - 3]
     cases["last tape cut"] = image[: len(image) - 7]
     cases["tapes missing"] = image[: levels_at + 2 * size + 5]
-    expected = {"negative level": b"nodes", "level above the index's": b"nodes", "last tape cut": b"nodes", "tapes missing": b"nodes"}
+    expected = {"128-bit keys": b"128-bit keys", "40-bit slots, last tape cut": b"nodes", "negative level": b"nodes", "level above the index's": b"nodes", "last tape cut": b"nodes", "tapes missing": b"nodes"}
     for name, data in cases.items():
         data = np.ascontiguousarray(data)
         err = C.c_char_p()

@@ -145,6 +145,46 @@ def without_vectors(image: np.ndarray) -> np.ndarray:
     return image[8 + int(rows) * int(cols):].copy()
 
 
+def with_40_bit_slots(image: np.ndarray) -> np.ndarray:
+    """The same index as an `index_dense_gt<u64, uint40_t>` would write it: every neighbour slot on the node tapes as the 5-byte
+    `uint40_t` of index.hpp:969-1031 (the compressed-slot kind of `index_dense_big_t`, index_dense.hpp:2230) and the head's
+    slot-kind byte set to u40_k (index_plugins.hpp:142). Transcoded here because the reference only instantiates that slot type
+    together with 128-bit keys."""
+    rows, cols = (int(v) for v in np.frombuffer(image[:8].tobytes(), dtype=np.uint32))
+    head = 8 + rows * cols
+    out = [image[:head + 64].copy()]
+    out[0][head + 16] = 2  # u40_k
+    size, m, m0 = (int(v) for v in np.frombuffer(image[head + 64:head + 88].tobytes(), dtype=np.uint64))
+    levels_at = head + 64 + 40
+    out.append(image[head + 64:levels_at + 2 * size])
+    levels = np.frombuffer(image[levels_at:levels_at + 2 * size].tobytes(), dtype=np.int16)
+    at = levels_at + 2 * size
+    raw = image.tobytes()
+    pieces = []
+    for level in levels:
+        pieces.append(raw[at:at + 10])  # key, level
+        at += 10
+        for cells in [m0] + [m] * int(level):
+            pieces.append(raw[at:at + 4])  # count
+            slots = np.frombuffer(raw[at + 4:at + 4 + 4 * cells], dtype=np.uint32)
+            wide = np.zeros((cells, 5), dtype=np.uint8)
+            wide[:, :4] = slots.view(np.uint8).reshape(cells, 4)
+            pieces.append(wide.tobytes())
+            at += 4 + 4 * cells
+    assert at == len(raw), "the image does not end with its last tape"
+    out.append(np.frombuffer(b"".join(pieces), dtype=np.uint8))
+    return np.concatenate(out)
+
+
+def with_uuid_keys_announced(image: np.ndarray) -> np.ndarray:
+    """The head of an `index_dense_big_t` file: key kind uuid_k (index_plugins.hpp:143). (Only the head: the loader must refuse it
+    by name before it looks at a tape.)"""
+    rows, cols = (int(v) for v in np.frombuffer(image[:8].tobytes(), dtype=np.uint32))
+    out = image.copy()
+    out[8 + rows * cols + 15] = 3
+    return out
+
+
 def mapped_hip_runtime() -> str:
     """Path of the HIP runtime this process has mapped (the engine's, shared with torch when torch is installed —
     usearch_amd/index.py `_share_hip_runtime`): a test that calls the runtime directly must not pull in a second copy."""

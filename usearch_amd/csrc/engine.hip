@@ -414,42 +414,61 @@ __global__ void node_sizes_kernel(const std::int16_t* levels, std::uint64_t n, s
     lists[i] = level;
 }
 
-/// Tapes start at an arbitrary byte of the image but are uploaded to the start of their own allocation, and every node size
-/// is even: 2-byte loads are always aligned.
-__device__ __forceinline__ std::uint32_t tape_u32(const std::uint8_t* p) {
-    const std::uint16_t* h = reinterpret_cast<const std::uint16_t*>(p);
-    return (std::uint32_t)h[0] | ((std::uint32_t)h[1] << 16);
+/// Tapes start at an arbitrary byte of the image but are uploaded to the start of their own allocation, and with 4-byte slots
+/// every node size is even: 2-byte loads are always aligned. With the 5-byte slots of `uint40_t` (index.hpp:969-1031) nothing is
+/// aligned any more and every load goes byte by byte (`bytewise_ak`).
+template <bool bytewise_ak> __device__ __forceinline__ std::uint32_t tape_u16(const std::uint8_t* p) {
+    if constexpr (bytewise_ak)
+        return (std::uint32_t)p[0] | ((std::uint32_t)p[1] << 8);
+    else
+        return *reinterpret_cast<const std::uint16_t*>(p);
 }
-__device__ __forceinline__ std::uint64_t tape_u64(const std::uint8_t* p) {
-    return (std::uint64_t)tape_u32(p) | ((std::uint64_t)tape_u32(p + 4) << 32);
+template <bool bytewise_ak> __device__ __forceinline__ std::uint32_t tape_u32(const std::uint8_t* p) {
+    return tape_u16<bytewise_ak>(p) | (tape_u16<bytewise_ak>(p + 2) << 16);
+}
+template <bool bytewise_ak> __device__ __forceinline__ std::uint64_t tape_u64(const std::uint8_t* p) {
+    return (std::uint64_t)tape_u32<bytewise_ak>(p) | ((std::uint64_t)tape_u32<bytewise_ak>(p + 4) << 32);
+}
+/// Neighbour slot `j` of a list: 4 bytes, or 5 of which the fifth must be zero for the slot to fit a 32-bit cell
+/// (`none_slot_k` otherwise: the caller's `slot >= n` check then flags the image).
+template <bool wide_ak> __device__ __forceinline__ std::uint32_t tape_slot(const std::uint8_t* list, std::uint32_t j) {
+    if constexpr (wide_ak) {
+        const std::uint8_t* p = list + 4 + 5 * (std::uint64_t)j;
+        return p[4] ? none_slot_k : tape_u32<true>(p);
+    } else {
+        return tape_u32<false>(list + 4 + 4 * (std::uint64_t)j);
+    }
 }
 
 /**
  *  One thread per node: key, level-0 row (reference order, later duplicates of a slot dropped — they could only ever be seen
  *  as "already visited", index.hpp:4229 — unused cells none), upper lists verbatim (no visited set up there,
  *  index.hpp:3976-4001), and the checks the reference's loader implies. flags[0] = corrupt, flags[1] = any tombstone.
+ *  `wide_ak`: 5-byte `uint40_t` slots on the tapes.
  */
+template <bool wide_ak>
 __global__ void flatten_kernel(const std::uint8_t* tapes, const std::uint64_t* offsets, const std::uint64_t* first_list,
                                const std::int16_t* levels, std::uint64_t n, std::uint32_t m, std::uint32_t m0,
                                std::uint64_t* keys, std::uint32_t* nbr0, std::uint32_t* upper_ref, std::uint32_t* upper,
                                std::uint32_t* flags) {
+    constexpr std::uint64_t slot_bytes = wide_ak ? 5 : 4;
     const std::uint64_t i = blockIdx.x * (std::uint64_t)blockDim.x + threadIdx.x;
     if (i >= n)
         return;
     const std::uint8_t* tape = tapes + offsets[i];
-    const std::uint64_t key = tape_u64(tape);
+    const std::uint64_t key = tape_u64<wide_ak>(tape);
     keys[i] = key;
     if (key == free_key_k)
         flags[1] = 1;
     const std::int16_t level = levels[i];
-    const std::int16_t taped_level = (std::int16_t)(*reinterpret_cast<const std::uint16_t*>(tape + 8));
+    const std::int16_t taped_level = (std::int16_t)tape_u16<wide_ak>(tape + 8);
     if (taped_level != level) {
         flags[0] = 1;
         return;
     }
     upper_ref[i] = level ? (std::uint32_t)first_list[i] : none_slot_k;
     const std::uint8_t* list = tape + 10;
-    std::uint32_t count = tape_u32(list);
+    std::uint32_t count = tape_u32<wide_ak>(list);
     if (count > m0) {
         flags[0] = 1;
         return;
@@ -457,7 +476,7 @@ __global__ void flatten_kernel(const std::uint8_t* tapes, const std::uint64_t* o
     std::uint32_t* row = nbr0 + i * m0;
     std::uint32_t kept = 0;
     for (std::uint32_t j = 0; j < count; ++j) {
-        const std::uint32_t slot = tape_u32(list + 4 + 4 * (std::uint64_t)j);
+        const std::uint32_t slot = tape_slot<wide_ak>(list, j);
         if (slot >= n) {
             flags[0] = 1;
             return;
@@ -470,9 +489,9 @@ __global__ void flatten_kernel(const std::uint8_t* tapes, const std::uint64_t* o
     }
     for (std::uint32_t j = kept; j < m0; ++j)
         row[j] = none_slot_k;
-    list += 4 + 4 * (std::uint64_t)m0;
-    for (std::int16_t l = 1; l <= level; ++l, list += 4 + 4 * (std::uint64_t)m) {
-        count = tape_u32(list);
+    list += 4 + slot_bytes * (std::uint64_t)m0;
+    for (std::int16_t l = 1; l <= level; ++l, list += 4 + slot_bytes * (std::uint64_t)m) {
+        count = tape_u32<wide_ak>(list);
         if (count > m) {
             flags[0] = 1;
             return;
@@ -481,7 +500,7 @@ __global__ void flatten_kernel(const std::uint8_t* tapes, const std::uint64_t* o
         for (std::uint32_t j = 0; j < m; ++j) {
             std::uint32_t slot = none_slot_k;
             if (j < count) {
-                slot = tape_u32(list + 4 + 4 * (std::uint64_t)j);
+                slot = tape_slot<wide_ak>(list, j);
                 if (slot >= n || levels[slot] < l) {
                     flags[0] = 1;
                     return;
@@ -543,7 +562,7 @@ const char* snapshot_t::build(const image_t& image, int device) {
         UA_HIP(hipMemcpy(d_levels, image.levels, n * 2, hipMemcpyHostToDevice)); // 2-byte aligned in its own allocation
         const unsigned blocks = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(node_sizes_kernel, dim3(blocks), dim3(256), 0, nullptr, d_levels, n,
-                           (std::uint64_t)image.node_bytes(0), (std::uint64_t)(4 + 4 * (std::uint64_t)m), d_sizes,
+                           (std::uint64_t)image.node_bytes(0), (std::uint64_t)(4 + image.slot_bytes * (std::uint64_t)m), d_sizes,
                            d_level_counts);
         UA_HIP(hipGetLastError());
         std::size_t scan_bytes = 0;
@@ -587,9 +606,14 @@ const char* snapshot_t::build(const image_t& image, int device) {
         UA_HIP(scratch.allocate((void**)&d_tapes, tapes_bytes));
         UA_HIP(hipMemcpy(d_tapes, image.tapes, tapes_bytes, hipMemcpyHostToDevice));
         const unsigned blocks = (unsigned)((n + 127) / 128);
-        hipLaunchKernelGGL(flatten_kernel, dim3(blocks), dim3(128), 0, nullptr, d_tapes, d_offsets, d_first_list, d_levels, n,
-                           m, m0, static_cast<std::uint64_t*>(d_keys_), static_cast<std::uint32_t*>(d_nbr0_),
-                           static_cast<std::uint32_t*>(d_upper_ref_), static_cast<std::uint32_t*>(d_upper_), d_flags);
+        if (image.slot_bytes == 5)
+            hipLaunchKernelGGL(flatten_kernel<true>, dim3(blocks), dim3(128), 0, nullptr, d_tapes, d_offsets, d_first_list, d_levels,
+                               n, m, m0, static_cast<std::uint64_t*>(d_keys_), static_cast<std::uint32_t*>(d_nbr0_),
+                               static_cast<std::uint32_t*>(d_upper_ref_), static_cast<std::uint32_t*>(d_upper_), d_flags);
+        else
+            hipLaunchKernelGGL(flatten_kernel<false>, dim3(blocks), dim3(128), 0, nullptr, d_tapes, d_offsets, d_first_list, d_levels,
+                               n, m, m0, static_cast<std::uint64_t*>(d_keys_), static_cast<std::uint32_t*>(d_nbr0_),
+                               static_cast<std::uint32_t*>(d_upper_ref_), static_cast<std::uint32_t*>(d_upper_), d_flags);
         UA_HIP(hipGetLastError());
         std::uint32_t flags[2] = {0, 0};
         UA_HIP(hipMemcpy(flags, d_flags, 8, hipMemcpyDeviceToHost));
@@ -835,10 +859,15 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
             }
         }
     }
-    // auto: keep the visited set in LDS only while that does not cost a resident wave; otherwise move it to the global hash
+    // auto: keep the visited set in LDS only while that does not cost a resident wave; otherwise move it to the global hash. A batch
+    // so small that every query gets a wave of its own even at the LDS residency (a `usearch_search` caller's single query above
+    // all) also takes LDS: residency buys it nothing, and every probe round of the global hash is a two-microsecond trip to the
+    // memory side — half of such a query's latency (profiles/r03_short_rows/README.md §1)
+    const std::uint64_t lds_mode_bytes = lds_bytes_for(scratch_lds_k, next_cap, hash_cap);
+    const bool small_batch = lds_mode_bytes <= lds_budget && count <= (std::uint64_t)waves_for(lds_mode_bytes) * compute_units_ &&
+                             !env_size("USEARCH_AMD_NO_SMALL_BATCH_LDS", 0);
     int mode = mode_request == 1 ? scratch_lds_k : mode_request == 2 ? scratch_hash_k : mode_request == 3 ? scratch_global_k
-               : (waves_for(lds_bytes_for(scratch_lds_k, next_cap, hash_cap)) >= std::min<std::uint32_t>(8, call.waves_cap) ? scratch_lds_k
-                                                                                                            : scratch_hash_k);
+               : (small_batch || waves_for(lds_mode_bytes) >= std::min<std::uint32_t>(8, call.waves_cap) ? scratch_lds_k : scratch_hash_k);
     call.mode = mode;
     call.hash_cap = hash_cap;
     call.next_cap = next_cap;

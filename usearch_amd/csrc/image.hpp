@@ -9,7 +9,11 @@
  *    index.hpp:1863-1869         5 × u64: size, connectivity, connectivity_base, max_level, entry_slot
  *    index.hpp:3298-3305         i16 level per node
  *    index.hpp:3308-3314         node tapes back to back, each (index.hpp:2085, 3731-3748):
- *                                u64 key | i16 level | {u32 count, u32 × M0} | level × {u32 count, u32 × M}
+ *                                u64 key | i16 level | {u32 count, slot × M0} | level × {u32 count, slot × M}
+ *                                slot = u32 (`index_dense_t`) or the 5-byte `uint40_t` of index.hpp:969-1031 (the compressed-slot
+ *                                kind of `index_dense_big_t`, index_dense.hpp:2230) — accepted while the index has fewer than 2³²
+ *                                members, i.e. while every slot fits the device's 32-bit cells; 128-bit `uuid_t` keys (the other
+ *                                half of `index_dense_big_t`) have no counterpart in the 64-bit key ABI and are refused by name
  *  Everything after the matrix is unaligned, hence the memcpy loads. The image is borrowed, never copied.
  */
 #pragma once
@@ -41,6 +45,7 @@ struct image_t {
     bool multi = false;
 
     std::uint64_t size = 0, connectivity = 0, connectivity_base = 0, max_level = 0, entry_slot = 0;
+    std::uint32_t slot_bytes = 4; ///< bytes per neighbour slot on the tapes: 4 (u32) or 5 (uint40_t)
     const std::uint8_t* levels = nullptr;
     const std::uint8_t* tapes = nullptr; ///< first node tape
     std::size_t tapes_length = 0;
@@ -52,7 +57,7 @@ struct image_t {
     }
 
     std::size_t node_bytes(std::int16_t level) const {
-        return 10 + (4 + 4 * connectivity_base) + (std::size_t)level * (4 + 4 * connectivity);
+        return 10 + (4 + slot_bytes * connectivity_base) + (std::size_t)level * (4 + slot_bytes * connectivity);
     }
 
     /// Parses the fixed-size parts. Returns nullptr on success or a static message (the reference's wording where
@@ -102,9 +107,13 @@ struct image_t {
             return "File format may be different, please rebuild";
         metric = (metric_kind_t)p[13];
         scalar = (scalar_kind_t)p[14];
+        if (p[15] == 3 /* uuid_k */)
+            return "128-bit keys (the uuid_t of index_dense_big_t) have no counterpart in the 64-bit key ABI of the device index";
         if (p[15] != scalar_u64_k)
             return "Key type doesn't match, consider rebuilding";
-        if (p[16] != scalar_u32_k)
+        if (p[16] == 2 /* u40_k: index.hpp:969-1031 */)
+            slot_bytes = 5;
+        else if (p[16] != scalar_u32_k)
             return "Slot type doesn't match, consider rebuilding";
         count_present = load<std::uint64_t>(p + 17);
         count_deleted = load<std::uint64_t>(p + 25);
