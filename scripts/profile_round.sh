@@ -13,19 +13,23 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-python "$REPO/bench.py" "$@" --no-cpu-baseline --no-stress-rows --steps 5 --warmup 2 > "$OUT/pick.json" 2> "$OUT/pick.log"
-tail -4 "$OUT/pick.log"
-EF=$(python -c "import json; print(json.load(open('$OUT/pick.json'))['config']['expansion_search'])" 2>/dev/null || echo 256)
-QUICK="$* --expansion $EF --recall-queries 0 --no-cpu-baseline --no-stress-rows --no-host-api --steps 5 --warmup 1"
+if [ -z "${PROFILE_EF:-}" ]; then
+  python "$REPO/bench.py" "$@" --no-cpu-baseline --no-stress-rows --no-placement-check --steps 5 --warmup 2 > "$OUT/pick.json" 2> "$OUT/pick.log"
+  tail -4 "$OUT/pick.log"
+  EF=$(python -c "import json; print(json.load(open('$OUT/pick.json'))['config']['expansion_search'])" 2>/dev/null || echo 256)
+else
+  EF=$PROFILE_EF   # the expansion is known (an earlier session picked it): no sweep
+fi
+QUICK="$* --expansion $EF --recall-queries 0 --no-cpu-baseline --no-stress-rows --no-host-api --no-placement-check --steps 5 --warmup 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python "$REPO/bench.py" $QUICK > "$OUT/stats_bench.json" 2> "$OUT/stats.log"
 find "$OUT/stats" -name "*kernel_stats.csv" | head -1 | while read f; do cp "$f" "$OUT/kernel_stats.csv"; done
 # the timed launches alone (the whole-process average above also covers the placement draws' candidates)
 find "$OUT/stats" -name "*kernel_trace.csv" | head -1 | while read f; do
   python "$REPO/scripts/trace_timed.py" "$f" "$OUT/stats_bench.json" > "$OUT/kernel_trace_timed.json" || echo "trace_timed failed"
 done
-GROUPS_LIMIT=${PROFILE_TRAFFIC_ONLY:+2}
+GROUPS_LIMIT=${PROFILE_TRAFFIC_ONLY:+4}
 PASS=0
-for counters in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS"; do
+for counters in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_ATOMIC_sum TCC_HIT_sum" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS"; do
   PASS=$((PASS + 1))
   if [ -n "${GROUPS_LIMIT:-}" ] && [ "$PASS" -gt "$GROUPS_LIMIT" ]; then break; fi
   name=$(echo $counters | tr ' ' '_' | cut -c1-40)
@@ -35,7 +39,8 @@ for counters in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDRE
   rm -rf "$OUT/pmc_$name" "$OUT/pmc_$name.json"
 done
 rm -rf "$OUT/stats"
-python "$REPO/scripts/pmc_traffic.py" "$OUT/pmc_FETCH_SIZE.csv" "$OUT/pmc_WRITE_SIZE.csv" search_kernel "$OUT/stats_bench.json" > "$OUT/traffic.json" && cat "$OUT/traffic.json"
+python "$REPO/scripts/pmc_traffic.py" "$OUT/pmc_FETCH_SIZE.csv" "$OUT/pmc_WRITE_SIZE.csv" search_kernel "$OUT/stats_bench.json" \
+    "$OUT/pmc_TCC_EA0_RDREQ_sum_TCC_EA0_RDREQ_32B_sum_.csv" "$OUT/pmc_TCC_EA0_WRREQ_sum_TCC_EA0_WRREQ_64B_sum_.csv" > "$OUT/traffic.json" && cat "$OUT/traffic.json"
 python "$REPO/bench.py" "$@" --expansion $EF --traffic-json "$OUT/traffic.json" --wave-clock > "$OUT/bench.json" 2> "$OUT/bench.log"
 cat "$OUT/bench.json"
 du -sh "$OUT"; head -8 "$OUT/kernel_stats.csv"
