@@ -332,6 +332,7 @@ typedef struct usearch_amd_build_stats_t {
     uint64_t select_distances, reverse_distances, repruned_lists, dropped_requests;
     double seconds_total, seconds_search, seconds_link, seconds_upload;
     uint32_t max_level, reserved;
+    uint64_t refiled_requests;                /**< reverse links that waited a round for room in a hub's inbox; none is lost */
 } usearch_amd_build_stats_t;
 
 /**

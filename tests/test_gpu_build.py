@@ -161,6 +161,47 @@ def test_build_is_reproducible_and_takes_device_vectors():
     assert np.array_equal(first, third)
 
 
+def test_hubs_lose_no_reverse_link(reference):
+    """A few rows that every other row picks as a neighbour (long vectors under the inner product): far more reverse-link
+    requests per pass than a hub's inbox holds. The reference takes any number (index.hpp:3848-3893, one at a time under the
+    node's lock); here the surplus waits for the next re-filing round — counted, and never dropped."""
+    n, ndim = 6000, 32
+    vectors = np.abs(util.make_vectors(n, ndim, "f32", seed=71))
+    vectors[:4] *= 25.0
+    built = usearch_amd.build(vectors, "ip", "f32", connectivity=16, expansion_add=128, max_batch=4096)
+    assert built.stats.dropped_requests == 0
+    assert built.stats.refiled_requests > 0
+    image = built.save_buffer()
+    check_structure(image, n, 16)
+    theirs = refbind.RefIndex.from_buffer(image, view=False, dtype="f32")
+    queries = np.abs(util.make_vectors(200, ndim, "f32", seed=72))
+    found = theirs.search(queries, 4, dtype="f32")[0]
+    assert np.mean(np.sort(found, axis=1) == np.arange(4)[None, :]) > 0.99  # the hubs are everybody's nearest
+
+
+@pytest.mark.parametrize("connectivity,connectivity_base", [(30, 0), (16, 63), (31, 62)])
+def test_wide_base_lists_build(reference, connectivity, connectivity_base):
+    """Base lists of 57 ... 63 neighbours leave 7 ... 1 places in the wave that re-prunes a list: more rounds, same graph rules."""
+    n, ndim = 4000, 48
+    vectors = util.make_vectors(n, ndim, "f32", seed=73)
+    queries = util.make_vectors(200, ndim, "f32", seed=74)
+    built = usearch_amd.build(vectors, "cos", "f32", connectivity=connectivity, connectivity_base=connectivity_base,
+                              expansion_add=128, max_batch=512)
+    assert built.stats.dropped_requests == 0
+    image = built.save_buffer()
+    theirs = refbind.RefIndex.from_buffer(image, view=False, dtype="f32")
+    assert len(theirs) == n and theirs.connectivity == connectivity
+    own = refbind.RefIndex(ndim, "cos", "f32", connectivity=connectivity, expansion_add=128)
+    own.add(np.arange(n, dtype=np.uint64), vectors, threads=1)
+    truth = theirs.search(queries, 10, dtype="f32", exact=True)[0]
+    ours_recall = recall_at(theirs.search(queries, 10, dtype="f32")[0], truth)
+    own_recall = recall_at(own.search(queries, 10, dtype="f32")[0], truth)
+    assert ours_recall >= own_recall - 0.03, (ours_recall, own_recall)
+    got = built.index.search(queries, 10, dtype="f32")
+    okeys, odistances, *_ = util.oracle_search(image, queries, 10, "f32", expansion=64, lanes=built.index.lanes_per_row)
+    assert np.array_equal(got.keys, okeys) and util.same_float_bits(got.distances, odistances)
+
+
 def test_build_edge_cases():
     one = usearch_amd.build(util.make_vectors(1, 16, "f32", seed=1), "cos", "f32")
     assert len(one.index) == 1

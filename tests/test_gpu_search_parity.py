@@ -286,10 +286,14 @@ def test_large_expansion(reference):
     from usearch_amd import Index
     image, _, _ = util.build_image(4000, 48, "l2sq", "f32", seed=51)
     index = Index.restore(image)
-    queries = util.make_vectors(40, 48, "f32", seed=52)
+    queries = util.make_vectors(3000, 48, "f32", seed=52)
     for expansion in (256, 1000):
         got = check_against_oracle(index, image, queries, 10, "f32", expansion)
         assert got.stats.mode == 2  # the visited set no longer fits LDS next to 8 waves per CU
+        # a batch so small that every query has a wave of its own even at the LDS residency keeps the visited set in LDS
+        few = check_against_oracle(index, image, queries[:40], 10, "f32", expansion)
+        assert few.stats.mode == 1
+        assert np.array_equal(few.keys, got.keys[:40]) and util.same_float_bits(few.distances, got.distances[:40])
 
 
 @pytest.mark.parametrize("metric,dtype,ndim", [("hamming", "b1", 64), ("cos", "f16", 48)])

@@ -34,6 +34,20 @@ hipError_t launch_build(metric_kind_t metric, scalar_kind_t scalar, const build_
     return hipErrorInvalidValue;
 }
 
+/// One thread per parked request of the previous round (`from_*`, `from_count` of them): filed again now that the reverse kernel
+/// has applied and emptied the inboxes; what still does not fit is parked for the round after (`b.deferred_*`).
+__global__ void build_refile_kernel(const build_args_t b, const std::uint32_t* from_targets, const cand_t* from_requests,
+                                    std::uint32_t from_count) {
+    const std::uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= from_count)
+        return;
+    const std::uint32_t target = from_targets[i];
+    const cand_t request = from_requests[i];
+    if (!build_file_request(b, target, request))
+        if (build_defer_request(b, target, request))
+            atomicAdd(b.counters + 3, 1ull);
+}
+
 /// Frees a set of device allocations when the build function returns, whatever the path.
 struct device_block_t {
     std::vector<void*> pointers;
@@ -220,8 +234,10 @@ const char* builder_t::build(metric_kind_t metric, scalar_kind_t scalar, std::si
     if (!config_.connectivity_base)
         config_.connectivity_base = 2 * m;
     const std::uint32_t widest = std::max(m, config_.connectivity_base);
-    if (widest > 56)
-        return "Connectivity is too large for the device builder (base connectivity must not exceed 56)";
+    // a list and the requests filed against it are re-pruned by one wave (build_reverse_kernel): 64 - widest requests per round;
+    // what does not fit waits for the next round (build_refile_kernel), so even a one-request inbox builds, in more rounds
+    if (widest > 63)
+        return "Connectivity is too large for the device builder (base connectivity must not exceed 63)";
     const std::uint32_t ef = std::max<std::uint32_t>(widest + 1, config_.expansion_add); // index.hpp:2799-2800
     if (ef > build_max_candidates_k)
         return "Expansion is too large for the device builder";
@@ -379,6 +395,11 @@ const char* builder_t::link_range(std::uint64_t begin, const std::uint64_t end_t
         UA_HIP(allocate((void**)&d_touched_, max_batch * m * 4));
         UA_HIP(allocate((void**)&d_touched_count_, 16));
         UA_HIP(allocate((void**)&d_counters_, 64));
+        for (int lot = 0; lot < 2; ++lot) {
+            UA_HIP(allocate((void**)&d_deferred_targets_[lot], max_batch * m * 4));
+            UA_HIP(allocate(&d_deferred_requests_[lot], max_batch * m * 8));
+        }
+        UA_HIP(allocate((void**)&d_deferred_count_, 16));
         UA_HIP(hipMemset(d_inbox_count_, 0, members * 4));
         UA_HIP(hipMemset(d_counters_, 0, 64));
         workspace_nodes_ = members;
@@ -402,6 +423,7 @@ const char* builder_t::link_range(std::uint64_t begin, const std::uint64_t end_t
     args.touched = d_touched_;
     args.touched_count = d_touched_count_;
     args.counters = d_counters_;
+    args.deferred_cap = (std::uint32_t)std::min<std::uint64_t>(max_batch * m, 0xFFFFFFFFull); // every request of a pass fits
 
     std::vector<std::uint32_t> nodes;
     std::vector<std::uint64_t> host_counters(max_batch);
@@ -443,6 +465,11 @@ const char* builder_t::link_range(std::uint64_t begin, const std::uint64_t end_t
 
             const double t_link = seconds_now();
             UA_HIP(hipMemsetAsync(d_touched_count_, 0, 4, stream));
+            UA_HIP(hipMemsetAsync(d_deferred_count_, 0, 8, stream));
+            int lot = 0;
+            args.deferred_targets = d_deferred_targets_[lot];
+            args.deferred_requests = static_cast<cand_t*>(d_deferred_requests_[lot]);
+            args.deferred_count = d_deferred_count_ + lot;
             args.level = level;
             args.capacity = level ? m : m0;
             args.count = pass_count;
@@ -455,6 +482,31 @@ const char* builder_t::link_range(std::uint64_t begin, const std::uint64_t end_t
             params.reverse = 1;
             params.grid = (std::uint32_t)std::min<std::uint64_t>((std::uint64_t)pass_count * m, resident);
             UA_HIP(launch_build(metric, scalar, params, view, args));
+            // Requests that found their target's inbox full (a hub that many of this pass's nodes picked: the inbox holds 64 - M0
+            // … 32 requests, index.hpp:3848-3893 takes any number) were parked: now that the reverse kernel has applied and
+            // emptied the inboxes they are filed again, round after round, until none is waiting. Nothing is dropped.
+            for (int round = 0; round < 256; ++round) {
+                std::uint32_t waiting = 0;
+                UA_HIP(hipMemcpyAsync(&waiting, d_deferred_count_ + lot, 4, hipMemcpyDeviceToHost, stream));
+                UA_HIP(hipStreamSynchronize(stream));
+                if (!waiting)
+                    break;
+                waiting = std::min(waiting, args.deferred_cap);
+                stats_.refiled_requests += waiting;
+                const std::uint32_t* from_targets = d_deferred_targets_[lot];
+                const cand_t* from_requests = static_cast<const cand_t*>(d_deferred_requests_[lot]);
+                lot ^= 1;
+                UA_HIP(hipMemsetAsync(d_deferred_count_ + lot, 0, 4, stream));
+                UA_HIP(hipMemsetAsync(d_touched_count_, 0, 4, stream));
+                args.deferred_targets = d_deferred_targets_[lot];
+                args.deferred_requests = static_cast<cand_t*>(d_deferred_requests_[lot]);
+                args.deferred_count = d_deferred_count_ + lot;
+                hipLaunchKernelGGL(build_refile_kernel, dim3((waiting + 255) / 256), dim3(256), 0, stream, args, from_targets,
+                                   from_requests, waiting);
+                UA_HIP(hipGetLastError());
+                params.grid = (std::uint32_t)std::min<std::uint64_t>(waiting, resident);
+                UA_HIP(launch_build(metric, scalar, params, view, args));
+            }
             // traversal counters of this pass (tiny) while the link kernels run
             UA_HIP(hipMemcpyAsync(host_counters.data(), d_computed_, (std::size_t)pass_count * 8, hipMemcpyDeviceToHost, stream));
             UA_HIP(hipStreamSynchronize(stream));

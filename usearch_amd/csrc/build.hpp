@@ -38,6 +38,7 @@ struct build_stats_t {
     std::uint64_t search_distances = 0; ///< `computed_distances` of the insertion searches
     std::uint64_t search_hops = 0;
     std::uint64_t select_distances = 0, reverse_distances = 0, repruned_lists = 0, dropped_requests = 0;
+    std::uint64_t refiled_requests = 0; ///< reverse-link requests that waited a round for room in their target's inbox
     double seconds_total = 0, seconds_search = 0, seconds_link = 0, seconds_upload = 0;
     std::uint32_t max_level = 0;
 };
@@ -101,6 +102,10 @@ class builder_t {
     void* d_inbox_ = nullptr;
     float* d_cand_distances_ = nullptr;
     unsigned long long* d_counters_ = nullptr;
+    // reverse-link requests that found an inbox full: two parking lots, filled and drained in turn (build_refile_kernel)
+    std::uint32_t* d_deferred_targets_[2] = {nullptr, nullptr};
+    void* d_deferred_requests_[2] = {nullptr, nullptr};
+    std::uint32_t* d_deferred_count_ = nullptr; ///< [2]
 };
 
 } // namespace usearch_amd

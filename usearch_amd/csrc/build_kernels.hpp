@@ -49,7 +49,33 @@ struct build_args_t {
     std::uint32_t* touched;         ///< nodes with a non-empty inbox
     std::uint32_t* touched_count;
     unsigned long long* counters;   ///< [0] distances in select, [1] distances in reverse, [2] re-pruned lists, [3] dropped requests
+    // requests that found their target's inbox full wait here and are filed again once the reverse kernel has emptied the inboxes
+    // (build_refile_kernel): nothing is dropped unless this list overflows too
+    std::uint32_t* deferred_targets; ///< [deferred_cap]
+    cand_t* deferred_requests;       ///< [deferred_cap] {distance, requesting slot}
+    std::uint32_t* deferred_count;   ///< how many are waiting (may exceed the capacity: the excess was dropped and counted)
+    std::uint32_t deferred_cap;
 };
+
+/// Files reverse-link request {`request`} against `target`; false = the inbox is full (the caller defers or drops it).
+UA_DEVICE bool build_file_request(const build_args_t& b, std::uint32_t target, cand_t request) {
+    const std::uint32_t position = atomicAdd(b.inbox_count + target, 1u);
+    if (position == 0)
+        b.touched[atomicAdd(b.touched_count, 1u)] = target;
+    if (position >= b.inbox_cap)
+        return false;
+    b.inbox[(std::uint64_t)target * b.inbox_cap + position] = request;
+    return true;
+}
+/// A request that did not fit: parked for the next round, or — the parking lot full — dropped. Returns 1 when dropped.
+UA_DEVICE std::uint32_t build_defer_request(const build_args_t& b, std::uint32_t target, cand_t request) {
+    const std::uint32_t position = atomicAdd(b.deferred_count, 1u);
+    if (position >= b.deferred_cap)
+        return 1;
+    b.deferred_targets[position] = target;
+    b.deferred_requests[position] = request;
+    return 0;
+}
 
 UA_DEVICE std::uint32_t* build_list(const build_args_t& b, const snapshot_view_t& ix, std::uint32_t slot) {
     return b.level ? b.upper + (std::uint64_t)(b.upper_ref[slot] + (b.level - 1)) * ix.m
@@ -171,13 +197,9 @@ __global__ __launch_bounds__(64) void build_select_kernel(const snapshot_view_t 
         // reverse-link requests, applied by build_reverse_kernel once the whole batch has filed its own
         if (lane < accepted) {
             const std::uint32_t target = l.sel[lane];
-            const std::uint32_t position = atomicAdd(b.inbox_count + target, 1u);
-            if (position < b.inbox_cap)
-                b.inbox[(std::uint64_t)target * b.inbox_cap + position] = make_cand(l.seld[lane], node);
-            else
-                ++dropped;
-            if (position == 0)
-                b.touched[atomicAdd(b.touched_count, 1u)] = target;
+            const cand_t request = make_cand(l.seld[lane], node);
+            if (!build_file_request(b, target, request))
+                dropped += build_defer_request(b, target, request);
         }
         wave_sync<false>();
     }

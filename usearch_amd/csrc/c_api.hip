@@ -576,6 +576,7 @@ void usearch_amd_build_stats(usearch_amd_builder_t builder, usearch_amd_build_st
     out->seconds_total = s.seconds_total, out->seconds_search = s.seconds_search;
     out->seconds_link = s.seconds_link, out->seconds_upload = s.seconds_upload;
     out->max_level = s.max_level;
+    out->refiled_requests = s.refiled_requests;
 }
 
 int usearch_amd_cast(int from_kind, int to_kind, void const* input, size_t dimensions, void* output) {

@@ -67,7 +67,7 @@ class BuildStats(C.Structure):
                 ("search_hops", C.c_uint64), ("select_distances", C.c_uint64), ("reverse_distances", C.c_uint64),
                 ("repruned_lists", C.c_uint64), ("dropped_requests", C.c_uint64), ("seconds_total", C.c_double),
                 ("seconds_search", C.c_double), ("seconds_link", C.c_double), ("seconds_upload", C.c_double),
-                ("max_level", C.c_uint32), ("reserved", C.c_uint32)]
+                ("max_level", C.c_uint32), ("reserved", C.c_uint32), ("refiled_requests", C.c_uint64)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
