@@ -19,6 +19,7 @@ def main():
     p.add_argument("--dtype", default="i8")
     p.add_argument("--queries", type=int, default=256)
     p.add_argument("--k", type=int, default=10)
+    p.add_argument("--tiles", type=int, nargs="+", default=[0], help="USEARCH_AMD_EXACT_TILE settings to time (0 = the default choice)")
     args = p.parse_args()
     import torch
 
@@ -34,13 +35,18 @@ def main():
         queries = bench.synthetic_vectors_device(args.queries, args.dim, args.dtype, 43, device).cpu().numpy().view(
             bench.NUMPY_STORAGE[args.dtype])
         plain = built.index.search(queries, args.k, dtype=args.dtype, exact=True)
-        tiled = built.index.search(queries, args.k, dtype=args.dtype, exact="tiled")
-        same_keys = float((plain.keys == tiled.keys).mean())
-        same_bits = float((plain.distances.view(np.uint32) == tiled.distances.view(np.uint32)).mean())
-        worst = float(np.nanmax(np.abs(plain.distances - tiled.distances)))
-        print(f"n={n} {args.dtype}x{args.dim}: keys equal {same_keys:.4f}, distance bits equal {same_bits:.4f}, max |diff| {worst:.3g}, "
-              f"counts equal {bool(np.array_equal(plain.counts, tiled.counts))}; wave kernel {plain.stats.kernel_ms:.1f} ms, "
-              f"tiled {tiled.stats.kernel_ms:.1f} ms; first rows {plain.distances[0, :4]} vs {tiled.distances[0, :4]}", flush=True)
+        flops = 2.0 * len(queries) * n * args.dim
+        for tile in args.tiles:
+            os.environ["USEARCH_AMD_EXACT_TILE"] = str(tile)
+            for _ in range(2):
+                tiled = built.index.search(queries, args.k, dtype=args.dtype, exact="tiled")
+            same_keys = float((plain.keys == tiled.keys).mean())
+            same_bits = float((plain.distances.view(np.uint32) == tiled.distances.view(np.uint32)).mean())
+            worst = float(np.nanmax(np.abs(plain.distances - tiled.distances)))
+            print(f"n={n} {args.dtype}x{args.dim}, {len(queries)} queries, tile setting {tile}: {tiled.stats.kernel_ms:.1f} ms = "
+                  f"{flops / tiled.stats.kernel_ms / 1e9:.0f} T(FL)OP/s; against the wave-per-query kernel ({plain.stats.kernel_ms:.1f} ms): "
+                  f"keys equal {same_keys:.4f}, distance bits equal {same_bits:.4f}, max |diff| {worst:.3g}, "
+                  f"counts equal {bool(np.array_equal(plain.counts, tiled.counts))}", flush=True)
         del built
 
 

@@ -67,16 +67,19 @@ def test_exact_search_of_a_raw_dataset():
     assert np.array_equal(keys[:, 0] == np.arange(50), distances[:, 0] == 0) and np.all(distances[:, 0] == 0)
 
 
+@pytest.mark.parametrize("tile", [64, 256])
 @pytest.mark.parametrize("metric,dtype,ndim,n,k", [("l2sq", "i8", 96, 20011, 10), ("cos", "i8", 40, 9000, 64),
-                                                   ("ip", "i8", 130, 5003, 7)])
-def test_tiled_exact_search_is_bit_identical_for_i8(reference, metric, dtype, ndim, n, k):
-    """The matrix-unit kernel (exact_tiled.hip) sums integers exactly and closes with the same arithmetic as the
-    wave-per-query kernel, so keys, distance bits and counts are identical — ties resolved as lower_bound insertion in slot
-    order does — tombstones skipped, ragged query counts, ragged row tiles, ragged dimensions."""
+                                                   ("ip", "i8", 130, 5003, 7), ("cos", "i8", 200, 9000, 16)])
+def test_tiled_exact_search_is_bit_identical_for_i8(reference, monkeypatch, metric, dtype, ndim, n, k, tile):
+    """The matrix-unit kernels (exact_tiled.hip: 64 queries per workgroup, and the wide tile of 256 for batches that fill the
+    chip with it — forced here either way) sum integers exactly and close with the same arithmetic as the wave-per-query
+    kernel, so keys, distance bits and counts are identical — ties resolved as lower_bound insertion in slot order does —
+    tombstones skipped, ragged query counts, ragged row tiles, ragged dimensions."""
     from usearch_amd import Index
+    monkeypatch.setenv("USEARCH_AMD_EXACT_TILE", str(tile))
     removed = np.arange(5, n, 13) + 1000
     image, vectors, _ = util.build_image(n, ndim, metric, dtype, seed=93, remove=removed[:200], expansion_add=16, connectivity=4)
-    queries = util.make_vectors(131, ndim, dtype, seed=94)
+    queries = util.make_vectors(131 if tile == 64 else 700, ndim, dtype, seed=94)
     queries[:20] = vectors[:20]
     index = Index.restore(image)
     exact = index.search(queries, k, exact=True)
@@ -87,14 +90,16 @@ def test_tiled_exact_search_is_bit_identical_for_i8(reference, metric, dtype, nd
     assert not np.isin(tiled.keys, removed[:200]).any()
 
 
+@pytest.mark.parametrize("tile", [64, 256])
 @pytest.mark.parametrize("metric,dtype,ndim,n,k", [("cos", "f16", 768, 12001, 10), ("ip", "f16", 100, 9000, 32),
-                                                   ("cos", "bf16", 96, 7000, 10), ("ip", "bf16", 768, 3000, 5)])
-def test_tiled_exact_search_of_float_pairs_is_within_tolerance(reference, metric, dtype, ndim, n, k):
+                                                   ("cos", "bf16", 96, 7000, 10), ("ip", "bf16", 768, 5000, 5)])
+def test_tiled_exact_search_of_float_pairs_is_within_tolerance(reference, monkeypatch, metric, dtype, ndim, n, k, tile):
     """f16 / bf16: products are exact, the matrix unit accumulates them in f32 in its own order — every distance within the
     float tolerance of the bit-exact kernel's, the same neighbours wherever distances are separated by more than that."""
     from usearch_amd import Index
+    monkeypatch.setenv("USEARCH_AMD_EXACT_TILE", str(tile))
     image, vectors, _ = util.build_image(n, ndim, metric, dtype, seed=95, expansion_add=16, connectivity=4)
-    queries = util.make_vectors(70, ndim, dtype, seed=96)
+    queries = util.make_vectors(70 if tile == 64 else 300, ndim, dtype, seed=96)
     queries[:10] = vectors[:10]
     index = Index.restore(image)
     exact = index.search(queries, k, exact=True, dtype=dtype)

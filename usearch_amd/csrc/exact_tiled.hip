@@ -20,6 +20,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 #include "engine.hpp"
 #include "host_util.hpp"
@@ -87,6 +89,41 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const std::uint8_t* rows
         if (lane == 0)
             out[row] = scalar_ak == scalar_i8_k ? (std::uint32_t)exact : __builtin_bit_cast(std::uint32_t, sum);
     }
+}
+
+/// The metric's closing arithmetic from the matrix unit's sum Σab and the two stored Σx² (bits of an f32, or an exact int32 for
+/// i8) — the same expressions as `finalize_distance` of kernels.hpp.
+template <int metric_ak, int scalar_ak, typename sum_at>
+__device__ __forceinline__ float closing_distance(sum_at sum, std::uint32_t a2_bits, std::uint32_t b2_bits) {
+    if constexpr (scalar_ak == scalar_i8_k) {
+        const int ab = sum, a2 = (int)a2_bits, b2 = (int)b2_bits;
+        if constexpr (metric_ak == metric_cos_k) { // metric_cos_i8_t, index_plugins.hpp:1583-1607
+            const float a2f = __builtin_sqrtf((float)a2), b2f = __builtin_sqrtf((float)b2);
+            return ab != 0 ? 1.f - (float)ab / (a2f * b2f) : 0.f;
+        } else if constexpr (metric_ak == metric_ip_k) {
+            return 1.f - (float)ab;
+        } else { // metric_l2sq_i8_t 1613-1630
+            return (float)(a2 + b2 - 2 * ab);
+        }
+    } else {
+        const float ab = sum, a2 = __builtin_bit_cast(float, a2_bits), b2 = __builtin_bit_cast(float, b2_bits);
+        if constexpr (metric_ak == metric_cos_k) { // metric_cos_gt, index_plugins.hpp:1334-1359
+            if (a2 == 0.f && b2 == 0.f)
+                return 0.f;
+            if (a2 == 0.f || b2 == 0.f)
+                return 1.f;
+            return 1.f - ab / (__builtin_sqrtf(a2) * __builtin_sqrtf(b2));
+        } else {
+            return 1.f - ab;
+        }
+    }
+}
+
+/// 1/√Σx² for the conservative bound of the wide kernel's epilogue; NaN (= "take the exact path") when the norm is zero or so
+/// small that the reciprocal would overflow.
+template <bool integers_ak> __device__ __forceinline__ float bound_scale(std::uint32_t norm_bits) {
+    const float x = integers_ak ? (float)(int)norm_bits : __builtin_bit_cast(float, norm_bits);
+    return x > 1e-30f ? __builtin_amdgcn_rsqf(x) : __builtin_nanf("");
 }
 
 /// (distance, slot) `a` goes before `b` in what `search_exact_` returns: closer first, the later slot first among equals.
@@ -198,30 +235,7 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const snapshot_view_t 
             for (int r = 0; r < 16; ++r) {
                 const std::uint32_t i = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const std::uint32_t j = wave * 32 + (lane & 31);
-                float distance;
-                if constexpr (scalar_ak == scalar_i8_k) {
-                    const int ab = acc[t][r], a2 = (int)norms_q[i], b2 = (int)norms_r[j];
-                    if constexpr (metric_ak == metric_cos_k) { // metric_cos_i8_t, index_plugins.hpp:1583-1607
-                        const float a2f = __builtin_sqrtf((float)a2), b2f = __builtin_sqrtf((float)b2);
-                        distance = ab != 0 ? 1.f - (float)ab / (a2f * b2f) : 0.f;
-                    } else if constexpr (metric_ak == metric_ip_k) {
-                        distance = 1.f - (float)ab;
-                    } else { // metric_l2sq_i8_t 1613-1630
-                        distance = (float)(a2 + b2 - 2 * ab);
-                    }
-                } else {
-                    const float ab = acc[t][r], a2 = __builtin_bit_cast(float, norms_q[i]), b2 = __builtin_bit_cast(float, norms_r[j]);
-                    if constexpr (metric_ak == metric_cos_k) { // metric_cos_gt, index_plugins.hpp:1334-1359
-                        if (a2 == 0.f && b2 == 0.f)
-                            distance = 0.f;
-                        else if (a2 == 0.f || b2 == 0.f)
-                            distance = 1.f;
-                        else
-                            distance = 1.f - ab / (__builtin_sqrtf(a2) * __builtin_sqrtf(b2));
-                    } else {
-                        distance = 1.f - ab;
-                    }
-                }
+                const float distance = closing_distance<metric_ak, scalar_ak>(acc[t][r], norms_q[i], norms_r[j]);
                 tile_d[i * (tile_rows_k + 1) + j] = valid_r[j] ? distance : __builtin_inff();
             }
         }
@@ -296,6 +310,340 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const snapshot_view_t 
         out_counts[(std::uint64_t)blockIdx.y * query_count + first_query + thread] = top_n[thread];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+//  The wide tile: 256 queries × 128 rows per workgroup of 8 waves, both operands double-buffered through LDS, register epilogue
+// ---------------------------------------------------------------------------------------------------------------------
+
+constexpr int wide_queries_k = 256; ///< queries per workgroup: a row is read once per 256 queries
+constexpr int wide_rows_k = 128;    ///< dataset rows per tile
+constexpr int wide_threads_k = 512; ///< 8 waves; wave w multiplies queries [32w, 32w + 32) with the tile's 128 rows
+constexpr int wide_wanted_k = 16;   ///< results per query this kernel keeps (its lists share LDS with two staging buffers)
+constexpr int wide_stage_rows_k = wide_queries_k + wide_rows_k;
+constexpr int wide_loads_k = wide_stage_rows_k * (chunk_bytes_k / 16) / wide_threads_k; ///< 16-byte loads per thread per chunk: 6
+constexpr std::uint32_t wide_stage_bytes_k = wide_stage_rows_k * pitch_k;
+
+inline std::uint64_t wide_padded_stride(std::uint64_t bytes_per_vector) {
+    return (bytes_per_vector + chunk_bytes_k - 1) / chunk_bytes_k * chunk_bytes_k;
+}
+constexpr std::uint32_t wide_lds_bytes() {
+    return 2 * wide_stage_bytes_k + wide_queries_k * wide_wanted_k * 8 + wide_queries_k * 4 * 3 + 2 * wide_rows_k * 4;
+}
+
+/**
+ *  grid = 1-D. Workgroups are dealt to the 8 XCDs round-robin by their linear index; inside an XCD, 32 consecutive workgroups
+ *  (one per CU) are 4 query tiles × 8 row partitions, so what the XCD's L2 holds at any time is 4 query tiles (1.5 MB for
+ *  768-d f16) and the row tiles 8 partitions are streaming, each shared by 4 workgroups.
+ *
+ *  Per 128-byte chunk of the summation: 6 global loads per thread issued TWO chunks ahead into registers, 4 × (1 query
+ *  fragment + 4 row fragments → 4 MFMAs) per wave out of the current LDS buffer, the chunk after next written to the other
+ *  buffer, one barrier. The accumulators never visit LDS: a lane tests its 64 sums against the queries' current k-th best
+ *  with a cheap conservative bound, and only the few that may enter a list (≈ k·ln(rows/k) per query over the whole scan,
+ *  after the first tile) take the exact closing arithmetic and the ordered insert, one at a time, by the wave that owns the
+ *  query's list. Same lists as the 64-query kernel: the best `wanted` under (distance ↑, slot ↓), whatever the order of arrival.
+ */
+template <int metric_ak, int scalar_ak>
+__global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapshot_view_t ix, const std::uint8_t* padded_queries,
+                                                                    std::uint64_t padded_stride, std::uint32_t query_count,
+                                                                    std::uint32_t wanted, std::uint64_t rows_per_partition,
+                                                                    std::uint32_t query_tiles, std::uint32_t local_partitions,
+                                                                    const std::uint32_t* row_norms, const std::uint32_t* query_norms,
+                                                                    std::uint32_t map_keys, float* out_distances,
+                                                                    std::uint64_t* out_keys, std::uint64_t* out_counts) {
+    using accumulator_t = typename accumulator_gt<scalar_ak>::type;
+    constexpr bool integers = scalar_ak == scalar_i8_k;
+    using sum_t = typename std::conditional<integers, int, float>::type;
+    extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
+    float* list_d = reinterpret_cast<float*>(lds + 2 * wide_stage_bytes_k);                   // [256][16]
+    std::uint32_t* list_s = reinterpret_cast<std::uint32_t*>(list_d + wide_queries_k * wide_wanted_k);
+    std::uint32_t* top_n = list_s + wide_queries_k * wide_wanted_k;                              // [256]
+    float* limit = reinterpret_cast<float*>(top_n + wide_queries_k);                            // [256] k-th best, +inf while filling
+    std::uint32_t* norms_q = reinterpret_cast<std::uint32_t*>(limit + wide_queries_k);          // [256]
+    std::uint32_t* norms_r = norms_q + wide_queries_k; // [2][128] Σb² of the rows staged in either buffer
+
+    const std::uint32_t thread = threadIdx.x, wave = thread / 64, lane = thread % 64;
+    // ---- which (query tile, partition) this workgroup is
+    const std::uint32_t xcd = blockIdx.x % 8, sequence = blockIdx.x / 8;
+    const std::uint32_t per_group = 4 * local_partitions;
+    const std::uint32_t query_tile = sequence / per_group * 4 + sequence % 4;
+    const std::uint32_t partition = sequence % per_group / 4 * 8 + xcd;
+    if (query_tile >= query_tiles) // uniform: the grid is padded to whole groups of 4 query tiles
+        return;
+    const std::uint32_t first_query = query_tile * wide_queries_k;
+    const std::uint64_t first_row = (std::uint64_t)partition * rows_per_partition;
+    const std::uint64_t last_row = first_row + rows_per_partition < ix.size ? first_row + rows_per_partition : ix.size;
+    const std::uint32_t bytes = ix.bytes_per_vector, row_bytes = ix.chunks * 16u;
+    const std::uint32_t chunks = (bytes + chunk_bytes_k - 1) / chunk_bytes_k;
+    const std::uint32_t tiles = first_row < last_row ? (std::uint32_t)((last_row - first_row + wide_rows_k - 1) / wide_rows_k) : 0u;
+    const std::uint32_t total = tiles * chunks;
+
+    for (std::uint32_t i = thread; i < wide_queries_k; i += wide_threads_k) {
+        top_n[i] = 0;
+        limit[i] = __builtin_inff();
+        norms_q[i] = first_query + i < query_count ? query_norms[first_query + i] : 0u;
+    }
+    __syncthreads();
+
+    // ---- per lane: the 16 queries its accumulator registers belong to (register r ↔ query 32·wave + (r&3) + 8(r>>2) + 4(lane>>5))
+    std::uint32_t exists = 0;   // bit r: that query is inside the batch
+    float query_scale[16];      // cos: 1/√Σa² (the conservative bound only; the exact arithmetic reads norms_q)
+    std::uint32_t query_norm[16];
+    float bound[16];            // copy of limit[] for those queries, refreshed after this wave changed a list
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const std::uint32_t i = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        exists |= (first_query + i < query_count ? 1u : 0u) << r;
+        query_norm[r] = norms_q[i];
+        query_scale[r] = metric_ak == metric_cos_k ? bound_scale<integers>(query_norm[r]) : 1.f;
+        bound[r] = __builtin_inff();
+    }
+
+    // ---- staging: 8 consecutive threads move one row's 128 bytes; thread t owns rows t/8 + 64·pass (4 passes of queries, 2 of
+    //      rows) and, with them, one row's Σb². No branch anywhere (addresses are clamped into the arrays, what lies outside is
+    //      replaced by zeros afterwards), so the loads of two chunks stay in flight across the barriers: the compiler counts them.
+    const std::uint32_t segment = thread % 8, stage_row = thread / 8;
+    const std::uint8_t* my_queries = padded_queries + (std::uint64_t)(first_query + stage_row) * padded_stride + segment * 16;
+    struct staged_t { // named members, no array: the chunk in flight must live in registers, not in a private-memory array
+        uint4 q0, q1, q2, q3, r0, r1;
+        std::uint32_t norm;
+    };
+    static_assert(wide_loads_k == 6 && wide_queries_k == 256 && wide_rows_k == 128, "staged_t is written out for this shape");
+    std::uint32_t fetch_tile = 0, fetch_chunk = 0;
+    // Nothing is computed on a loaded value before it is written to LDS (a select here would make the wave wait for the load
+    // right away): a row past the partition's end re-reads the last row (the epilogue drops it: `live`), bytes past a row's
+    // last 16-byte chunk re-read that chunk and meet the zeros the padded queries hold there.
+    auto fetch_row = [&](std::uint64_t row, std::uint32_t byte) -> uint4 {
+        const std::uint32_t byte_inside = byte < row_bytes ? byte : row_bytes - 16; // stored rows: 16-byte aligned, zero padded to 16
+        const std::uint64_t row_inside = row < last_row ? row : last_row - 1;
+        return *reinterpret_cast<const uint4*>(ix.vectors + row_inside * ix.row_stride + byte_inside);
+    };
+    auto fetch = [&]() -> staged_t {
+        staged_t regs;
+        const std::uint32_t byte = fetch_chunk * chunk_bytes_k + segment * 16;
+        const std::uint64_t tile_row = first_row + (std::uint64_t)fetch_tile * wide_rows_k;
+        const std::uint8_t* source = my_queries + fetch_chunk * chunk_bytes_k; // the padded copy: every chunk of every query of the tile exists
+        regs.q0 = *reinterpret_cast<const uint4*>(source);
+        regs.q1 = *reinterpret_cast<const uint4*>(source + 64 * padded_stride);
+        regs.q2 = *reinterpret_cast<const uint4*>(source + 128 * padded_stride);
+        regs.q3 = *reinterpret_cast<const uint4*>(source + 192 * padded_stride);
+        regs.r0 = fetch_row(tile_row + stage_row, byte);
+        regs.r1 = fetch_row(tile_row + 64 + stage_row, byte);
+        {
+            const std::uint64_t row = tile_row + (thread % wide_rows_k);
+            regs.norm = row_norms[row < last_row ? row : last_row - 1];
+        }
+        if (++fetch_chunk == chunks)
+            fetch_chunk = 0, ++fetch_tile;
+        return regs;
+    };
+    auto commit = [&](std::uint32_t buffer, const staged_t regs) {
+        std::uint8_t* cell = lds + buffer * wide_stage_bytes_k + stage_row * pitch_k + segment * 16;
+        *reinterpret_cast<uint4*>(cell) = regs.q0;
+        *reinterpret_cast<uint4*>(cell + 64 * pitch_k) = regs.q1;
+        *reinterpret_cast<uint4*>(cell + 128 * pitch_k) = regs.q2;
+        *reinterpret_cast<uint4*>(cell + 192 * pitch_k) = regs.q3;
+        *reinterpret_cast<uint4*>(cell + 256 * pitch_k) = regs.r0;
+        *reinterpret_cast<uint4*>(cell + 320 * pitch_k) = regs.r1;
+        if (thread < wide_rows_k)
+            norms_r[buffer * wide_rows_k + thread] = regs.norm;
+    };
+
+    accumulator_t acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[u][r] = 0;
+    std::uint32_t work_tile = 0, work_chunk = 0;
+
+    auto multiply_chunk = [&](std::uint32_t buffer) {
+        const std::uint8_t* stage = lds + buffer * wide_stage_bytes_k;
+        const std::uint8_t* mine = stage + (wave * 32 + (lane & 31)) * pitch_k + (lane >> 5) * 16;
+        const std::uint8_t* theirs = stage + (wide_queries_k + (lane & 31)) * pitch_k + (lane >> 5) * 16;
+#pragma unroll
+        for (int step = 0; step < chunk_bytes_k / 32; ++step) {
+            const uint4 a = *reinterpret_cast<const uint4*>(mine + step * 32);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint4 b = *reinterpret_cast<const uint4*>(theirs + u * 32 * pitch_k + step * 32);
+                acc[u] = multiply<scalar_ak>(a, b, acc[u]);
+            }
+        }
+    };
+
+    /// The tile's 32 × 128 sums of this wave against its queries' lists; the accumulators are cleared for the next tile.
+    auto fold_tile = [&](std::uint32_t buffer) {
+        const std::uint64_t tile_row = first_row + (std::uint64_t)work_tile * wide_rows_k;
+        bool changed = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const std::uint64_t my_row = tile_row + u * 32 + (lane & 31);
+            bool live = my_row < last_row;
+            if (ix.has_tombstones && live)
+                live = ix.keys[my_row] != free_key_k;
+            const std::uint32_t b2 = norms_r[buffer * wide_rows_k + u * 32 + (lane & 31)];
+            const float row_scale = metric_ak == metric_cos_k ? bound_scale<integers>(b2) : 1.f;
+            // conservative: never false for a sum whose exact distance is ≤ the bound (NaN — a zero norm — compares "may")
+            std::uint32_t may = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                bool candidate;
+                if constexpr (integers && metric_ak == metric_l2sq_k) {
+                    candidate = closing_distance<metric_ak, scalar_ak>(acc[u][r], query_norm[r], b2) <= bound[r];
+                } else if constexpr (metric_ak == metric_ip_k) {
+                    candidate = 1.f - (float)acc[u][r] <= bound[r];
+                } else { // cos: 1 − Σab/(√Σa²·√Σb²) up to a few ulps; an integer Σab = 0 closes to 0 whatever the norms
+                    const float approximate = 1.f - (float)acc[u][r] * query_scale[r] * row_scale;
+                    candidate = !(approximate > bound[r] + 1e-5f) || (integers && acc[u][r] == 0);
+                }
+                may |= (candidate ? 1u : 0u) << r;
+            }
+            may = live ? may & exists : 0u;
+            if (__ballot(may != 0) == 0)
+                continue;
+            for (int r = 0; r < 16; ++r) { // rare: kept rolled
+                std::uint64_t pending = __ballot((may >> r) & 1u);
+                while (pending) {
+                    const std::uint32_t source = (std::uint32_t)__ffsll((long long)pending) - 1;
+                    pending &= pending - 1;
+                    const std::uint32_t i = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (source >> 5);
+                    const std::uint32_t s = (std::uint32_t)(tile_row + u * 32 + (source & 31));
+                    sum_t sum = 0;
+#pragma unroll
+                    for (int rr = 0; rr < 16; ++rr) // the register index is a loop variable: select, then broadcast
+                        sum = rr == r ? acc[u][rr] : sum;
+                    sum = __shfl(sum, (int)source, 64);
+                    const std::uint32_t source_b2 = (std::uint32_t)__shfl((int)b2, (int)source, 64);
+                    const float d = closing_distance<metric_ak, scalar_ak>(sum, norms_q[i], source_b2);
+                    float* entries_d = list_d + i * wide_wanted_k;
+                    std::uint32_t* entries_s = list_s + i * wide_wanted_k;
+                    std::uint32_t size = top_n[i];
+                    if (size == wanted && !goes_before(d, s, entries_d[size - 1], entries_s[size - 1]))
+                        continue;
+                    // position = entries that go before the newcomer; the ones at and after it move one cell down
+                    const bool mine = lane < size;
+                    const float my_d = mine ? entries_d[lane] : 0.f;
+                    const std::uint32_t my_s = mine ? entries_s[lane] : 0u;
+                    const std::uint32_t position = (std::uint32_t)__popcll(__ballot(mine && goes_before(my_d, my_s, d, s)));
+                    const std::uint32_t grown = size < wanted ? size + 1 : size;
+                    if (mine && lane >= position && lane + 1 < grown)
+                        entries_d[lane + 1] = my_d, entries_s[lane + 1] = my_s;
+                    if (lane == position)
+                        entries_d[position] = d, entries_s[position] = s;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                    if (lane == 0) {
+                        top_n[i] = grown;
+                        limit[i] = grown == wanted ? entries_d[grown - 1] : __builtin_inff();
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                    changed = true;
+                }
+            }
+        }
+        if (__ballot(changed)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                bound[r] = limit[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[u][r] = 0;
+    };
+    auto finish_chunk = [&](std::uint32_t buffer) {
+        if (++work_chunk == chunks) {
+            fold_tile(buffer);
+            work_chunk = 0, ++work_tile;
+        }
+    };
+
+    // ---- the pipeline: chunk c is multiplied out of buffer c & 1 while chunk c + 1 sits in one register set (on its way to the
+    //      other buffer) and chunk c + 2 is in flight into the other set
+    //      (fetches past the end re-read the last tile into registers nobody commits to a buffer that is multiplied)
+    //      The pipeline fills by running the loop body once with the multiplication switched off, so the loop is entered with
+    //      no load in flight and its own register sets are the only ones the compiler has to count waits for.
+    staged_t even = {}, odd = {};
+    for (std::int64_t c = tiles ? -2 : 0; c < (std::int64_t)total; c += 2) {
+        even = fetch();
+        if (c >= 0) {
+            multiply_chunk(0);
+            finish_chunk(0);
+        }
+        commit(1, odd);
+        __syncthreads();
+        if (c + 1 >= (std::int64_t)total)
+            break;
+        odd = fetch();
+        if (c >= 0) {
+            multiply_chunk(1);
+            finish_chunk(1);
+        }
+        commit(0, even);
+        __syncthreads();
+    }
+
+    // ---- this partition's lists, laid out [partition][query][wanted] like the wave-per-query kernel's
+    __syncthreads();
+    for (std::uint32_t cell = thread; cell < wide_queries_k * wanted; cell += wide_threads_k) {
+        const std::uint32_t i = cell / wanted, position = cell % wanted;
+        const std::uint32_t q = first_query + i;
+        if (q >= query_count)
+            continue;
+        const std::uint64_t out = ((std::uint64_t)partition * query_count + q) * wanted + position;
+        std::uint64_t key = 0;
+        std::uint32_t bits = signaling_nan_bits_k;
+        if (position < top_n[i]) {
+            const std::uint32_t slot = list_s[i * wide_wanted_k + position];
+            key = map_keys ? ix.keys[slot] : (std::uint64_t)slot;
+            bits = __builtin_bit_cast(std::uint32_t, list_d[i * wide_wanted_k + position]);
+        }
+        out_keys[out] = key;
+        reinterpret_cast<std::uint32_t*>(out_distances)[out] = bits;
+    }
+    for (std::uint32_t i = thread; i < wide_queries_k; i += wide_threads_k)
+        if (first_query + i < query_count)
+            out_counts[(std::uint64_t)partition * query_count + first_query + i] = top_n[i];
+}
+
+/// Queries as the wide kernel stages them: whole 128-byte chunks of every row, whole tiles of 256 rows, zeros where the batch ends.
+__global__ __launch_bounds__(256) void pad_queries_kernel(const std::uint8_t* queries, std::uint64_t stride, std::uint32_t count,
+                                                          std::uint32_t bytes, std::uint8_t* padded, std::uint64_t padded_stride,
+                                                          std::uint64_t padded_rows) {
+    const std::uint64_t total = padded_rows * padded_stride;
+    for (std::uint64_t cell = (std::uint64_t)blockIdx.x * 256 + threadIdx.x; cell < total; cell += (std::uint64_t)gridDim.x * 256) {
+        const std::uint64_t row = cell / padded_stride, byte = cell % padded_stride;
+        padded[cell] = row < count && byte < bytes ? queries[row * stride + byte] : (std::uint8_t)0;
+    }
+}
+
+template <int metric_ak, int scalar_ak>
+hipError_t launch_wide(const snapshot_view_t& view, const std::uint8_t* queries, std::uint64_t query_stride,
+                       std::uint8_t* padded, std::uint32_t query_count, std::uint32_t wanted, std::uint32_t local_partitions,
+                       std::uint64_t rows_per_partition, const std::uint32_t* row_norms, const std::uint32_t* query_norms,
+                       bool map_keys, float* out_distances, std::uint64_t* out_keys, std::uint64_t* out_counts,
+                       hipStream_t stream) {
+    auto kernel = exact_wide_kernel<metric_ak, scalar_ak>;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)wide_lds_bytes());
+    if (e != hipSuccess)
+        return e;
+    const std::uint32_t query_tiles = (query_count + wide_queries_k - 1) / wide_queries_k;
+    const std::uint32_t groups = (query_tiles + 3) / 4;
+    const std::uint64_t padded_stride = wide_padded_stride(view.bytes_per_vector);
+    const std::uint64_t padded_rows = (std::uint64_t)query_tiles * wide_queries_k;
+    hipLaunchKernelGGL(pad_queries_kernel, dim3((unsigned)std::min<std::uint64_t>((padded_rows * padded_stride + 255) / 256, 1u << 20)),
+                       dim3(256), 0, stream, queries, query_stride, query_count, (std::uint32_t)view.bytes_per_vector, padded,
+                       padded_stride, padded_rows);
+    hipLaunchKernelGGL(kernel, dim3(groups * 4 * local_partitions * 8), dim3(wide_threads_k), wide_lds_bytes(), stream, view,
+                       (const std::uint8_t*)padded, padded_stride, query_count, wanted, rows_per_partition, query_tiles, local_partitions, row_norms,
+                       query_norms, map_keys ? 1u : 0u, out_distances, out_keys, out_counts);
+    return hipGetLastError();
+}
+
 constexpr std::uint32_t tiled_lds_bytes() {
     constexpr std::uint32_t staging = (tile_queries_k + tile_rows_k) * pitch_k;
     constexpr std::uint32_t tile = tile_queries_k * (tile_rows_k + 1) * 4;
@@ -359,15 +707,32 @@ const char* exact_search_tiled_device(metric_kind_t metric, scalar_kind_t scalar
         return "Batch is too large";
     if (!view.size)
         return "Nothing to scan";
-    // enough (query tile, partition) workgroups to fill the chip several times over; few enough lists per query to fold
-    const std::uint64_t query_tiles = (count + tile_queries_k - 1) / tile_queries_k;
-    std::uint64_t partitions = std::max<std::uint64_t>(1, (2048 + query_tiles - 1) / query_tiles);
-    partitions = std::min<std::uint64_t>(partitions, std::max<std::uint64_t>(1, 8192 / wanted));
-    partitions = std::min<std::uint64_t>(partitions, std::max<std::uint64_t>(1, view.size / (4 * tile_rows_k)));
-    partitions = std::min<std::uint64_t>(partitions, 65535);
-    std::uint64_t rows_per_partition = (view.size + partitions - 1) / partitions;
-    rows_per_partition = (rows_per_partition + tile_rows_k - 1) / tile_rows_k * tile_rows_k;
-    partitions = (view.size + rows_per_partition - 1) / rows_per_partition;
+    // The wide tile (256 queries per workgroup: a quarter of the dataset passes) takes batches that fill the chip with it; the
+    // 64-query tile keeps the small batches and the long result lists. USEARCH_AMD_EXACT_TILE=64 / 256 forces either.
+    const std::size_t forced_tile = env_size("USEARCH_AMD_EXACT_TILE", 0);
+    const bool wide = forced_tile != 64 && wanted <= (std::size_t)wide_wanted_k && view.size >= 8u * 4u * wide_rows_k &&
+                      (forced_tile == 256 || count > 512);
+    std::uint64_t partitions, rows_per_partition, local_partitions = 0;
+    if (wide) {
+        // partitions come in eights (one per XCD at a time, exact_wide_kernel); enough workgroups for four rounds of the chip
+        const std::uint64_t query_tiles = ((count + wide_queries_k - 1) / wide_queries_k + 3) / 4 * 4;
+        local_partitions = std::min<std::uint64_t>(32, std::max<std::uint64_t>(8, (1024 / (8 * query_tiles) + 7) / 8 * 8));
+        while (local_partitions > 1 && view.size / (local_partitions * 8) < 4 * wide_rows_k)
+            local_partitions /= 2;
+        partitions = local_partitions * 8;
+        rows_per_partition = (view.size + partitions - 1) / partitions;
+        rows_per_partition = (rows_per_partition + wide_rows_k - 1) / wide_rows_k * wide_rows_k;
+    } else {
+        // enough (query tile, partition) workgroups to fill the chip several times over; few enough lists per query to fold
+        const std::uint64_t query_tiles = (count + tile_queries_k - 1) / tile_queries_k;
+        partitions = std::max<std::uint64_t>(1, (2048 + query_tiles - 1) / query_tiles);
+        partitions = std::min<std::uint64_t>(partitions, std::max<std::uint64_t>(1, 8192 / wanted));
+        partitions = std::min<std::uint64_t>(partitions, std::max<std::uint64_t>(1, view.size / (4 * tile_rows_k)));
+        partitions = std::min<std::uint64_t>(partitions, 65535);
+        rows_per_partition = (view.size + partitions - 1) / partitions;
+        rows_per_partition = (rows_per_partition + tile_rows_k - 1) / tile_rows_k * tile_rows_k;
+        partitions = (view.size + rows_per_partition - 1) / rows_per_partition;
+    }
 
     struct scratch_t {
         std::vector<void*> pointers;
@@ -397,6 +762,10 @@ const char* exact_search_tiled_device(metric_kind_t metric, scalar_kind_t scalar
     UA_HIP(scratch.allocate((void**)&partial_distances, partitions * count * wanted * 4));
     UA_HIP(scratch.allocate((void**)&partial_keys, partitions * count * wanted * 8));
     UA_HIP(scratch.allocate((void**)&partial_counts, partitions * count * 8));
+    std::uint8_t* padded_queries = nullptr;
+    if (wide)
+        UA_HIP(scratch.allocate((void**)&padded_queries, (count + wide_queries_k - 1) / wide_queries_k * wide_queries_k *
+                                                              wide_padded_stride(view.bytes_per_vector)));
     if (kernel_ms) {
         UA_HIP(hipEventCreate(&scratch.begin));
         UA_HIP(hipEventCreate(&scratch.end));
@@ -409,7 +778,11 @@ const char* exact_search_tiled_device(metric_kind_t metric, scalar_kind_t scalar
         e = launch_norms<sc>(view.vectors, view.size, view.row_stride, view.bytes_per_vector, row_norms, stream);      \
         if (e == hipSuccess)                                                                                           \
             e = launch_norms<sc>(query_bytes, count, stride_bytes, view.bytes_per_vector, query_norms, stream);        \
-        if (e == hipSuccess)                                                                                           \
+        if (e == hipSuccess && wide)                                                                                   \
+            e = launch_wide<m, sc>(view, query_bytes, stride_bytes, padded_queries, (std::uint32_t)count,              \
+                                   (std::uint32_t)wanted, (std::uint32_t)local_partitions, rows_per_partition, row_norms, query_norms,        \
+                                   map_keys, partial_distances, partial_keys, partial_counts, stream);                 \
+        else if (e == hipSuccess)                                                                                      \
             e = launch_tiled<m, sc>(view, query_bytes, stride_bytes, (std::uint32_t)count, (std::uint32_t)wanted,      \
                                     (std::uint32_t)partitions, rows_per_partition, row_norms, query_norms, map_keys,   \
                                     partial_distances, partial_keys, partial_counts, stream);                          \
