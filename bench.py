@@ -264,6 +264,131 @@ PRESETS = {
 }
 
 
+MFMA_PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "i8": 5000.0}  # MI355X_MICROARCH.md: dense f16 / bf16 2.5 PF; i8 at twice that rate
+
+
+def run_exact(args) -> None:
+    """`python bench.py --exact [--gpus N]`: a step is `search(…, exact = true)` of the whole batch against every stored vector
+    (index.hpp:4252-4268 per query; `exact_search_t`, index_plugins.hpp:2071-2164, for a batch) through the matrix-unit kernel
+    of csrc/exact_tiled.hip — SURVEY §8(f) rank 1, and where bench.py's own recall ground truth comes from. Every query meets
+    every row, so this kernel IS bound by the matrix units: `roofline.bound` = "mfma", 2·Q·N·d operations per step. Same launch
+    contract and JSON line as the default mode; replicas, one batch per GPU."""
+    import torch
+    import torch.distributed as dist
+
+    import usearch_amd
+    metric = args.metric or ("l2sq" if args.dtype == "i8" else "cos")
+    if args.dtype not in MFMA_PEAK_TFLOPS:
+        raise SystemExit("--exact times the matrix-unit kernel: --dtype f16, bf16 or i8")
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    cores = host_cores()
+
+    data = synthetic_vectors_device(args.n, args.dim, args.dtype, 42, device)
+    t0 = time.time()
+    # the scan does not read the graph: the cheapest one the builder makes carries the rows into a snapshot
+    built = usearch_amd.build(None, metric, args.dtype, connectivity=4, expansion_add=16, device=local_rank,
+                              device_pointer=data.data_ptr(), count=args.n, stride=data.stride(0), ndim=args.dim)
+    del data
+    torch.cuda.empty_cache()
+    index = built.index
+    queries_dev = synthetic_vectors_device(args.queries, args.dim, args.dtype, 43 + 1000 * rank, device)
+    queries_host = queries_dev.cpu().numpy().view(NUMPY_STORAGE[args.dtype])
+    keys_dev = torch.zeros((args.queries, args.k), dtype=torch.int64, device=device)
+    dist_dev = torch.zeros((args.queries, args.k), dtype=torch.float32, device=device)
+    counts_dev = torch.zeros(args.queries, dtype=torch.int64, device=device)
+    stream = torch.cuda.Stream(device)
+    if rank == 0:
+        log(f"[bench] {args.n}x{args.dim} {args.dtype} in HBM ({time.time() - t0:.1f}s), batch of {args.queries} resident")
+
+    def step() -> float:
+        return index.exact_search_device(queries_dev.data_ptr(), args.queries, queries_dev.stride(0), args.k, keys_dev.data_ptr(),
+                                         dist_dev.data_ptr(), counts_dev.data_ptr(), stream=stream.cuda_stream, tiled=True)
+
+    flush_native_stdio()
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.75:  # sustained clocks, as in the default mode
+        step()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kernel_ms.append(step())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        operations = 2.0 * args.queries * args.n * args.dim
+        kernel_s = float(np.mean(kernel_ms)) / 1e3
+        achieved = operations / kernel_s / 1e12
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        found_keys = keys_dev.cpu().numpy().astype(np.uint64)
+        found_distances = dist_dev.cpu().numpy()
+        # the bit-exact wave-per-query kernel on a sample of the batch (one dataset pass per query)
+        checked = min(args.queries, 64)
+        plain = index.search(queries_host[:checked], args.k, dtype=args.dtype, exact=True)
+        same_keys = float(np.mean(plain.keys == found_keys[:checked]))
+        worst = float(np.nanmax(np.abs(plain.distances - found_distances[:checked])))
+        same_bits = float(np.mean(plain.distances.view(np.uint32) == found_distances[:checked].view(np.uint32)))
+        log(f"[bench] exact step: kernel {kernel_s * 1e3:.1f} ms = {achieved:.0f} T(FL)OP/s; against the bit-exact kernel on {checked} queries: "
+            f"keys equal {same_keys:.4f}, distance bits equal {same_bits:.4f}, max |diff| {worst:.3g}")
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import refbind
+            image = built.save_buffer()
+            reference = refbind.RefIndex.from_buffer(image, view=True, dtype=args.dtype)
+            t1 = time.perf_counter()
+            reference.search(queries_host[:cores], args.k, dtype=args.dtype, exact=True, threads=cores)
+            pilot_seconds = time.perf_counter() - t1
+            sample_q = int(min(args.queries, max(cores, cores * int(args.cpu_seconds / max(pilot_seconds, 1e-3)))))
+            t1 = time.perf_counter()
+            rkeys, *_ = reference.search(queries_host[:sample_q], args.k, dtype=args.dtype, exact=True, threads=cores)
+            cpu_seconds = time.perf_counter() - t1
+            cpu = {"value": sample_q / cpu_seconds, "unit": "queries/s", "cores": cores, "kind": "reference",
+                   "sample": f"{sample_q} of the step's {args.queries} queries against the same {args.n} vectors, the reference's "
+                             f"`search(…, exact = true)` (index.hpp:4252-4268) on {cores} threads, serial (auto-vectorised) metrics; "
+                             f"{cpu_seconds:.1f}s; label agreement with the GPU {float(np.mean(rkeys == found_keys[:sample_q])):.4f}"}
+            del reference, image
+        workload = f"exact search, {args.n}x{args.dim} {args.dtype} {metric}, batch {args.queries}, k={args.k}"
+        line = {
+            "metric": f"exact-search QPS (search(..., exact=true) for a batch), {args.n}x{args.dim} {args.dtype} {metric}, batch={args.queries}",
+            "value": args.queries * world * args.steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic (seeded rank-32 latent + 0.05 noise, out-of-sample queries)",
+            "config": {"workload": workload, "vectors": args.n, "dimensions": args.dim, "parallelism": f"replicas{world}",
+                       "kernel": "exact_wide_kernel (256 queries x 128 rows per workgroup) + row / query norms + partition merge",
+                       "checked_against_bit_exact_kernel": {"queries": checked, "keys_equal": same_keys,
+                                                            "distance_bits_equal": same_bits, "max_abs_difference": worst},
+                       "sources": source_hash()},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s" if args.dtype != "i8" else "TOP/s",
+                         "frac": achieved / peak, "traffic": None, "kernel": "exact_wide_kernel", "kernel_ms": kernel_s * 1e3,
+                         "operations_per_launch": operations},
+            "cpu_baseline": cpu,
+        }
+        flush_native_stdio()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main() -> None:
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -304,6 +429,8 @@ def main() -> None:
     parser.add_argument("--wave-clock", action="store_true", help="record the batch-tail telemetry of the timed steps")
     parser.add_argument("--no-placement-check", action="store_true",
                         help="skip re-timing the batch with the engine's placement draws switched off (roofline.frac_first_placement)")
+    parser.add_argument("--exact", action="store_true",
+                        help="time the exact (brute-force) search of the batch through the matrix-unit kernel instead of the graph walk")
     parser.add_argument("--config", default=None, choices=sorted(PRESETS),
                         help="one of BASELINE.json's configurations by name: " + "; ".join(f"{k} = {v['what']}" for k, v in sorted(PRESETS.items())))
     args = parser.parse_args()
@@ -313,6 +440,8 @@ def main() -> None:
                 setattr(args, name, value)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_with_ranks(args.gpus)
+    if args.exact:
+        return run_exact(args)
     metric = args.metric or ("hamming" if args.dtype == "b1" else "l2sq" if args.dtype == "i8" else "cos")
     cores = host_cores()
     if not args.build_threads:

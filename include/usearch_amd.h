@@ -212,6 +212,18 @@ USEARCH_AMD_EXPORT void usearch_amd_exact_search_many_tiled(usearch_amd_snapshot
                                                             float* kernel_ms, usearch_amd_error_t* error);
 
 /**
+ *  Either exact search over DEVICE buffers (queries in the storage scalar kind, `queries_stride` bytes apart; keys, distances and
+ *  counts dense `[queries_count][wanted]` / `[queries_count]` in HBM), enqueued on `stream` (NULL: a stream of the snapshot);
+ *  returns when the results are complete. `tiled != 0` selects the matrix-unit kernel. `kernel_ms` (may be NULL): HIP-event
+ *  time of the kernels. What `bench.py --exact` times.
+ */
+USEARCH_AMD_EXPORT void usearch_amd_exact_search_many_device(usearch_amd_snapshot_t snapshot, void const* queries,
+                                                             size_t queries_count, size_t queries_stride, size_t wanted,
+                                                             usearch_amd_key_t* keys, usearch_amd_distance_t* distances,
+                                                             uint64_t* counts, void* stream, int tiled, float* kernel_ms,
+                                                             usearch_amd_error_t* error);
+
+/**
  *  Exact search of a raw host dataset — `usearch_exact_search` (c/usearch.h:467-474, c/lib.cpp:468-501): keys are row
  *  offsets of `dataset`. `metric_kind` / `scalar_kind` use the C enumerators of c/usearch.h:40-62. Ties between equal
  *  distances (unspecified in the reference: `std::partial_sort` by distance) resolve to the later row first.

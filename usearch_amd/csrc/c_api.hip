@@ -351,6 +351,17 @@ void usearch_amd_exact_search_many_tiled(usearch_amd_snapshot_t snapshot, void c
     fail_from_exception(error);
 }
 
+void usearch_amd_exact_search_many_device(usearch_amd_snapshot_t snapshot, void const* queries, size_t queries_count,
+                                          size_t queries_stride, size_t wanted, usearch_amd_key_t* keys,
+                                          usearch_amd_distance_t* distances, uint64_t* counts, void* stream, int tiled,
+                                          float* kernel_ms, usearch_amd_error_t* error) try {
+    if (const char* e = as_snapshot(snapshot)->exact_device(queries, queries_count, queries_stride, wanted, keys, distances,
+                                                            counts, static_cast<hipStream_t>(stream), kernel_ms, tiled != 0))
+        fail(error, e);
+} catch (...) {
+    fail_from_exception(error);
+}
+
 void usearch_amd_exact_search_dataset(void const* dataset, size_t dataset_count, size_t dataset_stride,
                                       void const* queries, size_t queries_count, size_t queries_stride,
                                       int scalar_kind, size_t dimensions, int metric_kind, size_t wanted,

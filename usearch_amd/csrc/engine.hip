@@ -1528,7 +1528,9 @@ const char* exact_search_device(metric_kind_t metric, scalar_kind_t scalar, std:
 
 const char* snapshot_t::exact_device(const void* queries, std::size_t count, std::size_t stride_bytes,
                                      std::size_t wanted, std::uint64_t* keys, float* distances, std::uint64_t* counts,
-                                     hipStream_t stream, float* kernel_ms) {
+                                     hipStream_t stream, float* kernel_ms, bool tiled) {
+    if (!count || !wanted)
+        return nullptr;
     UA_HIP(hipSetDevice(device_));
     lease_t lease(*this);
     if (!stream) {
@@ -1536,6 +1538,9 @@ const char* snapshot_t::exact_device(const void* queries, std::size_t count, std
             return e;
         stream = lease.workspace->stream;
     }
+    if (tiled)
+        return exact_search_tiled_device(kernel_metric(metric_), scalar_, view_, queries, count, stride_bytes, wanted, true, keys,
+                                         distances, counts, stream, kernel_ms);
     return exact_search_device(metric_, scalar_, lanes_, view_, queries, count, stride_bytes, wanted, true, keys,
                                distances, counts, stream, kernel_ms);
 }

@@ -231,7 +231,7 @@ class snapshot_t {
     /// queries in the storage kind.
     const char* exact_device(const void* queries, std::size_t count, std::size_t stride_bytes, std::size_t wanted,
                              std::uint64_t* keys, float* distances, std::uint64_t* counts, hipStream_t stream,
-                             float* kernel_ms);
+                             float* kernel_ms, bool tiled = false);
     /// Same with host buffers and any query scalar kind. `tiled`: the matrix-unit kernel where one exists for the pair
     /// (exact_tiled.hip; an error otherwise) instead of the bit-exact wave-per-query one.
     const char* exact_host(const void* queries, scalar_kind_t query_kind, std::size_t count, std::size_t stride_bytes,

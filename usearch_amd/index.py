@@ -87,6 +87,7 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_search_many_device", "usearch_amd_last_peaks", "usearch_amd_distances",
     "usearch_amd_last_distances_ms", "usearch_amd_merge_many", "usearch_amd_merge_many_device",
     "usearch_amd_exact_search_many", "usearch_amd_exact_search_many_tiled", "usearch_amd_exact_search_dataset",
+    "usearch_amd_exact_search_many_device",
     "usearch_amd_cluster_many",
     "usearch_amd_cast",
     "usearch_amd_build", "usearch_amd_build_free", "usearch_amd_build_snapshot",
@@ -173,6 +174,9 @@ def library() -> C.CDLL:
     L.usearch_amd_exact_search_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), err_p]
     L.usearch_amd_exact_search_many_tiled.argtypes = L.usearch_amd_exact_search_many.argtypes
+    L.usearch_amd_exact_search_many_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float),
+                                                       C.POINTER(C.c_char_p)]
     L.usearch_amd_exact_search_dataset.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                                    C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p,
                                                    C.c_size_t, C.c_void_p, C.c_size_t, err_p]
@@ -506,6 +510,19 @@ class Index:
                                                  C.byref(stats), C.byref(err))
         _raise(err, "usearch_amd_search_many_device")
         return stats
+
+    def exact_search_device(self, queries_ptr: int, queries_count: int, queries_stride: int, count: int, keys_ptr: int,
+                            distances_ptr: int, counts_ptr: int, stream: int = 0, tiled: bool = True) -> float:
+        """Exact search of an HBM-resident batch into HBM-resident results (`search(…, exact = true)` of the class for a batch);
+        returns the kernels' HIP-event time in ms. `tiled`: the matrix-unit kernel (exact_tiled.hip)."""
+        kernel_ms = C.c_float(0)
+        err = C.c_char_p()
+        library().usearch_amd_exact_search_many_device(self._handle, C.c_void_p(queries_ptr), queries_count, queries_stride,
+                                                       count, C.c_void_p(keys_ptr), C.c_void_p(distances_ptr),
+                                                       C.c_void_p(counts_ptr), C.c_void_p(stream), int(tiled),
+                                                       C.byref(kernel_ms), C.byref(err))
+        _raise(err, "usearch_amd_exact_search_many_device")
+        return float(kernel_ms.value)
 
     @property
     def last_distances_ms(self) -> float:
