@@ -125,13 +125,19 @@ def synthetic_vectors_device(count: int, dim: int, dtype: str, seed: int, device
     return out
 
 
+WALK_SOURCES = ("common.hpp", "engine.hpp", "engine.hip", "host_util.hpp", "image.hpp", "kernels.hpp", "launch_impl.hpp",
+                "pair_kernels.hpp", "placement.hpp", "placement.hip")
+
+
 def source_hash() -> str:
-    """Names the product build: sha256 over the kernel / engine sources the library is compiled from. A `roofline.traffic`
-    measured by PMC passes is only attached to a line produced by the same sources (profiles/<round>/traffic.json)."""
+    """Names the build of the timed path: sha256 over the sources the graph walk is compiled from (the kernels, their launch
+    dispatch, the engine that sizes and launches them, placement). A `roofline.traffic` measured by PMC passes is only attached
+    to a line produced by the same sources (profiles/<round>/traffic.json); the builder, the exact-search kernels, the
+    collective and the C surfaces can change without voiding it."""
     digest = hashlib.sha256()
     directory = os.path.join(ROOT, "usearch_amd", "csrc")
     for name in sorted(os.listdir(directory)):
-        if name.endswith((".hip", ".hpp")):
+        if name in WALK_SOURCES or (name.startswith("search_") and name.endswith(".hip")):
             digest.update(name.encode())
             digest.update(open(os.path.join(directory, name), "rb").read())
     return digest.hexdigest()[:16]
