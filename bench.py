@@ -241,6 +241,7 @@ def stress_rows(args, metric: str, device, local_rank: int, expansion: int) -> d
             row["self_recall_at_1_ef64"] = float((keys[:, 0].cpu().numpy() == np.arange(q)).mean())
             stats = run(64, True)
             row["qps_ef64"] = q / (stats.kernel_ms / 1e3)
+            row["kernel_passes_ef64"] = int(stats.passes)  # 1 = every traversal fit the default scratch sizing
         else:
             sample = min(q, 1000)
             host = queries[:sample].cpu().numpy().view(NUMPY_STORAGE[args.dtype])
@@ -250,6 +251,7 @@ def stress_rows(args, metric: str, device, local_rank: int, expansion: int) -> d
                 found = keys[:sample].cpu().numpy().astype(np.uint64)
                 row[f"recall_at_{args.k}_ef{ef}"] = float(np.mean(recall_per_query(found, truth, args.k)))
                 row[f"qps_ef{ef}"] = q / (stats.kernel_ms / 1e3)
+                row[f"kernel_passes_ef{ef}"] = int(stats.passes)
         row["seconds"] = round(time.time() - t0, 1)
         rows[name] = row
         log(f"[bench] stress row {name}: {row}")

@@ -202,6 +202,28 @@ def test_wide_base_lists_build(reference, connectivity, connectivity_base):
     assert np.array_equal(got.keys, okeys) and util.same_float_bits(got.distances, odistances)
 
 
+@pytest.mark.parametrize("expansion_add", [300, 1000])
+def test_wide_insertion_beams_build(reference, expansion_add):
+    """expansion_add above 256: the candidates' bitmap of `refine_` lives in LDS, any beam up to 1 024 links (the reference has
+    no bound, index.hpp:1359-1394); the graph is at least as good as the reference's at the same setting."""
+    n, ndim = 3000, 32
+    vectors = util.make_vectors(n, ndim, "f32", seed=75)
+    queries = util.make_vectors(200, ndim, "f32", seed=76)
+    built = usearch_amd.build(vectors, "l2sq", "f32", connectivity=8, expansion_add=expansion_add, max_batch=256)
+    assert built.stats.dropped_requests == 0
+    image = built.save_buffer()
+    check_structure(image, n, 8)
+    theirs = refbind.RefIndex.from_buffer(image, view=False, dtype="f32")
+    own = refbind.RefIndex(ndim, "l2sq", "f32", connectivity=8, expansion_add=expansion_add)
+    own.add(np.arange(n, dtype=np.uint64), vectors, threads=1)
+    truth = theirs.search(queries, 10, dtype="f32", exact=True)[0]
+    ours_recall = recall_at(theirs.search(queries, 10, dtype="f32")[0], truth)
+    own_recall = recall_at(own.search(queries, 10, dtype="f32")[0], truth)
+    assert ours_recall >= own_recall - 0.03, (ours_recall, own_recall)
+    with pytest.raises(RuntimeError):
+        usearch_amd.build(vectors[:100], "l2sq", "f32", connectivity=8, expansion_add=1025)
+
+
 def test_build_edge_cases():
     one = usearch_amd.build(util.make_vectors(1, 16, "f32", seed=1), "cos", "f32")
     assert len(one.index) == 1

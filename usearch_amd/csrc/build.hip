@@ -424,6 +424,7 @@ const char* builder_t::link_range(std::uint64_t begin, const std::uint64_t end_t
     args.touched_count = d_touched_count_;
     args.counters = d_counters_;
     args.deferred_cap = (std::uint32_t)std::min<std::uint64_t>(max_batch * m, 0xFFFFFFFFull); // every request of a pass fits
+    args.candidate_cap = std::max<std::uint32_t>(64, (ef + 63) / 64 * 64);
 
     std::vector<std::uint32_t> nodes;
     std::vector<std::uint64_t> host_counters(max_batch);

@@ -20,8 +20,8 @@ namespace usearch_amd {
 
 /// Largest `expansion_add` (and base connectivity) the link kernels take: a node's candidates are ranked by one wave
 /// (build_kernels.hpp `build_max_candidates_k`; build.hip checks that the two agree).
-constexpr std::uint32_t builder_max_expansion_k = 256;
-constexpr std::uint32_t builder_max_connectivity_base_k = 56;
+constexpr std::uint32_t builder_max_expansion_k = 1024;
+constexpr std::uint32_t builder_max_connectivity_base_k = 63;
 
 struct build_config_t {
     std::uint32_t connectivity = 16;      ///< M,  index.hpp `default_connectivity()`

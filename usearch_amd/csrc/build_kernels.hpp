@@ -27,7 +27,7 @@
 
 namespace usearch_amd {
 
-constexpr std::uint32_t build_max_candidates_k = 256; ///< insertion beam width the link kernels accept (ef_construction)
+constexpr std::uint32_t build_max_candidates_k = 1024; ///< insertion beam width the link kernels accept (ef_construction)
 
 /// One linking pass: the nodes of one batch that exist on `level`.
 struct build_args_t {
@@ -55,6 +55,7 @@ struct build_args_t {
     cand_t* deferred_requests;       ///< [deferred_cap] {distance, requesting slot}
     std::uint32_t* deferred_count;   ///< how many are waiting (may exceed the capacity: the excess was dropped and counted)
     std::uint32_t deferred_cap;
+    std::uint32_t candidate_cap;     ///< candidates per node the LDS carve-up is cut for: `ef` rounded up to whole 64s (≥ 64)
 };
 
 /// Files reverse-link request {`request`} against `target`; false = the inbox is full (the caller defers or drops it).
@@ -82,25 +83,30 @@ UA_DEVICE std::uint32_t* build_list(const build_args_t& b, const snapshot_view_t
                    : b.nbr0 + (std::uint64_t)slot * ix.m0;
 }
 
-/// LDS carve-up of the link kernels (after the staged query).
+/// Waves per SIMD the link kernels are cut for: what they had before the candidates' bitmap moved to LDS (one-chunk rows 6, others 4).
+constexpr int build_waves(int lanes) { return lanes == 1 ? 6 : 4; }
+
+/// LDS carve-up of the link kernels (after the staged query); `cap` = build_args_t::candidate_cap.
 struct build_lds_t {
     std::uint32_t* cand_slots;   // [64] gather list of one measure_rows call
     float* cand_distances;       // [64]
-    std::uint32_t* slots;        // [build_max_candidates_k] candidates, ascending
-    float* dists;                // [build_max_candidates_k]
+    std::uint32_t* slots;        // [cap] candidates, ascending
+    float* dists;                // [cap]
     std::uint32_t* sel;          // [64] accepted
     float* seld;                 // [64]
+    std::uint64_t* alive;        // [cap / 64] one bit per candidate `refine_forward` has not struck yet
 };
-constexpr std::uint32_t build_lds_bytes_k = 64 * 4 * 2 + build_max_candidates_k * 4 * 2 + 64 * 4 * 2;
+inline __host__ __device__ std::uint32_t build_lds_bytes(std::uint32_t cap) { return 64 * 4 * 2 + cap * 4 * 2 + 64 * 4 * 2 + cap / 64 * 8; }
 
-UA_DEVICE build_lds_t build_lds(std::uint8_t* base) {
+UA_DEVICE build_lds_t build_lds(std::uint8_t* base, std::uint32_t cap) {
     build_lds_t l;
     l.cand_slots = reinterpret_cast<std::uint32_t*>(base);
     l.cand_distances = reinterpret_cast<float*>(base + 256);
     l.slots = reinterpret_cast<std::uint32_t*>(base + 512);
-    l.dists = reinterpret_cast<float*>(base + 512 + build_max_candidates_k * 4);
-    l.sel = reinterpret_cast<std::uint32_t*>(base + 512 + build_max_candidates_k * 8);
-    l.seld = reinterpret_cast<float*>(base + 512 + build_max_candidates_k * 8 + 256);
+    l.dists = reinterpret_cast<float*>(base + 512 + cap * 4);
+    l.sel = reinterpret_cast<std::uint32_t*>(base + 512 + cap * 8);
+    l.seld = reinterpret_cast<float*>(base + 512 + cap * 8 + 256);
+    l.alive = reinterpret_cast<std::uint64_t*>(base + 512 + cap * 8 + 512);
     return l;
 }
 
@@ -111,39 +117,40 @@ UA_DEVICE build_lds_t build_lds(std::uint8_t* base) {
 template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak>
 UA_DEVICE std::uint32_t refine_forward(const snapshot_view_t& ix, std::uint8_t* query_lds, const build_lds_t& l,
                                        std::uint32_t count, std::uint32_t needed, std::uint32_t& evaluated) {
-    constexpr int words_k = build_max_candidates_k / 64;
+    // the bitmap of live candidates sits in LDS, one 64-bit word per lane of the first `words` lanes: any expansion up to
+    // build_max_candidates_k at the register cost of one
     const std::uint32_t lane = lane_id();
-    std::uint64_t alive[words_k];
-#pragma unroll
-    for (int w = 0; w < words_k; ++w) {
-        const std::uint32_t first = 64u * w;
-        alive[w] = count >= first + 64 ? ~0ull : count > first ? (1ull << (count - first)) - 1ull : 0ull;
+    const std::uint32_t words = (count + 63) / 64;
+    auto word_at = [&](std::uint32_t w) -> std::uint64_t { // every lane reads the same cell; the value comes back wave-uniform
+        const std::uint64_t v = l.alive[w];
+        return ((std::uint64_t)uniform_u32((std::uint32_t)(v >> 32)) << 32) | uniform_u32((std::uint32_t)v);
+    };
+    if (lane < words) {
+        const std::uint32_t first = 64u * lane;
+        l.alive[lane] = count >= first + 64 ? ~0ull : (1ull << (count - first)) - 1ull;
     }
+    wave_sync<false>();
     std::uint32_t accepted = 0;
     while (accepted < needed) {
-        std::uint32_t chosen_index = none_slot_k;
-#pragma unroll
-        for (int w = 0; w < words_k; ++w)
-            if (chosen_index == none_slot_k && alive[w]) {
-                chosen_index = 64u * w + (std::uint32_t)__ffsll((long long)alive[w]) - 1;
-                alive[w] &= alive[w] - 1;
-            }
-        if (chosen_index == none_slot_k)
+        const std::uint64_t nonempty = ballot(lane < words && l.alive[lane] != 0); // bit w: word w still has candidates
+        if (!nonempty)
             break;
+        const std::uint32_t first_word = (std::uint32_t)__ffsll((long long)nonempty) - 1;
+        const std::uint64_t first_live = word_at(first_word);
+        const std::uint32_t chosen_index = 64u * first_word + (std::uint32_t)__ffsll((long long)first_live) - 1;
+        const std::uint64_t first_left = first_live & (first_live - 1);
         const std::uint32_t chosen = uniform_u32(l.slots[chosen_index]);
-        if (lane == 0)
+        if (lane == 0) {
+            l.alive[first_word] = first_left;
             l.sel[accepted] = chosen, l.seld[accepted] = l.dists[chosen_index];
+        }
+        wave_sync<false>();
         ++accepted;
-        std::uint64_t any = 0;
-#pragma unroll
-        for (int w = 0; w < words_k; ++w)
-            any |= alive[w];
-        if (accepted == needed || !any)
+        if (accepted == needed || !((nonempty & (nonempty - 1)) | first_left))
             break;
         const query_norm_t a2 = stage_row<metric_ak, scalar_ak, lanes_ak>(ix, chosen, query_lds);
-#pragma unroll
-        for (int w = 0; w < words_k; ++w) {
-            const std::uint64_t live = alive[w];
+        for (std::uint32_t w = first_word; w < words; ++w) {
+            const std::uint64_t live = word_at(w);
             if (!live)
                 continue;
             const bool mine = (live >> lane) & 1ull;
@@ -156,7 +163,9 @@ UA_DEVICE std::uint32_t refine_forward(const snapshot_view_t& ix, std::uint8_t* 
                                                                            l.cand_distances, batch);
             evaluated += batch;
             const bool struck = mine && l.cand_distances[position] < l.dists[64u * w + lane]; // index.hpp:4300, strict
-            alive[w] = live & ~ballot(struck);
+            const std::uint64_t left = live & ~ballot(struck);
+            if (lane == 0)
+                l.alive[w] = left;
             wave_sync<false>();
         }
     }
@@ -165,11 +174,11 @@ UA_DEVICE std::uint32_t refine_forward(const snapshot_view_t& ix, std::uint8_t* 
 }
 
 template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak>
-__global__ __launch_bounds__(64) void build_select_kernel(const snapshot_view_t ix, const build_args_t b) {
+__global__ __launch_bounds__(64, build_waves(lanes_ak)) void build_select_kernel(const snapshot_view_t ix, const build_args_t b) {
     extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
     const std::uint32_t lane = lane_id();
     std::uint8_t* query_lds = lds;
-    const build_lds_t l = build_lds(lds + query_lds_bytes<scalar_ak>(ix.chunks));
+    const build_lds_t l = build_lds(lds + query_lds_bytes<scalar_ak>(ix.chunks), b.candidate_cap);
     std::uint32_t evaluated = 0, dropped = 0;
     for (std::uint32_t t = blockIdx.x; t < b.count; t += gridDim.x) {
         const std::uint32_t node = uniform_u32(b.nodes[t]);
@@ -216,11 +225,11 @@ __global__ __launch_bounds__(64) void build_select_kernel(const snapshot_view_t 
 }
 
 template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak>
-__global__ __launch_bounds__(64) void build_reverse_kernel(const snapshot_view_t ix, const build_args_t b) {
+__global__ __launch_bounds__(64, build_waves(lanes_ak)) void build_reverse_kernel(const snapshot_view_t ix, const build_args_t b) {
     extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
     const std::uint32_t lane = lane_id();
     std::uint8_t* query_lds = lds;
-    const build_lds_t l = build_lds(lds + query_lds_bytes<scalar_ak>(ix.chunks));
+    const build_lds_t l = build_lds(lds + query_lds_bytes<scalar_ak>(ix.chunks), b.candidate_cap);
     const std::uint32_t touched = uniform_u32(*b.touched_count);
     std::uint32_t evaluated = 0, repruned = 0;
     for (std::uint32_t t = blockIdx.x; t < touched; t += gridDim.x) {

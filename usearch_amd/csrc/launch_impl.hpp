@@ -193,7 +193,7 @@ hipError_t launch_exact_metric(const exact_params_t& p, const snapshot_view_t& v
 template <int metric_ak, int scalar_ak, int lanes_ak>
 hipError_t launch_build_one(const build_params_t& p, const snapshot_view_t& view, const build_args_t& args) {
     constexpr int unroll_ak = lanes_ak == 8 ? 8 : 4;
-    const std::uint32_t lds_bytes = query_lds_bytes<scalar_ak>(view.chunks) + build_lds_bytes_k;
+    const std::uint32_t lds_bytes = query_lds_bytes<scalar_ak>(view.chunks) + build_lds_bytes(args.candidate_cap);
     if (p.reverse)
         hipLaunchKernelGGL((build_reverse_kernel<metric_ak, scalar_ak, lanes_ak, unroll_ak>), dim3(p.grid), dim3(64),
                            lds_bytes, p.stream, view, args);
