@@ -1038,15 +1038,10 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
             float trial_ms[8] = {0};
             std::size_t drawn = 0;
             const char* failure = nullptr;
-            for (; drawn < scratch_draws && !failure; ++drawn) {
-                if (hipMalloc(&candidates[drawn], slab * grid) != hipSuccess) {
-                    (void)hipGetLastError();
-                    candidates[drawn] = nullptr;
-                    break;
-                }
-                args.scratch = static_cast<std::uint8_t*>(candidates[drawn]);
-                args.count = grid; // one query per wave: the launch's steady state, a single query's latency long
-                for (int repeat = 0; repeat < 2 && !failure; ++repeat) { // the first run of a block also pays its first touch
+            auto trial = [&](void* block, float& ms) -> const char* { // the launch's first `grid` queries over this block, second run timed
+                args.scratch = static_cast<std::uint8_t*>(block);
+                args.count = grid;
+                for (int repeat = 0; repeat < 2; ++repeat) {
                     hipError_t e = hipMemsetAsync(ws.d_queue, 0, 8, stream);
                     if (e == hipSuccess)
                         e = hipEventRecord(begin, stream);
@@ -1057,10 +1052,32 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
                     if (e == hipSuccess)
                         e = hipEventSynchronize(end);
                     if (e == hipSuccess)
-                        e = hipEventElapsedTime(&trial_ms[drawn], begin, end);
+                        e = hipEventElapsedTime(&ms, begin, end);
                     if (e != hipSuccess)
-                        failure = hip_message(e);
+                        return hip_message(e);
                 }
+                return nullptr;
+            };
+            // diagnostic (USEARCH_AMD_SCRATCH_REMAP = n): ONE physical block mapped at n fresh virtual ranges, each view timed the
+            // same way — does the speed follow the physical pages or the mapping (its page tables)?
+            if (const std::size_t views = env_size("USEARCH_AMD_SCRATCH_REMAP", 0)) {
+                std::vector<float> view_ms;
+                if (const char* e = remap_trial(slab * grid, views, [&](void* view, float& ms) { return trial(view, ms); }, view_ms))
+                    std::fprintf(stderr, "[usearch_amd] remap trial: %s\n", e);
+                std::fprintf(stderr, "[usearch_amd] one physical block of %.0f MB under %zu mappings:", slab * grid / 1e6, view_ms.size());
+                for (float ms : view_ms)
+                    std::fprintf(stderr, " %.3f", ms);
+                std::fprintf(stderr, " ms\n");
+            }
+            for (; drawn < scratch_draws && !failure; ++drawn) {
+                if (hipMalloc(&candidates[drawn], slab * grid) != hipSuccess) {
+                    (void)hipGetLastError();
+                    candidates[drawn] = nullptr;
+                    break;
+                }
+                // one query per wave: the launch's steady state, a single query's latency long; the first run of a block also pays
+                // its first touch
+                failure = trial(candidates[drawn], trial_ms[drawn]);
             }
             (void)hipEventDestroy(begin);
             (void)hipEventDestroy(end);

@@ -152,6 +152,54 @@ hipError_t draw(void** out, std::size_t bytes) {
 
 } // namespace
 
+const char* remap_trial(std::size_t bytes, std::size_t views, const std::function<const char*(void*, float&)>& judge,
+                        std::vector<float>& view_ms) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess)
+        return "no device";
+    hipMemAllocationProp properties = {};
+    properties.type = hipMemAllocationTypePinned;
+    properties.location.type = hipMemLocationTypeDevice;
+    properties.location.id = device;
+    std::size_t granularity = 0;
+    if (hipMemGetAllocationGranularity(&granularity, &properties, hipMemAllocationGranularityRecommended) != hipSuccess)
+        return "no allocation granularity";
+    granularity = std::max<std::size_t>(granularity, 4096);
+    const std::size_t padded = (bytes + granularity - 1) / granularity * granularity;
+    hipMemGenericAllocationHandle_t handle;
+    if (hipMemCreate(&handle, padded, &properties, 0) != hipSuccess)
+        return (void)hipGetLastError(), "hipMemCreate failed";
+    hipMemAccessDesc access = {};
+    access.location = properties.location;
+    access.flags = hipMemAccessFlagsProtReadWrite;
+    const char* error = nullptr;
+    std::vector<void*> held; // earlier views stay mapped, so that every further one gets a range (and page tables) of its own
+    for (std::size_t v = 0; v < views && !error; ++v) {
+        void* base = nullptr;
+        if (hipMemAddressReserve(&base, padded, granularity, nullptr, 0) != hipSuccess) {
+            error = "hipMemAddressReserve failed";
+            break;
+        }
+        if (hipMemMap(base, padded, 0, handle, 0) != hipSuccess || hipMemSetAccess(base, padded, &access, 1) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipMemAddressFree(base, padded);
+            error = "hipMemMap failed (a second mapping of one allocation?)";
+            break;
+        }
+        held.push_back(base);
+        float ms = 0.f;
+        error = judge(base, ms);
+        view_ms.push_back(ms);
+    }
+    (void)hipDeviceSynchronize();
+    for (void* base : held) {
+        (void)hipMemUnmap(base, padded);
+        (void)hipMemAddressFree(base, padded);
+    }
+    (void)hipMemRelease(handle);
+    return error;
+}
+
 void placed_free(void* pointer) {
     if (!pointer)
         return;

@@ -25,6 +25,8 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <functional>
+#include <vector>
 
 namespace usearch_amd {
 
@@ -58,5 +60,10 @@ hipError_t translation_probe(const void* base, std::size_t bytes, float* mega_to
 /// of `base[0 .. bytes)`, few enough chains in flight that nothing queues. Reports nanoseconds per dependent read. The walk is a
 /// chain of dependent reads too; the throughput probes above run thousands of independent loads deep and hide what it feels.
 hipError_t latency_probe(const void* base, std::size_t bytes, std::size_t row_bytes, float* nanoseconds);
+
+/// Diagnostic: one physical allocation of `bytes` mapped, one after the other, at `views` fresh virtual ranges; `judge(view, ms)`
+/// times the walk over each (returns an error message or null). Everything is unmapped and released before returning.
+const char* remap_trial(std::size_t bytes, std::size_t views, const std::function<const char*(void*, float&)>& judge,
+                        std::vector<float>& view_ms);
 
 } // namespace usearch_amd
