@@ -581,8 +581,7 @@ def main() -> None:
         t0 = time.time()
         # ground truth: the matrix-unit exact kernel where the pair has one (f16 / bf16 within float tolerance of the bit-exact
         # kernel, i8 identical to it; tests/test_gpu_exact.py), the wave-per-query exact kernel otherwise
-        tiled = metric in ("cos", "ip", "l2sq") and args.dtype in ("f16", "bf16", "i8") and not (
-            metric == "l2sq" and args.dtype != "i8") and args.k <= 64
+        tiled = metric in ("cos", "ip", "l2sq") and args.dtype in ("f16", "bf16", "i8") and args.k <= 64
         exact = index.search(queries_host[:sample], args.k, dtype=args.dtype, exact="tiled" if tiled else True)
         truth, truth_distances = exact.keys, exact.distances
         exact_ms = exact.stats.kernel_ms

@@ -201,7 +201,7 @@ USEARCH_AMD_EXPORT void usearch_amd_cluster_many(usearch_amd_snapshot_t snapshot
 /**
  *  The same exact search as a TILED MATRIX PRODUCT on the matrix units (usearch_amd/csrc/exact_tiled.hip) — what the reference's
  *  `exact_search_t` does with its distance matrix (index_plugins.hpp:2071-2164): dataset rows are read once per 64 queries
- *  instead of once per query. Pairs: cos / ip over f16 and bf16 (f32 accumulation in the matrix unit: distances within the
+ *  instead of once per query (once per 256 for batches above 512 queries). Pairs: cos / ip / l2sq over f16 and bf16 (f32 accumulation in the matrix unit: distances within the
  *  float tolerance of `usearch_amd_exact_search_many`, which remains the bit-exact path) and cos / ip / l2sq over i8
  *  (bit-identical to it, ties included); `wanted` ≤ 64. Other pairs: an error.
  */

@@ -92,7 +92,8 @@ def test_tiled_exact_search_is_bit_identical_for_i8(reference, monkeypatch, metr
 
 @pytest.mark.parametrize("tile", [64, 256])
 @pytest.mark.parametrize("metric,dtype,ndim,n,k", [("cos", "f16", 768, 12001, 10), ("ip", "f16", 100, 9000, 32),
-                                                   ("cos", "bf16", 96, 7000, 10), ("ip", "bf16", 768, 5000, 5)])
+                                                   ("cos", "bf16", 96, 7000, 10), ("ip", "bf16", 768, 5000, 5),
+                                                   ("l2sq", "f16", 96, 6000, 10), ("l2sq", "bf16", 200, 5000, 8)])
 def test_tiled_exact_search_of_float_pairs_is_within_tolerance(reference, monkeypatch, metric, dtype, ndim, n, k, tile):
     """f16 / bf16: products are exact, the matrix unit accumulates them in f32 in its own order — every distance within the
     float tolerance of the bit-exact kernel's, the same neighbours wherever distances are separated by more than that."""

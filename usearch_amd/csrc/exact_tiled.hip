@@ -8,7 +8,7 @@
  *  of once per query, the products run on `v_mfma_f32_32x32x16_{f16,bf16}` / `v_mfma_i32_32x32x32_i8`, and the per-query
  *  top-k is folded in the epilogue of every tile (a candidate survives only if it beats the query's current k-th best).
  *
- *  Pairs: cos and ip over f16 / bf16 (f32 accumulation inside the matrix unit: results within the float tolerance of the
+ *  Pairs: cos, ip and l2sq over f16 / bf16 (f32 accumulation inside the matrix unit: results within the float tolerance of the
  *  wave-per-query kernel of kernels.hpp, which stays THE bit-exact path), and ip / cos / l2sq over i8 (exact int32 sums and
  *  the same closing arithmetic as `finalize_distance`: bit-identical to that kernel, ties included — selection is the total
  *  order (distance ↑, slot ↓) that `search_exact_`'s lower_bound inserts produce).
@@ -113,6 +113,9 @@ __device__ __forceinline__ float closing_distance(sum_at sum, std::uint32_t a2_b
             if (a2 == 0.f || b2 == 0.f)
                 return 1.f;
             return 1.f - ab / (__builtin_sqrtf(a2) * __builtin_sqrtf(b2));
+        } else if constexpr (metric_ak == metric_l2sq_k) { // Σ(a−b)² (index_plugins.hpp:1365-1385) as Σa² + Σb² − 2Σab, never below 0
+            const float d = a2 + b2 - 2.f * ab;
+            return d > 0.f ? d : 0.f;
         } else {
             return 1.f - ab;
         }
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 bool candidate;
-                if constexpr (integers && metric_ak == metric_l2sq_k) {
+                if constexpr (metric_ak == metric_l2sq_k) {
                     candidate = closing_distance<metric_ak, scalar_ak>(acc[u][r], query_norm[r], b2) <= bound[r];
                 } else if constexpr (metric_ak == metric_ip_k) {
                     candidate = 1.f - (float)acc[u][r] <= bound[r];
@@ -687,7 +690,7 @@ bool exact_tiled_available(metric_kind_t metric, scalar_kind_t scalar, std::size
     if (!wanted || wanted > (std::size_t)max_wanted_k)
         return false;
     if (scalar == scalar_f16_k || scalar == scalar_bf16_k)
-        return metric == metric_cos_k || metric == metric_ip_k;
+        return metric == metric_cos_k || metric == metric_ip_k || metric == metric_l2sq_k;
     if (scalar == scalar_i8_k)
         return metric == metric_cos_k || metric == metric_ip_k || metric == metric_l2sq_k;
     return false;
@@ -791,6 +794,8 @@ const char* exact_search_tiled_device(metric_kind_t metric, scalar_kind_t scalar
     UA_TILED(metric_ip_k, scalar_f16_k)
     UA_TILED(metric_cos_k, scalar_bf16_k)
     UA_TILED(metric_ip_k, scalar_bf16_k)
+    UA_TILED(metric_l2sq_k, scalar_f16_k)
+    UA_TILED(metric_l2sq_k, scalar_bf16_k)
     UA_TILED(metric_cos_k, scalar_i8_k)
     UA_TILED(metric_ip_k, scalar_i8_k)
     UA_TILED(metric_l2sq_k, scalar_i8_k)
