@@ -78,6 +78,8 @@ def check_against_oracle(index, image, queries, k, dtype, expansion, **search_kw
 
 @pytest.mark.parametrize("metric,dtype,ndim,n,connectivity,k,expansion,nq", CONFIGS)
 def test_search_matches_oracle_and_reference(reference, metric, dtype, ndim, n, connectivity, k, expansion, nq):
+    """Small batches over long rows run four waves per query (the team build) on their own; `test_team_and_one_wave_agree`
+    holds that against the one-wave kernel, which every batch that fills the chip uses."""
     from usearch_amd import Index
     image, vectors, ref_index = util.build_image(n, ndim, metric, dtype, seed=11, connectivity=connectivity)
     queries = util.make_vectors(nq, ndim, dtype, seed=12, metric=metric)
@@ -280,6 +282,27 @@ def test_exact_float_ties_between_frontier_candidates(reference):
     assert util.same_float_bits(in_top.distances, heap.distances), "the same neighbourhoods, whichever twin is named"
     hops_in_top, hops_heap = in_top.visited_per_query.astype(float), heap.visited_per_query.astype(float)
     assert abs(hops_in_top.mean() / hops_heap.mean() - 1) < 0.05
+
+
+@pytest.mark.parametrize("metric,dtype,ndim,expansion", [("cos", "f16", 768, 64), ("cos", "f32", 256, 300), ("l2sq", "i8", 1024, 128),
+                                                         ("ip", "bf16", 512, 600), ("l2sq", "f32", 300, 1000)])
+def test_team_and_one_wave_agree(reference, monkeypatch, metric, dtype, ndim, expansion):
+    """Rows of at least 128 bytes, batches of at most two queries per CU: four waves share a query (team_search_kernel) — wave 0
+    walks, all four measure the hop's rows. Keys, distance bits and both counters equal the one-wave kernel's and the oracle's;
+    a single query, a handful, and the largest batch that still takes the team build."""
+    from usearch_amd import Index
+    image, vectors, _ = util.build_image(5000, ndim, metric, dtype, seed=57)
+    index = Index.restore(image)
+    queries = util.make_vectors(600, ndim, dtype, seed=58)
+    for count in (1, 7, 512, 600):
+        monkeypatch.delenv("USEARCH_AMD_NO_TEAM", raising=False)
+        team = check_against_oracle(index, image, queries[:count], 10, dtype, expansion)
+        monkeypatch.setenv("USEARCH_AMD_NO_TEAM", "1")
+        plain = index.search(queries[:count], 10, expansion=expansion, dtype=dtype)
+        assert team.stats.variant == (5 if count <= 512 else plain.stats.variant) and plain.stats.variant != 5
+        assert np.array_equal(team.keys, plain.keys) and util.same_float_bits(team.distances, plain.distances)
+        assert np.array_equal(team.visited_per_query, plain.visited_per_query)
+        assert np.array_equal(team.computed_per_query, plain.computed_per_query)
 
 
 def test_large_expansion(reference):

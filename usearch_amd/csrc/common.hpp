@@ -134,6 +134,7 @@ struct search_args_t {
     const std::uint32_t* allow_bits; ///< optional: one bit per slot, 0 = the caller's predicate rejects that member
                                      ///< (`usearch_filtered_search`, index_dense.hpp:2071-2081)
     unsigned long long* phases;     ///< optional [8] diagnostic: shader-clock ticks per phase summed over all waves
+    std::uint32_t team_offset;      ///< team_search_kernel: where in the workgroup's LDS the shared `team_t` sits
     unsigned long long* wave_clock; ///< optional [grid][2] telemetry: 100-MHz wall clock at the start and the exit of every
                                     ///< persistent wave (how long the drain phase of a batch leaves the chip part-idle)
 };

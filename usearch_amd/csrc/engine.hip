@@ -827,6 +827,13 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
             return "That kernel build exists for the in-`top` frontier only";
         variant = requested;
     }
+    // A batch that cannot give every CU two queries to walk (a `usearch_search` caller's single query above all) over long rows: four
+    // waves per query — the hop's rows split four ways, everything else as ever (kernels.hpp team_search_kernel)
+    const bool team = every_build && chunks_per_lane >= 8 && !variant_request && !pair && mode_request != 3 &&
+                      count <= 2ull * compute_units_ && !(extras && extras->descent_only) && !env_size("USEARCH_AMD_NO_TEAM", 0) &&
+                      !tuning.waves_per_cu;
+    if (team)
+        variant = variant_u12_w2_k;
     const std::uint32_t variant_waves_per_cu = 4u * (std::uint32_t)kernel_waves(variant, (int)entries_per_lane, frontier, (int)lanes_);
     const std::uint32_t waves_cap = tuning.waves_per_cu ? tuning.waves_per_cu
                                                         : (std::uint32_t)env_size("USEARCH_AMD_WAVES_PER_CU", 32);
@@ -903,10 +910,11 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
     params.lanes = lanes_;
     params.variant = variant;
     params.frontier = frontier;
+    params.team = team ? 1u : 0u;
     params.stream = stream;
     call.stats = search_stats_t{};
     call.stats.frontier = frontier == frontier_top_k ? 2u : 1u;
-    call.stats.variant = (std::uint32_t)variant + 1;
+    call.stats.variant = team ? 5u : (std::uint32_t)variant + 1; // 5 = the team build (four waves per query)
     call.stats.top_cells = entries_per_lane;
 
     // diagnostic: per-phase shader-clock ticks of the search kernel, printed to stderr (USEARCH_AMD_PHASES=1)
@@ -1004,8 +1012,12 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         }
     }
     if (call.mode != scratch_global_k) {
-        const std::uint64_t lds_bytes = lds_bytes_for(call.mode, call.next_cap, call.hash_cap);
-        const std::uint32_t grid = (std::uint32_t)std::min<std::uint64_t>(pending, (std::uint64_t)waves_for(lds_bytes) * compute_units_);
+        // a team's workgroup carries the leader's LDS areas plus the shared control block; one workgroup per query of the small batch
+        const std::uint64_t wave_lds_bytes = lds_bytes_for(call.mode, call.next_cap, call.hash_cap);
+        const std::uint64_t lds_bytes = params.team ? (wave_lds_bytes + 15) / 16 * 16 + 64 : wave_lds_bytes;
+        args.team_offset = params.team ? (std::uint32_t)((wave_lds_bytes + 15) / 16 * 16) : 0u;
+        const std::uint32_t grid = params.team ? pending
+                                               : (std::uint32_t)std::min<std::uint64_t>(pending, (std::uint64_t)waves_for(lds_bytes) * compute_units_);
         const std::uint64_t slab = call.mode == scratch_hash_k ? (std::uint64_t)call.hash_cap * 4 : 0;
         // WHERE the block of visited-set slabs lands decides which of the walk's speeds this batch runs at (with the index arrays
         // untouched, a fresh 268-MB block flips the headline batch between 45.5 and 51.6 ms; profiles/r03_placement/), and no
@@ -1151,6 +1163,7 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         args.scratch_stride = slab;
         args.wave_clock = nullptr;
         params.mode = scratch_global_k;
+        params.team = 0;
         params.entries_per_lane = 0;
         params.frontier = frontier_heap_k;
         params.grid = (std::uint32_t)chunk;

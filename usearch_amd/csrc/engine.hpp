@@ -75,6 +75,7 @@ struct launch_params_t {
     hipStream_t stream;
     std::uint32_t pair = 0;       ///< 0 = one query per wave; 1 = two (pair_kernels.hpp)
     std::uint32_t pair_cells = 0; ///< register cells of `top` per lane in that kernel (2 or 4)
+    std::uint32_t team = 0;       ///< 1 = four waves per query (team_search_kernel): small batches over long rows
 };
 
 /**

@@ -33,7 +33,9 @@ namespace usearch_amd {
 //  Wave-level helpers (wave = 64 lanes = the whole workgroup)
 // ---------------------------------------------------------------------------------------------------------------------
 
-UA_DEVICE std::uint32_t lane_id() { return threadIdx.x; }
+/// Lane of the wave. Workgroups are one wave wide except the team kernel's (four waves share a query): the mask costs nothing
+/// where the compiler knows the workgroup is 64 wide.
+UA_DEVICE std::uint32_t lane_id() { return threadIdx.x & 63u; }
 
 /**
  *  Orders this wave's scratch accesses across lanes: later reads see earlier writes of any lane. The LDS flavour
@@ -1103,13 +1105,34 @@ template <int scalar_ak> inline __host__ __device__ std::uint32_t query_lds_byte
     return chunks * ((scalar_ak == scalar_f16_k || scalar_ak == scalar_bf16_k) ? 32u : 16u); // a multiple of 16
 }
 
+/// What the waves of a TEAM share besides the leader's LDS areas (team_search_kernel): how many rows the hop in progress has
+/// gathered, and the query's norms.
+struct team_t {
+    std::uint32_t count;
+    std::uint32_t reserved[3];
+    query_norm_t a2;
+};
+constexpr std::uint32_t team_exit_k = 0xFFFFFFFFu;
+
+/// Wave `wave` of `team_ak` measures its share of the `count` rows gathered in `slots` — whole rows, each by a lane group in the
+/// very layout `measure_rows` uses everywhere, so every distance has the bits the one-wave kernel computes.
+template <int metric_ak, int scalar_ak, int lanes_ak, int loads_ak, int team_ak>
+UA_DEVICE void team_share(const snapshot_view_t& ix, const std::uint8_t* query_lds, query_norm_t a2, const std::uint32_t* slots,
+                          float* out, std::uint32_t count, std::uint32_t wave) {
+    const std::uint32_t per_wave = (count + team_ak - 1) / team_ak;
+    const std::uint32_t begin = wave * per_wave;
+    const std::uint32_t end = begin + per_wave < count ? begin + per_wave : count;
+    if (begin < end)
+        measure_rows<metric_ak, scalar_ak, lanes_ak, loads_ak, false, 1>(ix, query_lds, a2, slots + begin, out + begin, end - begin);
+}
+
 /**
  *  One query, start to finish. `heaps` = top/next/candidate arrays (LDS, or the slab in `scratch_global_k`), `visits` = the
  *  visited set (LDS hash, slab hash or slab bitmap). Returns false on scratch overflow (nothing written but `status`).
  */
-template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, int mode_ak, int epl_ak, int frontier_ak>
+template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, int mode_ak, int epl_ak, int frontier_ak, int team_ak = 1>
 UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, std::uint32_t q,
-                          std::uint8_t* query_lds, std::uint8_t* heaps, std::uint32_t* visits) {
+                          std::uint8_t* query_lds, std::uint8_t* heaps, std::uint32_t* visits, team_t* team = nullptr) {
     constexpr bool global_ak = mode_ak == scratch_global_k;
     constexpr bool in_top_ak = frontier_ak == frontier_top_k;
     static_assert(!in_top_ak || (epl_ak > 0 && !global_ak), "the frontier rides in the register layout of `top`");
@@ -1166,8 +1189,17 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
         computed += count;
     };
     auto measure_hop = [&](std::uint32_t count) { // the beam: up to M0 fresh neighbours per hop
-        measure_rows<metric_ak, scalar_ak, lanes_ak, loads_ak, global_ak, rows_ak>(ix, query_lds, a2, cand_slots,
-                                                                                   cand_distances, count);
+        if constexpr (team_ak > 1) {
+            // the leader of a team: publish the gather list, take the first share, meet the helpers again when all of it is measured
+            if (lane == 0)
+                team->count = count, team->a2 = a2;
+            __syncthreads();
+            team_share<metric_ak, scalar_ak, lanes_ak, loads_ak, team_ak>(ix, query_lds, a2, cand_slots, cand_distances, count, 0);
+            __syncthreads();
+        } else {
+            measure_rows<metric_ak, scalar_ak, lanes_ak, loads_ak, global_ak, rows_ak>(ix, query_lds, a2, cand_slots,
+                                                                                       cand_distances, count);
+        }
         computed += count;
     };
     // index_dense.hpp:2071-2081: a member is a result candidate unless it is a tombstone or the caller's predicate
@@ -1552,6 +1584,59 @@ __global__ __launch_bounds__(64, kernel_waves(variant_ak, epl_ak, frontier_ak, l
     }
     if (args.wave_clock && lane_id() == 0)
         args.wave_clock[2 * (std::uint64_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+}
+
+/**
+ *  FOUR waves per query, for batches too small to fill the chip with one wave each (a `usearch_search` caller's single query
+ *  above all) over long rows: wave 0 walks exactly as `search_kernel` does — pop, list, visited set, ordered commit, `top` in its
+ *  registers — and the three others help with the one step that is bandwidth a lone wave cannot pull: the hop's ≤ M0 rows are
+ *  split four ways (`team_share`), two workgroup barriers per hop. Same distances bit for bit (whole rows per lane group), same
+ *  order of commits, same counters. The helpers share the leader's LDS image of the query and its gather list.
+ */
+template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak, int frontier_ak>
+__global__ __launch_bounds__(256) void team_search_kernel(const snapshot_view_t ix, const search_args_t args) {
+    static_assert(mode_ak != scratch_global_k, "the team walks with its heaps in LDS");
+    constexpr int team_ak = 4;
+    constexpr int loads_ak = variant_unroll(variant_ak);
+    extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
+    std::uint8_t* query_lds = lds;
+    const std::uint32_t query_bytes = query_lds_bytes<scalar_ak>(ix.chunks);
+    const scratch_layout_t layout = scratch_layout(epl_ak ? 0 : args.ef, frontier_ak == frontier_top_k ? 0 : args.next_cap, 0);
+    std::uint8_t* heaps = lds + query_bytes;
+    team_t* team = reinterpret_cast<team_t*>(lds + args.team_offset);
+    const std::uint32_t wave = threadIdx.x / 64;
+    if (wave == 0) {
+        std::uint8_t* slab = args.scratch + (std::uint64_t)blockIdx.x * args.scratch_stride;
+        std::uint32_t* visits = mode_ak == scratch_lds_k ? reinterpret_cast<std::uint32_t*>(heaps + layout.visits)
+                                                         : reinterpret_cast<std::uint32_t*>(slab);
+        for (;;) {
+            std::uint32_t ticket = 0;
+            if (lane_id() == 0)
+                ticket = atomicAdd(args.queue, 1u);
+            ticket = uniform_u32(ticket);
+            if (ticket >= args.count)
+                break;
+            const std::uint32_t q = args.todo ? args.todo[ticket] : ticket;
+            search_one<metric_ak, scalar_ak, lanes_ak, loads_ak, mode_ak, epl_ak, frontier_ak, team_ak>(ix, args, q, query_lds, heaps,
+                                                                                                       visits, team);
+            wave_sync<false>();
+        }
+        if (lane_id() == 0)
+            team->count = team_exit_k;
+        __syncthreads();
+    } else {
+        const std::uint32_t* cand_slots = reinterpret_cast<const std::uint32_t*>(heaps + layout.cand_slots);
+        float* cand_distances = reinterpret_cast<float*>(heaps + layout.cand_distances);
+        for (;;) {
+            __syncthreads(); // the leader has published a hop (or the end)
+            const std::uint32_t count = uniform_u32(team->count);
+            if (count == team_exit_k)
+                break;
+            const query_norm_t a2 = team->a2;
+            team_share<metric_ak, scalar_ak, lanes_ak, loads_ak, team_ak>(ix, query_lds, a2, cand_slots, cand_distances, count, wave);
+            __syncthreads(); // every share is in LDS: the leader commits
+        }
+    }
 }
 
 /**
