@@ -486,13 +486,20 @@ const char* builder_t::link_range(std::uint64_t begin, const std::uint64_t end_t
             // Requests that found their target's inbox full (a hub that many of this pass's nodes picked: the inbox holds 64 - M0
             // … 32 requests, index.hpp:3848-3893 takes any number) were parked: now that the reverse kernel has applied and
             // emptied the inboxes they are filed again, round after round, until none is waiting. Nothing is dropped.
-            for (int round = 0; round < 256; ++round) {
+            // Every round files at least one request per target that still has some (its inbox starts the round empty), so the
+            // number waiting falls strictly; should it ever not, what is left is counted as dropped instead of spinning.
+            for (std::uint32_t before = 0xFFFFFFFFu;;) {
                 std::uint32_t waiting = 0;
                 UA_HIP(hipMemcpyAsync(&waiting, d_deferred_count_ + lot, 4, hipMemcpyDeviceToHost, stream));
                 UA_HIP(hipStreamSynchronize(stream));
                 if (!waiting)
                     break;
                 waiting = std::min(waiting, args.deferred_cap);
+                if (waiting >= before) {
+                    unfiled_requests_ += waiting;
+                    break;
+                }
+                before = waiting;
                 stats_.refiled_requests += waiting;
                 const std::uint32_t* from_targets = d_deferred_targets_[lot];
                 const cand_t* from_requests = static_cast<const cand_t*>(d_deferred_requests_[lot]);
@@ -536,7 +543,7 @@ const char* builder_t::link_range(std::uint64_t begin, const std::uint64_t end_t
     stats_.select_distances = counters[0];
     stats_.reverse_distances = counters[1];
     stats_.repruned_lists = counters[2];
-    stats_.dropped_requests = counters[3];
+    stats_.dropped_requests = counters[3] + unfiled_requests_;
     return nullptr;
 }
 

@@ -106,6 +106,7 @@ class builder_t {
     std::uint32_t* d_deferred_targets_[2] = {nullptr, nullptr};
     void* d_deferred_requests_[2] = {nullptr, nullptr};
     std::uint32_t* d_deferred_count_ = nullptr; ///< [2]
+    std::uint64_t unfiled_requests_ = 0;        ///< parked requests given up on (never, unless a re-filing round made no progress)
 };
 
 } // namespace usearch_amd
