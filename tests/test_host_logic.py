@@ -221,3 +221,15 @@ def test_placement_draws_keep_the_fastest_and_release_the_rest():
     assert best.number == 0 and report["kept"] == 1 and 99 not in Stub.closed
     best, report = run({99: 45.0, 0: 51.7}, draws=2, first=already_there)
     assert best is already_there and Stub.closed == [0]
+
+
+def test_the_bench_hash_names_files_that_exist():
+    """`config.sources` of the bench line (and of every traffic.json) hashes the sources the walk is compiled from: a renamed file must
+    not silently fall out of it."""
+    import bench
+    directory = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "usearch_amd", "csrc")
+    for name in bench.WALK_SOURCES:
+        assert os.path.isfile(os.path.join(directory, name)), name
+    pairs = [name for name in os.listdir(directory) if name.startswith("search_") and name.endswith(".hip")]
+    assert len(pairs) == 29  # one translation unit per (metric, scalar) pair of the reference's dispatch table
+    assert len(bench.source_hash()) == 16
