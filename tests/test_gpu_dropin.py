@@ -441,11 +441,15 @@ def test_capacity_multi_and_damaged_files(lib):
     lib.usearch_free(loaded, C.byref(err))
 
 
-def test_concurrent_callers_share_the_index(lib):
-    """The reference leases a context per thread (index_dense.hpp:1984-2000); here every call in flight leases a workspace.
+@pytest.mark.parametrize("coalesce", [False, True])
+def test_concurrent_callers_share_the_index(lib, monkeypatch, coalesce):
+    """The reference leases a context per thread (index_dense.hpp:1984-2000); here every call in flight leases a workspace — or,
+    with `USEARCH_AMD_COALESCE=1` (read when the index is created), calls in flight share a launch (csrc/combiner.hpp).
     Eight threads looping `usearch_search` get the answers a single thread gets."""
     import threading
     err = C.c_char_p()
+    if coalesce:
+        monkeypatch.setenv("USEARCH_AMD_COALESCE", "1")
     index, data = filled_index(lib, 2000, 48, options=create_options(48, metric_kind=METRIC["cos"], connectivity=16,
                                                                      expansion_add=64, expansion_search=64))
     lib.usearch_change_threads_search(index, 8, C.byref(err))

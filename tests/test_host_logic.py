@@ -233,3 +233,16 @@ def test_the_bench_hash_names_files_that_exist():
     pairs = [name for name in os.listdir(directory) if name.startswith("search_") and name.endswith(".hip")]
     assert len(pairs) == 29  # one translation unit per (metric, scalar) pair of the reference's dispatch table
     assert len(bench.source_hash()) == 16
+
+
+def test_calls_in_flight_share_a_launch():
+    """The drop-in's call combiner (usearch_amd/csrc/combiner.hpp: pure host logic) under 32 threads with a mock launch
+    (tests/cpp/combiner_test.cpp): every call gets its own answer, callers that queue up during a launch go out together,
+    groups never mix query kinds or result counts, an exception inside a launch becomes every call's error string."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    binary = "/tmp/usearch_amd_combiner_test"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-pthread",
+                           os.path.join(root, "tests", "cpp", "combiner_test.cpp"), "-o", binary])
+    out = subprocess.run([binary], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "PASSED" in out.stdout, out.stdout + out.stderr

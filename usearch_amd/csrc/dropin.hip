@@ -35,6 +35,7 @@
 
 #include "build.hpp"
 #include "casts.hpp"
+#include "combiner.hpp"
 #include "engine.hpp"
 #include "host_util.hpp"
 
@@ -141,6 +142,9 @@ struct index_t {
     /// index_dense.hpp:1984-2000); everything that changes the index, or links pending members, takes it alone.
     std::shared_mutex mutex;
     std::size_t threads_search = 0; ///< `usearch_change_threads_search`: batches in flight at once (0 = the engine's default)
+    /// `USEARCH_AMD_COALESCE=1` (read when the index is created): `usearch_search` calls in flight share a launch (combiner.hpp)
+    bool coalesce = env_size("USEARCH_AMD_COALESCE", 0) != 0;
+    combiner_t combiner;
     // configuration — `usearch_init_options_t`, c/usearch.h:64-110
     metric_kind_t metric = metric_cos_k;
     scalar_kind_t scalar = scalar_f32_k;
@@ -823,6 +827,44 @@ size_t usearch_search(usearch_index_t handle, void const* query, usearch_scalar_
     if (kind == scalar_unknown_k) {
         fail(error, "Unknown scalar kind!");
         return 0;
+    }
+    if (index.coalesce && query && keys && distances && count) {
+        // callers that arrive while a launch is in flight go out together in the next one (csrc/combiner.hpp)
+        combined_call_t call;
+        call.query = query, call.query_bytes = bytes_per_vector(kind, index.dimensions), call.kind = (int)kind, call.wanted = count;
+        call.keys = reinterpret_cast<std::uint64_t*>(keys), call.distances = distances;
+        index.combiner.submit(call, [&index](std::vector<combined_call_t*>& batch) {
+            const combined_call_t& first = *batch[0];
+            if (batch.size() == 1) {
+                usearch_error_t failure = nullptr;
+                batch[0]->found = search_shared(index, first.query, (scalar_kind_t)first.kind, 1, first.query_bytes, first.wanted,
+                                                reinterpret_cast<usearch_key_t*>(first.keys), first.wanted * 8, first.distances,
+                                                first.wanted * 4, nullptr, nullptr, nullptr, nullptr, nullptr, &failure);
+                batch[0]->error = failure;
+                return;
+            }
+            std::vector<std::uint8_t> queries(batch.size() * first.query_bytes);
+            std::vector<std::uint64_t> all_keys(batch.size() * first.wanted);
+            std::vector<float> all_distances(batch.size() * first.wanted);
+            std::vector<std::size_t> counts(batch.size(), 0);
+            for (std::size_t i = 0; i < batch.size(); ++i)
+                std::memcpy(queries.data() + i * first.query_bytes, batch[i]->query, first.query_bytes);
+            usearch_error_t failure = nullptr;
+            search_shared(index, queries.data(), (scalar_kind_t)first.kind, batch.size(), first.query_bytes, first.wanted,
+                          reinterpret_cast<usearch_key_t*>(all_keys.data()), first.wanted * 8, all_distances.data(), first.wanted * 4,
+                          counts.data(), nullptr, nullptr, nullptr, nullptr, &failure);
+            for (std::size_t i = 0; i < batch.size(); ++i) {
+                batch[i]->error = failure;
+                if (failure)
+                    continue;
+                std::memcpy(batch[i]->keys, all_keys.data() + i * first.wanted, first.wanted * 8);
+                std::memcpy(batch[i]->distances, all_distances.data() + i * first.wanted, first.wanted * 4);
+                batch[i]->found = counts[i];
+            }
+        });
+        if (call.error)
+            fail(error, call.error);
+        return call.error ? 0 : call.found;
     }
     return search_shared(index, query, kind, 1, bytes_per_vector(kind, index.dimensions), count, keys, count * 8, distances,
                          count * 4, nullptr, nullptr, nullptr, nullptr, nullptr, error);
