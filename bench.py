@@ -126,7 +126,7 @@ def synthetic_vectors_device(count: int, dim: int, dtype: str, seed: int, device
 
 
 WALK_SOURCES = ("common.hpp", "engine.hpp", "engine.hip", "host_util.hpp", "image.hpp", "kernels.hpp", "launch_impl.hpp",
-                "pair_kernels.hpp", "placement.hpp", "placement.hip")
+                "placement.hpp", "placement.hip")
 
 
 def source_hash() -> str:
@@ -904,7 +904,7 @@ def main() -> None:
                        "index_builder": args.builder, "index_build_seconds": round(build_seconds, 1),
                        "index_build": build_stats, "kernel_passes": passes,
                        "kernel_passes_by_expansion": {str(ef): n for ef, n in sorted(sweep_passes.items())},
-                       "scratch_mode": {1: "lds", 2: "global-hash", 3: "global", 4: "pair-lds"}.get(stats.mode, "?"),
+                       "scratch_mode": {1: "lds", 2: "global-hash", 3: "global"}.get(stats.mode, "?"),
                        "frontier": {1: "heap", 2: "in-top"}.get(stats.frontier, "?"), "kernel_build": stats.variant,
                        "persistent_waves": stats.grid, "lds_bytes_per_wave": stats.lds_bytes,
                        "rows_inline_with_lists": bool(index.inline_rows),

@@ -932,10 +932,24 @@ template <typename key_at = default_key_t, typename compressed_slot_at = default
         result.keys_.resize(wanted), result.distances_.resize(wanted);
         usearch_error_t error = nullptr;
         std::size_t found = 0;
-        if (exact) { // brute force over every member (index.hpp:3046-3049); predicates apply to graph searches
+        if (exact && std::is_same<predicate_t, dummy_predicate_t>::value) { // brute force over every member (index.hpp:3046-3049)
             amd_detail::api().search_exact_many(handle_, query, amd_detail::to_c(kind), 1, 0, wanted, result.keys_.data(),
                                                 wanted * sizeof(vector_key_t), result.distances_.data(), wanted * sizeof(distance_t),
                                                 &found, &error);
+        } else if (exact) { // … over the members the predicate lets through (`search_exact_` skips the others, index.hpp:4260-4263)
+            using callable_t = typename std::remove_reference<predicate_at>::type;
+            auto trampoline = [](usearch_key_t key, void* opaque) -> int {
+                return (*static_cast<callable_t*>(opaque))((vector_key_t)key) ? 1 : 0;
+            };
+            usearch_filter_t made = amd_detail::api().filter_from_callback(
+                handle_, +trampoline, const_cast<void*>(static_cast<void const*>(std::addressof(predicate))), &error);
+            if (!error) {
+                amd_detail::api().filtered_search_exact_many(handle_, made, query, amd_detail::to_c(kind), 1, 0, wanted,
+                                                             result.keys_.data(), wanted * sizeof(vector_key_t),
+                                                             result.distances_.data(), wanted * sizeof(distance_t), &found, &error);
+                usearch_error_t ignored = nullptr;
+                amd_detail::api().filter_free(made, &ignored);
+            }
         } else if (std::is_same<predicate_t, dummy_predicate_t>::value) {
             amd_detail::api().search_many(handle_, query, amd_detail::to_c(kind), 1, 0, wanted, result.keys_.data(),
                                           wanted * sizeof(vector_key_t), result.distances_.data(), wanted * sizeof(distance_t), &found,

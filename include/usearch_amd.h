@@ -186,6 +186,60 @@ USEARCH_AMD_EXPORT void usearch_amd_exact_search_many(usearch_amd_snapshot_t sna
                                                       usearch_amd_distance_t* distances, uint64_t* counts,
                                                       float* kernel_ms, usearch_amd_error_t* error);
 
+/* ---- filtered search: the caller's predicate as an HBM-resident bitmap --------------------------------------------------
+ *  The reference's predicate is a host callable evaluated inside the traversal (`usearch_filtered_search`, c/usearch.h:391-395 →
+ *  c/lib.cpp:413-429 → index_dense.hpp:774-779, 2071-2084 → index.hpp:4200-4205, 4236-4240) and inside the brute-force scan
+ *  (index.hpp:4260-4263). A host function cannot run on the device: the predicate travels as ONE BIT PER SLOT, tested by the
+ *  kernels at exactly those places — members that fail it still route the walk, they never enter the result. A filter is made
+ *  once (a kernel over the snapshot's keys; nothing per member happens on the host), lives in HBM, and serves any number of
+ *  batches; it describes the snapshot it was made for, with the members that snapshot had at that moment.
+ * -------------------------------------------------------------------------------------------------------------------------- */
+
+typedef void* usearch_amd_filter_t;
+
+/** Members whose key lies in [first_key, last_key], both ends included. */
+USEARCH_AMD_EXPORT usearch_amd_filter_t usearch_amd_filter_from_key_range(usearch_amd_snapshot_t snapshot,
+                                                                         usearch_amd_key_t first_key, usearch_amd_key_t last_key,
+                                                                         usearch_amd_error_t* error);
+/** Members whose key is among `keys[0 .. keys_count)` (`allow != 0`) or is NOT among them (`allow == 0`: a deny list). */
+USEARCH_AMD_EXPORT usearch_amd_filter_t usearch_amd_filter_from_keys(usearch_amd_snapshot_t snapshot, usearch_amd_key_t const* keys,
+                                                                    size_t keys_count, int allow, usearch_amd_error_t* error);
+/** The caller's own bitmap (host memory): bit `s & 31` of `bits[s >> 5]` = the member in slot `s` passes; slots are the members in
+ *  the order the image holds them (= the order they were added). `words` ≥ ⌈size / 32⌉. */
+USEARCH_AMD_EXPORT usearch_amd_filter_t usearch_amd_filter_from_bits(usearch_amd_snapshot_t snapshot, uint32_t const* bits, size_t words,
+                                                                    usearch_amd_error_t* error);
+/** How many members pass (tombstones never do). */
+USEARCH_AMD_EXPORT size_t usearch_amd_filter_allowed(usearch_amd_filter_t filter);
+/** The bitmap in HBM (⌈size / 32⌉ words), e.g. to hand to `usearch_amd_search_many_device`-style callers of their own kernels. */
+USEARCH_AMD_EXPORT void const* usearch_amd_filter_device_bits(usearch_amd_filter_t filter);
+USEARCH_AMD_EXPORT void usearch_amd_filter_free(usearch_amd_filter_t filter, usearch_amd_error_t* error);
+
+/** `usearch_amd_search_many` under a filter — `usearch_filtered_search` (c/usearch.h:391-395) for a batch. Keys, distances, counts
+ *  and both traversal counters are the reference's for the predicate the bitmap stands for. `filter` = NULL: no predicate. */
+USEARCH_AMD_EXPORT void usearch_amd_filtered_search_many(usearch_amd_snapshot_t snapshot, usearch_amd_filter_t filter,
+                                                         void const* queries, int query_kind, size_t queries_count,
+                                                         size_t queries_stride, size_t wanted, size_t expansion,
+                                                         usearch_amd_key_t* keys, usearch_amd_distance_t* distances,
+                                                         uint64_t* counts, uint64_t* visited, uint64_t* computed,
+                                                         usearch_amd_tuning_t const* tuning, usearch_amd_stats_t* stats,
+                                                         usearch_amd_error_t* error);
+/** `usearch_amd_search_many_device` under a filter (HBM in / out, the caller's stream). */
+USEARCH_AMD_EXPORT void usearch_amd_filtered_search_many_device(usearch_amd_snapshot_t snapshot, usearch_amd_filter_t filter,
+                                                                void const* queries, size_t queries_count, size_t queries_stride,
+                                                                size_t wanted, size_t expansion, usearch_amd_key_t* keys,
+                                                                usearch_amd_distance_t* distances, uint64_t* counts,
+                                                                uint64_t* visited, uint64_t* computed, void* stream,
+                                                                usearch_amd_tuning_t const* tuning, int timed,
+                                                                usearch_amd_stats_t* stats, usearch_amd_error_t* error);
+/** `filtered_search(query, wanted, predicate, thread, exact = true)` of the class for a batch (index_dense.hpp:774-779 →
+ *  `search_exact_` with the predicate, index.hpp:4252-4268): brute force over the members that pass. Host buffers, any query scalar
+ *  kind; `tiled != 0` = the matrix-unit kernel (pairs and tolerances of `usearch_amd_exact_search_many_tiled`). */
+USEARCH_AMD_EXPORT void usearch_amd_filtered_exact_search_many(usearch_amd_snapshot_t snapshot, usearch_amd_filter_t filter,
+                                                               void const* queries, int query_kind, size_t queries_count,
+                                                               size_t queries_stride, size_t wanted, usearch_amd_key_t* keys,
+                                                               usearch_amd_distance_t* distances, uint64_t* counts, int tiled,
+                                                               float* kernel_ms, usearch_amd_error_t* error);
+
 /**
  *  Closest member on a given LEVEL of the hierarchy for a batch of queries — `index_dense_gt::cluster(query, level)`
  *  (index_dense.hpp:788-793 → index_gt::cluster, index.hpp:3089-3125): the greedy descent of `search_for_one_` from the top

@@ -183,6 +183,44 @@ USEARCH_EXPORT void usearch_search_exact_many(usearch_index_t index, void const*
                                               size_t queries_count, size_t queries_stride, size_t count, usearch_key_t* keys,
                                               size_t keys_stride, usearch_distance_t* distances, size_t distances_stride,
                                               size_t* counts, usearch_error_t* error);
+/* ---- filtered search without a callback per member ------------------------------------------------------------------------
+ *  `usearch_filtered_search` (c/usearch.h:391-395 → c/lib.cpp:413-429 → index_dense.hpp:774-779, 2071-2084) takes a host callback.
+ *  The reference runs it inside the traversal — a few thousand calls per query (index.hpp:4200-4205, 4236-4240). A host function
+ *  cannot run on the device, so this library evaluates it over EVERY member first (one bit per slot, which the kernels then test
+ *  where the reference calls the predicate): O(members) callbacks per `usearch_filtered_search` call. That entry point stays, for
+ *  compatibility; a caller that searches more than once under one predicate, or that can say what the predicate IS, makes a
+ *  filter instead: a bitmap built once (by a kernel over the keys in HBM for ranges and key sets) that any number of batches
+ *  reuse. A filter describes the index as it was when the filter was made: after `usearch_add / remove / rename / load / view /
+ *  clear / usearch_gpu_release` searches under it fail with "The index changed since the filter was made".
+ * ---------------------------------------------------------------------------------------------------------------------------- */
+typedef void* usearch_filter_t;
+
+/** Members whose key lies in [first_key, last_key], both ends included. */
+USEARCH_EXPORT usearch_filter_t usearch_filter_from_key_range(usearch_index_t index, usearch_key_t first_key, usearch_key_t last_key,
+                                                             usearch_error_t* error);
+/** Members whose key is among `keys[0 .. keys_count)` (`allow`) or is not among them (`!allow`: a deny list). */
+USEARCH_EXPORT usearch_filter_t usearch_filter_from_keys(usearch_index_t index, usearch_key_t const* keys, size_t keys_count,
+                                                        bool allow, usearch_error_t* error);
+/** The callback of `usearch_filtered_search`, evaluated over every member NOW, once. */
+USEARCH_EXPORT usearch_filter_t usearch_filter_from_callback(usearch_index_t index, int (*filter)(usearch_key_t key, void* filter_state),
+                                                            void* filter_state, usearch_error_t* error);
+/** Members that pass. */
+USEARCH_EXPORT size_t usearch_filter_allowed(usearch_filter_t filter, usearch_error_t* error);
+USEARCH_EXPORT void usearch_filter_free(usearch_filter_t filter, usearch_error_t* error);
+/** `usearch_filtered_search` for a batch under a made filter; layout as `usearch_search_many`. */
+USEARCH_EXPORT void usearch_filtered_search_many(usearch_index_t index, usearch_filter_t filter, void const* queries,
+                                                 usearch_scalar_kind_t query_kind, size_t queries_count, size_t queries_stride,
+                                                 size_t count, usearch_key_t* keys, size_t keys_stride, usearch_distance_t* distances,
+                                                 size_t distances_stride, size_t* counts, size_t* visited_members,
+                                                 size_t* computed_distances, usearch_error_t* error);
+/** `index_dense_gt::filtered_search(query, count, predicate, thread, exact = true)` for a batch (index_dense.hpp:774-779 →
+ *  `search_exact_` with the predicate, index.hpp:4252-4268): brute force over the members that pass. Layout as
+ *  `usearch_search_exact_many`. */
+USEARCH_EXPORT void usearch_filtered_search_exact_many(usearch_index_t index, usearch_filter_t filter, void const* queries,
+                                                       usearch_scalar_kind_t query_kind, size_t queries_count, size_t queries_stride,
+                                                       size_t count, usearch_key_t* keys, size_t keys_stride,
+                                                       usearch_distance_t* distances, size_t distances_stride, size_t* counts,
+                                                       usearch_error_t* error);
 /** Threads `usearch_change_threads_add / _search` recorded (the reference's `index_limits_t`, index.hpp:1338-1357). */
 USEARCH_EXPORT size_t usearch_threads_search(usearch_index_t index, usearch_error_t* error);
 /** Takes (or refreshes) the HBM snapshot now instead of at the next search. */
@@ -249,6 +287,15 @@ typedef struct usearch_amd_c_api_t {
     size_t (*threads_search)(usearch_index_t, usearch_error_t*);
     void (*gpu_sync)(usearch_index_t, usearch_error_t*);
     void (*gpu_release)(usearch_index_t, usearch_error_t*);
+    usearch_filter_t (*filter_from_key_range)(usearch_index_t, usearch_key_t, usearch_key_t, usearch_error_t*);
+    usearch_filter_t (*filter_from_keys)(usearch_index_t, usearch_key_t const*, size_t, bool, usearch_error_t*);
+    usearch_filter_t (*filter_from_callback)(usearch_index_t, int (*)(usearch_key_t, void*), void*, usearch_error_t*);
+    size_t (*filter_allowed)(usearch_filter_t, usearch_error_t*);
+    void (*filter_free)(usearch_filter_t, usearch_error_t*);
+    void (*filtered_search_many)(usearch_index_t, usearch_filter_t, void const*, usearch_scalar_kind_t, size_t, size_t, size_t,
+                                 usearch_key_t*, size_t, usearch_distance_t*, size_t, size_t*, size_t*, size_t*, usearch_error_t*);
+    void (*filtered_search_exact_many)(usearch_index_t, usearch_filter_t, void const*, usearch_scalar_kind_t, size_t, size_t, size_t,
+                                       usearch_key_t*, size_t, usearch_distance_t*, size_t, size_t*, usearch_error_t*);
 } usearch_amd_c_api_t;
 USEARCH_EXPORT usearch_amd_c_api_t const* usearch_amd_c_api(void);
 

@@ -172,14 +172,19 @@ class OracleIndex:
         return keys, dists, visited, computed
 
     def filtered_search(self, query: np.ndarray, k: int, predicate, dtype: Optional[str] = None,
-                        expansion: int = 64, lanes: int = 0):
+                        expansion: int = 64, lanes: int = 0, exact: bool = False, counters: bool = False):
+        """→ (found, keys, distances) [+ (visited_members, computed_distances) with `counters`]; `exact`: the brute-force scan
+        under the predicate (index.hpp:4252-4268)."""
         dtype = dtype or self.dtype
         query = np.ascontiguousarray(query)
         keys = np.zeros(k, dtype=np.uint64)
         dists = np.zeros(k, dtype=np.float32)
+        visited, computed = C.c_uint64(0), C.c_uint64(0)
         cb = FILTER_T(lambda key, _state: int(bool(predicate(int(key)))))
-        n = lib().uo_search(C.byref(self.ix), _ptr(query), SCALAR[dtype], k, expansion, 0, lanes,
-                            C.cast(cb, C.c_void_p), None, _ptr(keys), _ptr(dists), None, None)
+        n = lib().uo_search(C.byref(self.ix), _ptr(query), SCALAR[dtype], k, expansion, int(exact), lanes,
+                            C.cast(cb, C.c_void_p), None, _ptr(keys), _ptr(dists), C.byref(visited), C.byref(computed))
+        if counters:
+            return int(n), keys, dists, int(visited.value), int(computed.value)
         return int(n), keys, dists
 
 

@@ -116,6 +116,15 @@ int main(int argc, char** argv) {
     EXPECT(filtered && filtered.size() == wanted);
     for (std::size_t j = 0; j < filtered.size(); ++j)
         EXPECT(filtered[j].member.key % 2 == 0);
+    // filtered AND exact: the brute-force scan skips what the predicate rejects (index.hpp:4260-4263) — an in-sample query with an
+    // odd key must not come back under "even keys only", and nothing odd may
+    auto filtered_exact = index.filtered_search(data.data() + 7 * dims, wanted, [](default_key_t key) { return key % 2 == 0; }, 0, true);
+    EXPECT(filtered_exact && filtered_exact.size() == wanted);
+    for (std::size_t j = 0; j < filtered_exact.size(); ++j)
+        EXPECT(filtered_exact[j].member.key % 2 == 0);
+    auto unfiltered_exact = index.search(data.data() + 7 * dims, wanted, 0, true);
+    EXPECT(unfiltered_exact[0].member.key == ids[7]);
+    EXPECT((ids[7] % 2 == 0) == (filtered_exact[0].member.key == ids[7]));
     // dump_to with a capacity pads: key 0 and a (signalling) NaN
     default_key_t padded_keys[16];
     float padded_distances[16];

@@ -80,6 +80,20 @@ def lib():
     L.usearch_exact_search.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int,
                                        C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                        C.c_size_t, err]
+    L.usearch_filter_from_key_range.restype = C.c_void_p
+    L.usearch_filter_from_key_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, err]
+    L.usearch_filter_from_keys.restype = C.c_void_p
+    L.usearch_filter_from_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_bool, err]
+    L.usearch_filter_from_callback.restype = C.c_void_p
+    L.usearch_filter_from_callback.argtypes = [C.c_void_p, FILTER, C.c_void_p, err]
+    L.usearch_filter_allowed.restype = C.c_size_t
+    L.usearch_filter_allowed.argtypes = [C.c_void_p, err]
+    L.usearch_filter_free.argtypes = [C.c_void_p, err]
+    L.usearch_filtered_search_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
+                                               C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               err]
+    L.usearch_filtered_search_exact_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t,
+                                                     C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, err]
     return L
 
 
@@ -242,6 +256,75 @@ def test_known_distances(lib):
     half = np.zeros(2, dtype=np.float16)
     lib.usearch_distance(ptr(half), ptr(half), SCALAR["f16"], 2, METRIC["haversine"], C.byref(err))
     assert err.value and b"kernel" in err.value
+
+
+def test_made_filters_answer_like_the_callback(lib):
+    """`usearch_filter_from_*` + `usearch_filtered_search_many`: the predicate evaluated once (or never on the host: ranges and key
+    sets are built by a kernel over the keys in HBM) must answer exactly like `usearch_filtered_search` with the callback, query by
+    query — and a filter must refuse to outlive a change of the index."""
+    err = C.c_char_p()
+    n, dims, k = 3000, 48, 10
+    data = util.make_vectors(n, dims, "f32", seed=5)
+    options = Options(METRIC["cos"], None, SCALAR["f32"], dims, 16, 128, 64, False)
+    index, _ = filled_index(lib, n, dims, options=options, data=data)
+    queries = util.make_vectors(32, dims, "f32", seed=6)
+    listed = np.array([key for key in range(n) if key % 7 == 3], dtype=np.uint64)
+    cases = {
+        "range": (lambda key: 500 <= key <= 1999, lambda: lib.usearch_filter_from_key_range(index, 500, 1999, C.byref(err))),
+        "keys": (lambda key: key % 7 == 3, lambda: lib.usearch_filter_from_keys(index, ptr(listed), len(listed), True, C.byref(err))),
+        "deny": (lambda key: key % 7 != 3, lambda: lib.usearch_filter_from_keys(index, ptr(listed), len(listed), False, C.byref(err))),
+    }
+    calls = [0]
+    def counting(key, state):
+        calls[0] += 1
+        return int(key % 5 == 0)
+    counted = FILTER(counting)
+    cases["callback"] = (lambda key: key % 5 == 0, lambda: lib.usearch_filter_from_callback(index, counted, None, C.byref(err)))
+    for name, (predicate, make) in cases.items():
+        made = make()
+        ok(err)
+        assert made, name
+        assert lib.usearch_filter_allowed(made, C.byref(err)) == sum(1 for key in range(n) if predicate(key)), name
+        keys = np.zeros((len(queries), k), dtype=np.uint64)
+        distances = np.zeros((len(queries), k), dtype=np.float32)
+        counts = np.zeros(len(queries), dtype=np.uint64)
+        before = calls[0]
+        lib.usearch_filtered_search_many(index, made, ptr(queries), SCALAR["f32"], len(queries), queries.strides[0], k, ptr(keys),
+                                         keys.strides[0], ptr(distances), distances.strides[0], ptr(counts), None, None, C.byref(err))
+        ok(err)
+        assert calls[0] == before, "a made filter costs no callback at search time"
+        callback = FILTER(lambda key, state, predicate=predicate: int(predicate(key)))
+        one_keys, one_distances = np.zeros(k, dtype=np.uint64), np.zeros(k, dtype=np.float32)
+        for q in range(len(queries)):
+            found = lib.usearch_filtered_search(index, ptr(queries[q]), SCALAR["f32"], k, callback, None, ptr(one_keys),
+                                                ptr(one_distances), C.byref(err))
+            ok(err)
+            assert found == counts[q], (name, q)
+            assert np.array_equal(one_keys[:found], keys[q, :found]) and util.same_float_bits(one_distances[:found], distances[q, :found])
+            assert all(predicate(int(key)) for key in keys[q, :found])
+        # brute force under the same filter: nothing the predicate rejects, and never farther than the graph's answer
+        exact_keys = np.zeros((len(queries), k), dtype=np.uint64)
+        exact_distances = np.zeros((len(queries), k), dtype=np.float32)
+        exact_counts = np.zeros(len(queries), dtype=np.uint64)
+        lib.usearch_filtered_search_exact_many(index, made, ptr(queries), SCALAR["f32"], len(queries), queries.strides[0], k,
+                                               ptr(exact_keys), exact_keys.strides[0], ptr(exact_distances),
+                                               exact_distances.strides[0], ptr(exact_counts), C.byref(err))
+        ok(err)
+        assert np.all(exact_counts == k) and all(predicate(int(key)) for key in exact_keys.reshape(-1))
+        assert np.all(exact_distances[:, 0] <= distances[:, 0] + 1e-6)
+        if name == "callback":
+            assert calls[0] == n, "the callback ran once per member, when the filter was made"
+            # the index changes: the filter describes members that are no longer the whole story
+            fresh = util.make_vectors(1, dims, "f32", seed=9)
+            lib.usearch_reserve(index, n + 8, C.byref(err))
+            lib.usearch_add(index, 900000, ptr(fresh[0]), SCALAR["f32"], C.byref(err))
+            ok(err)
+            lib.usearch_filtered_search_many(index, made, ptr(queries), SCALAR["f32"], len(queries), queries.strides[0], k, ptr(keys),
+                                             keys.strides[0], ptr(distances), distances.strides[0], ptr(counts), None, None, C.byref(err))
+            assert err.value and b"changed since the filter was made" in err.value
+            err = C.c_char_p()
+        lib.usearch_filter_free(made, C.byref(err))
+    lib.usearch_free(index, C.byref(err))
 
 
 def test_filtered_search_and_rename(lib):

@@ -101,17 +101,6 @@ def test_search_matches_oracle_and_reference(reference, metric, dtype, ndim, n, 
             assert np.array_equal(heap.visited_per_query, got.visited_per_query)
             assert np.array_equal(heap.computed_per_query, got.computed_per_query)
 
-    # integer-valued pairs on short rows: the two-queries-per-wave walk (pair_kernels.hpp) is one switch away and must be
-    # indistinguishable — keys, distance bits, counts, both counters
-    if dtype in ("b1", "i8") and connectivity <= 16 and vectors.shape[1] * vectors.itemsize <= 128 and max(expansion, k) <= 128:
-        from usearch_amd import Tuning
-        pair = check_against_oracle(index, image, queries, k, dtype, expansion, tuning=Tuning(mode=4))
-        assert pair.stats.mode == 4, "the two-queries-per-wave kernel did not run"
-        assert np.array_equal(pair.keys, got.keys) and util.same_float_bits(pair.distances, got.distances)
-        assert np.array_equal(pair.counts, got.counts)
-        assert np.array_equal(pair.visited_per_query, got.visited_per_query)
-        assert np.array_equal(pair.computed_per_query, got.computed_per_query)
-
     # the real reference, same image, same queries
     ref_index.expansion_search = expansion
     rkeys, rdists, rcounts, rvisited, rcomputed = ref_index.search(queries, k, dtype=dtype, threads=1)

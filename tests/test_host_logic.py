@@ -117,7 +117,8 @@ def test_drop_in_library_exports_the_reference_c_abi():
         assert hasattr(library, f"usearch_{name}"), f"usearch_{name} is missing from the drop-in"
     header = open(os.path.join(ROOT, "include", "usearch_c_dropin.h")).read()
     declared = sorted(set(re.findall(r"USEARCH_EXPORT[^;(]*?\b(usearch_\w+)\s*\(", header)))
-    assert len(declared) == 45  # the 38 + search_many, cluster_many, search_exact_many, threads_search, gpu_sync, gpu_release, c_api
+    # the 38 + search_many, cluster_many, search_exact_many, threads_search, gpu_sync, gpu_release, c_api + the seven filter entry points
+    assert len(declared) == 52, declared
     for name in declared:
         assert hasattr(library, name), f"{name} is declared in include/usearch_c_dropin.h but not exported"
     reference_header = "/root/reference/c/usearch.h"

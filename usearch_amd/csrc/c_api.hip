@@ -16,6 +16,7 @@
 #include "build.hpp"
 #include "casts.hpp"
 #include "engine.hpp"
+#include "filter.hpp"
 #include "kernels.hpp"
 #include "sharded.hpp"
 
@@ -303,6 +304,113 @@ void usearch_amd_search_many_device(usearch_amd_snapshot_t snapshot, void const*
                                                              &s, timed != 0))
         return fail(error, e);
     stats_to_c(s, stats);
+} catch (...) {
+    fail_from_exception(error);
+}
+
+// ---- filters (filter.hpp)
+static filter_t* as_filter(usearch_amd_filter_t f) { return static_cast<filter_t*>(f); }
+
+usearch_amd_filter_t usearch_amd_filter_from_key_range(usearch_amd_snapshot_t snapshot, usearch_amd_key_t first_key,
+                                                       usearch_amd_key_t last_key, usearch_amd_error_t* error) try {
+    std::unique_ptr<filter_t> filter;
+    if (const char* e = filter_t::from_key_range(*as_snapshot(snapshot), first_key, last_key, filter))
+        return fail(error, e), nullptr;
+    return filter.release();
+} catch (...) {
+    return fail_from_exception(error), nullptr;
+}
+
+usearch_amd_filter_t usearch_amd_filter_from_keys(usearch_amd_snapshot_t snapshot, usearch_amd_key_t const* keys, size_t keys_count,
+                                                  int allow, usearch_amd_error_t* error) try {
+    std::unique_ptr<filter_t> filter;
+    if (const char* e = filter_t::from_keys(*as_snapshot(snapshot), keys, keys_count, allow != 0, filter))
+        return fail(error, e), nullptr;
+    return filter.release();
+} catch (...) {
+    return fail_from_exception(error), nullptr;
+}
+
+usearch_amd_filter_t usearch_amd_filter_from_bits(usearch_amd_snapshot_t snapshot, uint32_t const* bits, size_t words,
+                                                  usearch_amd_error_t* error) try {
+    std::unique_ptr<filter_t> filter;
+    if (const char* e = filter_t::from_bits(*as_snapshot(snapshot), bits, words, filter))
+        return fail(error, e), nullptr;
+    return filter.release();
+} catch (...) {
+    return fail_from_exception(error), nullptr;
+}
+
+size_t usearch_amd_filter_allowed(usearch_amd_filter_t filter) { return filter ? (size_t)as_filter(filter)->allowed() : 0; }
+void const* usearch_amd_filter_device_bits(usearch_amd_filter_t filter) { return filter ? as_filter(filter)->bits() : nullptr; }
+void usearch_amd_filter_free(usearch_amd_filter_t filter, usearch_amd_error_t*) { delete as_filter(filter); }
+
+void usearch_amd_filtered_search_many(usearch_amd_snapshot_t snapshot, usearch_amd_filter_t filter, void const* queries,
+                                      int query_kind, size_t queries_count, size_t queries_stride, size_t wanted,
+                                      size_t expansion, usearch_amd_key_t* keys, usearch_amd_distance_t* distances,
+                                      uint64_t* counts, uint64_t* visited, uint64_t* computed,
+                                      usearch_amd_tuning_t const* tuning, usearch_amd_stats_t* stats,
+                                      usearch_amd_error_t* error) try {
+    const scalar_kind_t kind = scalar_from_c(query_kind);
+    if (kind == scalar_unknown_k)
+        return fail(error, "Unknown scalar kind!");
+    search_extras_t extras;
+    if (filter) {
+        if (const char* e = as_filter(filter)->check(*as_snapshot(snapshot)))
+            return fail(error, e);
+        extras.allow_bits = as_filter(filter)->bits();
+    }
+    search_stats_t s;
+    if (const char* e = as_snapshot(snapshot)->search_host(queries, kind, queries_count, queries_stride, wanted, expansion, keys,
+                                                           distances, counts, visited, computed, tuning_from_c(tuning), &s,
+                                                           nullptr, &extras))
+        return fail(error, e);
+    stats_to_c(s, stats);
+} catch (...) {
+    fail_from_exception(error);
+}
+
+void usearch_amd_filtered_search_many_device(usearch_amd_snapshot_t snapshot, usearch_amd_filter_t filter, void const* queries,
+                                             size_t queries_count, size_t queries_stride, size_t wanted, size_t expansion,
+                                             usearch_amd_key_t* keys, usearch_amd_distance_t* distances, uint64_t* counts,
+                                             uint64_t* visited, uint64_t* computed, void* stream,
+                                             usearch_amd_tuning_t const* tuning, int timed, usearch_amd_stats_t* stats,
+                                             usearch_amd_error_t* error) try {
+    if (queries_count && wanted && (!queries || !keys || !distances || !counts || !visited || !computed))
+        return fail(error, "Device entry point needs every buffer");
+    search_extras_t extras;
+    if (filter) {
+        if (const char* e = as_filter(filter)->check(*as_snapshot(snapshot)))
+            return fail(error, e);
+        extras.allow_bits = as_filter(filter)->bits();
+    }
+    search_stats_t s;
+    if (const char* e = as_snapshot(snapshot)->search_device(queries, queries_count, queries_stride, wanted, expansion, keys,
+                                                             distances, counts, visited, computed,
+                                                             static_cast<hipStream_t>(stream), tuning_from_c(tuning), &s,
+                                                             timed != 0, &extras))
+        return fail(error, e);
+    stats_to_c(s, stats);
+} catch (...) {
+    fail_from_exception(error);
+}
+
+void usearch_amd_filtered_exact_search_many(usearch_amd_snapshot_t snapshot, usearch_amd_filter_t filter, void const* queries,
+                                            int query_kind, size_t queries_count, size_t queries_stride, size_t wanted,
+                                            usearch_amd_key_t* keys, usearch_amd_distance_t* distances, uint64_t* counts,
+                                            int tiled, float* kernel_ms, usearch_amd_error_t* error) try {
+    const scalar_kind_t kind = scalar_from_c(query_kind);
+    if (kind == scalar_unknown_k)
+        return fail(error, "Unknown scalar kind!");
+    const std::uint32_t* bits = nullptr;
+    if (filter) {
+        if (const char* e = as_filter(filter)->check(*as_snapshot(snapshot)))
+            return fail(error, e);
+        bits = as_filter(filter)->bits();
+    }
+    if (const char* e = as_snapshot(snapshot)->exact_host(queries, kind, queries_count, queries_stride, wanted, keys, distances,
+                                                          counts, kernel_ms, tiled != 0, bits))
+        fail(error, e);
 } catch (...) {
     fail_from_exception(error);
 }

@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <shared_mutex>
@@ -37,6 +38,7 @@
 #include "casts.hpp"
 #include "combiner.hpp"
 #include "engine.hpp"
+#include "filter.hpp"
 #include "host_util.hpp"
 
 using namespace usearch_amd;
@@ -126,11 +128,17 @@ template <typename result_at, typename body_at> result_at guarded(usearch_error_
 
 /// Callers of this library loop single queries from many threads (Go routines, C# tasks: the reference leases a context per thread,
 /// index_dense.hpp:1984-2000). Every call is a launch on its own stream, and the HIP runtime multiplexes streams onto FOUR hardware
-/// queues unless told otherwise — kernels sharing a queue run one after the other. Ask for sixteen before the runtime starts (a
-/// value the process already set wins): 16 callers on the 10M×768 f16 index, expansion 64: 11.4 k → 23.8 k calls per second
-/// (scripts/threads_check.py). No effect on a process whose HIP runtime is already up.
+/// queues unless told otherwise — kernels sharing a queue run one after the other. `GPU_MAX_HW_QUEUES=16` in the process
+/// environment lifts that (16 callers on the 10M×768 f16 index, expansion 64: 11.4 k → 23.8 k calls per second,
+/// scripts/threads_check.py). The library does not touch the environment of its host process on its own: a
+/// process that cannot set the variable itself opts in with USEARCH_AMD_HW_QUEUES=n, which is copied over at load time (before
+/// the HIP runtime starts; a GPU_MAX_HW_QUEUES already set wins).
 struct hardware_queues_t {
-    hardware_queues_t() { (void)setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0); }
+    hardware_queues_t() {
+        if (const char* wanted = std::getenv("USEARCH_AMD_HW_QUEUES"))
+            if (*wanted)
+                (void)setenv("GPU_MAX_HW_QUEUES", wanted, /*overwrite=*/0);
+    }
 } hardware_queues;
 
 using shared_lock_t = std::shared_lock<std::shared_mutex>;
@@ -172,10 +180,14 @@ struct index_t {
     std::unordered_multimap<std::uint64_t, std::uint32_t> lookup;
     bool lookup_valid = false;
 
+    /// Bumped by everything that changes the members or drops their HBM copy: a `usearch_filter_t` describes one version.
+    std::uint64_t version = 0;
+
     std::size_t bpv() const { return bytes_per_vector(scalar, dimensions); }
     std::size_t size() const { return staged ? keys.size() : has_image ? (std::size_t)image.size : 0; }
 
     void drop_device() {
+        ++version;
         delete builder, builder = nullptr;
         delete snapshot, snapshot = nullptr;
     }
@@ -317,6 +329,46 @@ struct index_t {
 };
 
 index_t* as_index(usearch_index_t handle) { return static_cast<index_t*>(handle); }
+
+/// A `usearch_filter_t`: the predicate as a bitmap in HBM, and the version of the index it describes.
+struct made_filter_t {
+    index_t* index = nullptr;
+    std::uint64_t version = 0;
+    std::unique_ptr<filter_t> bitmap; ///< null while the index has no members
+};
+
+/// The host callback over every member, as one bit per slot (what `usearch_filtered_search` has to do per call, and
+/// `usearch_filter_from_callback` once). Any lock on the index will do.
+static void callback_bits(index_t& index, int (*filter)(usearch_key_t key, void* filter_state), void* filter_state,
+                          std::vector<std::uint32_t>& bits) {
+    std::vector<std::uint64_t> from_image;
+    const std::vector<std::uint64_t>* member_keys = &index.keys;
+    if (!index.staged && index.has_image)
+        index.image_keys(from_image), member_keys = &from_image;
+    bits.assign((member_keys->size() + 31) / 32 + 1, 0);
+    for (std::size_t slot = 0; slot < member_keys->size(); ++slot)
+        if ((*member_keys)[slot] != free_key_k && filter((*member_keys)[slot], filter_state))
+            bits[slot >> 5] |= 1u << (slot & 31);
+}
+
+/// Brings the device index up to date and wraps what `make` builds over it. `make` gets the snapshot (never null).
+template <typename make_at> usearch_filter_t make_filter(usearch_index_t handle, usearch_error_t* error, make_at&& make) {
+    index_t& index = *as_index(handle);
+    return guarded(error, usearch_filter_t(nullptr), [&]() -> usearch_filter_t {
+        unique_lock_t lock(index.mutex);
+        snapshot_t* device_index = nullptr;
+        if (const char* e = index.ready(&device_index))
+            return fail(error, e), nullptr;
+        std::unique_ptr<made_filter_t> made(new made_filter_t());
+        made->index = &index;
+        made->version = index.version;
+        if (device_index)
+            if (const char* e = make(index, *device_index, made->bitmap))
+                return fail(error, e), nullptr;
+        return made.release();
+    });
+}
+
 
 /// An index without nodes still serializes to its headers (index_dense.hpp:995-1062 with zero rows).
 void write_empty_image(const index_t& index, std::uint8_t* p) {
@@ -715,6 +767,7 @@ void usearch_add(usearch_index_t handle, usearch_key_t key, void const* vector, 
         if (!cast_vector(kind, index.scalar, static_cast<const std::uint8_t*>(vector), index.dimensions, target))
             std::memcpy(target, vector, bpv);
         index.keys.push_back(key);
+        ++index.version;
         if (index.lookup_valid)
             index.lookup.emplace(key, (std::uint32_t)slot);
         // the device index, if there is one, stays: the next search links the members added since (builder_t::extend)
@@ -744,7 +797,7 @@ static size_t search_shared(index_t& index, void const* queries, scalar_kind_t k
                             usearch_distance_t* distances, std::size_t distances_stride, std::size_t* counts,
                             std::size_t* visited_total, std::size_t* computed_total,
                             int (*filter)(usearch_key_t key, void* filter_state), void* filter_state,
-                            usearch_error_t* error) {
+                            usearch_error_t* error, const made_filter_t* made = nullptr) {
     if (!queries_count || !count)
         return 0;
     std::size_t result = 0;
@@ -768,25 +821,27 @@ static size_t search_shared(index_t& index, void const* queries, scalar_kind_t k
                     if (!out_distances)
                         spare_distances.resize(queries_count * count), out_distances = spare_distances.data();
                     std::vector<std::uint32_t> bits;
-                    if (filter) {
+                    search_extras_t extras;
+                    if (made) {
+                        // the predicate is already a bitmap in HBM (usearch_filter_from_*): nothing per member happens here
+                        if (made->index != &index || made->version != index.version)
+                            return fail(error, "The index changed since the filter was made");
+                        if (made->bitmap)
+                            extras.allow_bits = made->bitmap->bits();
+                    } else if (filter) {
                         // The callback is a host function: run it once per member and hand the device one bit per slot. The
                         // traversal then applies it where the reference does (index.hpp:4200-4205, 4236-4240), so results are
-                        // the reference's as long as the predicate is a pure function of the key.
-                        std::vector<std::uint64_t> from_image;
-                        const std::vector<std::uint64_t>* member_keys = &index.keys;
-                        if (!index.staged && index.has_image)
-                            index.image_keys(from_image), member_keys = &from_image;
-                        bits.assign((member_keys->size() + 31) / 32 + 1, 0);
-                        for (std::size_t slot = 0; slot < member_keys->size(); ++slot)
-                            if ((*member_keys)[slot] != free_key_k && filter((*member_keys)[slot], filter_state))
-                                bits[slot >> 5] |= 1u << (slot & 31);
+                        // the reference's as long as the predicate is a pure function of the key. O(members) callbacks PER
+                        // CALL — the reference makes a few thousand; callers that search more than once under one predicate
+                        // make a `usearch_filter_t` instead.
+                        callback_bits(index, filter, filter_state, bits);
                     }
                     if (!device_index) { // nothing indexed yet: index.hpp:3034-3037
                         pad_results(reinterpret_cast<usearch_key_t*>(out_keys), out_distances, queries_count * count);
                     } else if (const char* e = device_index->search_host(
                                    queries, kind, queries_count, queries_stride, count, index.expansion_search, out_keys,
                                    out_distances, found.data(), visited.data(), computed.data(), search_tuning_t{}, nullptr,
-                                   filter ? bits.data() : nullptr)) {
+                                   filter && !made ? bits.data() : nullptr, made ? &extras : nullptr)) {
                         return fail(error, e);
                     }
                     std::size_t total_visited = 0, total_computed = 0;
@@ -961,6 +1016,7 @@ size_t usearch_remove(usearch_index_t handle, usearch_key_t key, usearch_error_t
         for (auto it = range.first; it != range.second; ++it, ++removed) {
             // a tombstone: the member keeps routing, stops matching (index_dense.hpp:1479-1511)
             index.keys[it->second] = free_key_k;
+            ++index.version;
             if (index.builder && it->second < index.builder->size()) // in place on the device too: nothing is relinked
                 if (const char* e = index.builder->set_key(it->second, free_key_k))
                     fail(error, e);
@@ -992,6 +1048,7 @@ size_t usearch_rename(usearch_index_t handle, usearch_key_t from, usearch_key_t 
         index.lookup.erase(from);
         for (std::uint32_t slot : slots) {
             index.keys[slot] = to;
+            ++index.version;
             index.lookup.emplace(to, slot);
             if (index.builder && slot < index.builder->size()) // keys live next to the graph in HBM: renamed in place
                 if (const char* e = index.builder->set_key(slot, to))
@@ -1040,9 +1097,10 @@ void usearch_clear(usearch_index_t handle, usearch_error_t* error) {
     });
 }
 
-void usearch_search_exact_many(usearch_index_t handle, void const* queries, usearch_scalar_kind_t query_kind, size_t queries_count,
-                               size_t queries_stride, size_t count, usearch_key_t* keys, size_t keys_stride,
-                               usearch_distance_t* distances, size_t distances_stride, size_t* counts, usearch_error_t* error) {
+static void search_exact_many(usearch_index_t handle, const made_filter_t* made, void const* queries,
+                              usearch_scalar_kind_t query_kind, size_t queries_count, size_t queries_stride, size_t count,
+                              usearch_key_t* keys, size_t keys_stride, usearch_distance_t* distances, size_t distances_stride,
+                              size_t* counts, usearch_error_t* error) {
     index_t& index = *as_index(handle);
     guarded(error, [&] {
         const scalar_kind_t kind = scalar_from_c(query_kind);
@@ -1052,14 +1110,18 @@ void usearch_search_exact_many(usearch_index_t handle, void const* queries, usea
             return;
         unique_lock_t lock(index.mutex);
         snapshot_t* device_index = nullptr;
+        const std::uint64_t version_before = index.version;
         if (const char* e = index.ready(&device_index))
             return fail(error, e);
+        if (made && (made->index != &index || made->version != version_before || made->version != index.version))
+            return fail(error, "The index changed since the filter was made");
         std::vector<std::uint64_t> dense_keys(queries_count * count), found(queries_count, 0);
         std::vector<float> dense_distances(queries_count * count);
         if (!device_index) // nothing indexed yet
             pad_results(reinterpret_cast<usearch_key_t*>(dense_keys.data()), dense_distances.data(), queries_count * count);
         else if (const char* e = device_index->exact_host(queries, kind, queries_count, queries_stride, count, dense_keys.data(),
-                                                          dense_distances.data(), found.data(), nullptr))
+                                                          dense_distances.data(), found.data(), nullptr, false,
+                                                          made && made->bitmap ? made->bitmap->bits() : nullptr))
             return fail(error, e);
         for (std::size_t q = 0; q < queries_count; ++q) {
             if (keys)
@@ -1071,6 +1133,71 @@ void usearch_search_exact_many(usearch_index_t handle, void const* queries, usea
                 counts[q] = (std::size_t)found[q];
         }
     });
+}
+
+void usearch_search_exact_many(usearch_index_t handle, void const* queries, usearch_scalar_kind_t query_kind, size_t queries_count,
+                               size_t queries_stride, size_t count, usearch_key_t* keys, size_t keys_stride,
+                               usearch_distance_t* distances, size_t distances_stride, size_t* counts, usearch_error_t* error) {
+    search_exact_many(handle, nullptr, queries, query_kind, queries_count, queries_stride, count, keys, keys_stride, distances,
+                      distances_stride, counts, error);
+}
+
+// ---- filters: a predicate made once, in HBM, for any number of searches (include/usearch_c_dropin.h)
+
+usearch_filter_t usearch_filter_from_key_range(usearch_index_t handle, usearch_key_t first_key, usearch_key_t last_key,
+                                               usearch_error_t* error) {
+    return make_filter(handle, error, [&](index_t&, snapshot_t& device_index, std::unique_ptr<filter_t>& out) {
+        return filter_t::from_key_range(device_index, first_key, last_key, out);
+    });
+}
+
+usearch_filter_t usearch_filter_from_keys(usearch_index_t handle, usearch_key_t const* keys, size_t keys_count, bool allow,
+                                          usearch_error_t* error) {
+    return make_filter(handle, error, [&](index_t&, snapshot_t& device_index, std::unique_ptr<filter_t>& out) {
+        return filter_t::from_keys(device_index, reinterpret_cast<const std::uint64_t*>(keys), keys_count, allow, out);
+    });
+}
+
+usearch_filter_t usearch_filter_from_callback(usearch_index_t handle, int (*filter)(usearch_key_t key, void* filter_state),
+                                              void* filter_state, usearch_error_t* error) {
+    if (!filter)
+        return fail(error, "No predicate given"), nullptr;
+    return make_filter(handle, error, [&](index_t& index, snapshot_t& device_index, std::unique_ptr<filter_t>& out) {
+        std::vector<std::uint32_t> bits;
+        callback_bits(index, filter, filter_state, bits);
+        return filter_t::from_bits(device_index, bits.data(), bits.size(), out);
+    });
+}
+
+size_t usearch_filter_allowed(usearch_filter_t filter, usearch_error_t*) {
+    const made_filter_t* made = static_cast<const made_filter_t*>(filter);
+    return made && made->bitmap ? (std::size_t)made->bitmap->allowed() : 0;
+}
+
+void usearch_filter_free(usearch_filter_t filter, usearch_error_t*) { delete static_cast<made_filter_t*>(filter); }
+
+void usearch_filtered_search_many(usearch_index_t handle, usearch_filter_t filter, void const* queries,
+                                  usearch_scalar_kind_t query_kind, size_t queries_count, size_t queries_stride, size_t count,
+                                  usearch_key_t* keys, size_t keys_stride, usearch_distance_t* distances, size_t distances_stride,
+                                  size_t* counts, size_t* visited_members, size_t* computed_distances, usearch_error_t* error) {
+    index_t& index = *as_index(handle);
+    const scalar_kind_t kind = scalar_from_c(query_kind);
+    if (kind == scalar_unknown_k)
+        return fail(error, "Unknown scalar kind!");
+    if (!filter)
+        return fail(error, "No filter given");
+    search_shared(index, queries, kind, queries_count, queries_stride, count, keys, keys_stride, distances, distances_stride,
+                  counts, visited_members, computed_distances, nullptr, nullptr, error, static_cast<const made_filter_t*>(filter));
+}
+
+void usearch_filtered_search_exact_many(usearch_index_t handle, usearch_filter_t filter, void const* queries,
+                                        usearch_scalar_kind_t query_kind, size_t queries_count, size_t queries_stride, size_t count,
+                                        usearch_key_t* keys, size_t keys_stride, usearch_distance_t* distances,
+                                        size_t distances_stride, size_t* counts, usearch_error_t* error) {
+    if (!filter)
+        return fail(error, "No filter given");
+    search_exact_many(handle, static_cast<const made_filter_t*>(filter), queries, query_kind, queries_count, queries_stride, count,
+                      keys, keys_stride, distances, distances_stride, counts, error);
 }
 
 size_t usearch_threads_search(usearch_index_t handle, usearch_error_t*) { return as_index(handle)->threads_search; }
@@ -1093,7 +1220,7 @@ void usearch_gpu_release(usearch_index_t handle, usearch_error_t*) {
 
 usearch_amd_c_api_t const* usearch_amd_c_api(void) {
     static const usearch_amd_c_api_t table = {
-        44,
+        51,
         &usearch_version, &usearch_init, &usearch_free, &usearch_memory_usage, &usearch_hardware_acceleration,
         &usearch_serialized_length, &usearch_save, &usearch_load, &usearch_view, &usearch_metadata, &usearch_save_buffer,
         &usearch_load_buffer, &usearch_view_buffer, &usearch_metadata_buffer, &usearch_size, &usearch_capacity,
@@ -1103,6 +1230,8 @@ usearch_amd_c_api_t const* usearch_amd_c_api(void) {
         &usearch_count, &usearch_search, &usearch_filtered_search, &usearch_get, &usearch_remove, &usearch_rename,
         &usearch_distance, &usearch_exact_search, &usearch_clear, &usearch_search_many, &usearch_cluster_many,
         &usearch_search_exact_many, &usearch_threads_search, &usearch_gpu_sync, &usearch_gpu_release,
+        &usearch_filter_from_key_range, &usearch_filter_from_keys, &usearch_filter_from_callback, &usearch_filter_allowed,
+        &usearch_filter_free, &usearch_filtered_search_many, &usearch_filtered_search_exact_many,
     };
     return &table;
 }

@@ -17,13 +17,6 @@
 #include "casts.hpp"
 #include "host_util.hpp"
 #include "kernels.hpp"
-#include "pair_kernels.hpp"
-
-/// Which short-row walk plain b1 / i8 searches take when nobody says: 0 = one query per wave (kernels.hpp), 1 / 2 = two queries
-/// per wave with the visited set in LDS / in a global slab (pair_kernels.hpp). USEARCH_AMD_PAIR overrides at run time.
-#ifndef USEARCH_AMD_PAIR_DEFAULT
-#define USEARCH_AMD_PAIR_DEFAULT 0
-#endif
 
 namespace usearch_amd {
 
@@ -137,7 +130,7 @@ const char* workspace_t::reserve(std::size_t queries_wanted, std::size_t scratch
             (void)hipFree(d_scratch);
         d_scratch = nullptr;
         scratch_bytes = 0;
-        UA_HIP(hipMalloc((void**)&d_scratch, scratch_wanted)); // big blocks for chip-filling launches are drawn by run_ladder
+        UA_HIP(block_malloc((void**)&d_scratch, scratch_wanted)); // big blocks for chip-filling launches are drawn by run_ladder
         scratch_bytes = scratch_wanted;
     }
     return nullptr;
@@ -730,8 +723,14 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
     call.query_lds = query_lds;
     const std::uint32_t lds_budget = (std::uint32_t)env_size("USEARCH_AMD_LDS_BUDGET", 160 * 1024);
     std::uint32_t hash_cap = tuning.hash_cap ? tuning.hash_cap : (std::uint32_t)env_size("USEARCH_AMD_HASH_CAP", 0);
-    if (!hash_cap)
-        hash_cap = std::max<std::uint32_t>(1024, (ef * 30 + 1600) / 3 * 4); // entries expected ÷ the 75 % load limit
+    if (!hash_cap) {
+        // entries expected ÷ the load the set is sized for: 75 % (the kernel's limit) for short rows, whose slabs must stay
+        // cache-resident (profiles/r02_visited_set.log); 50 % for rows of ≥ 128 bytes — every probe round is a two-microsecond trip
+        // to the memory side for the whole wave, and the headline batch runs 1.9 % faster with 65 536 cells than with 32 768
+        // (46.2 against 47.1 ms on fresh blocks, profiles/r04_placement/scratch_footprint.log); USEARCH_AMD_HASH_LOAD_PCT overrides
+        const std::uint32_t load_pct = (std::uint32_t)std::min<std::size_t>(75, std::max<std::size_t>(10, env_size("USEARCH_AMD_HASH_LOAD_PCT", lanes_ >= 8 ? 50 : 75)));
+        hash_cap = std::max<std::uint32_t>(1024, (std::uint32_t)((std::uint64_t)(ef * 30 + 1600) * 100 / load_pct));
+    }
     hash_cap = pow2_ceil(hash_cap);
     std::uint32_t next_cap = tuning.next_cap ? tuning.next_cap : (std::uint32_t)env_size("USEARCH_AMD_NEXT_CAP", 0);
     if (!next_cap)
@@ -741,50 +740,8 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
     next_cap = (std::uint32_t)std::min<std::uint64_t>(next_cap, view_.size + 64);
 
     std::uint32_t mode_request = tuning.mode ? tuning.mode : (std::uint32_t)env_size("USEARCH_AMD_MODE", 0);
-    // ---- the short-row walk, two queries per wave (pair_kernels.hpp): integer-valued pairs, rows of ≤ 128 bytes, lists of
-    //      ≤ 32 neighbours, plain searches (no predicate, no tombstones, level 0) at expansions its register `top` holds
-    const std::uint32_t used_chunks = (view_.bytes_per_vector + 15) / 16;
-    const bool pair_possible = (scalar_ == scalar_b1x8_k || scalar_ == scalar_i8_k) && !view_.has_tombstones &&
-                               !(extras && (extras->allow_bits || extras->beam_level || extras->descent_only)) &&
-                               ef <= pair_max_expansion_k && view_.m0 <= pair_max_list_k && view_.m <= pair_max_list_k &&
-                               used_chunks <= pair_max_chunks_k && !tuning.top_in_memory && !env_size("USEARCH_AMD_TOP_IN_MEMORY", 0);
-    std::uint32_t pair = 0;
-    if (mode_request == 4) {
-        if (!pair_possible)
-            return "The two-queries-per-wave walk does not apply to this search (pair, row length, list length, expansion or filter)";
-        pair = 1;
-        mode_request = 0;
-    } else if (mode_request == 0 && pair_possible) {
-        pair = env_size("USEARCH_AMD_PAIR", USEARCH_AMD_PAIR_DEFAULT) ? 1u : 0u;
-    }
-    if (pair) {
-        // LDS is what limits the queries in flight of that kernel (two visited sets and two frontiers per wave): as many waves
-        // per compute unit as still leave each half a visited set for what its traversal is expected to reach (1 700 + 9·ef
-        // members under the kernel's 87.5 % load limit: measured maxima 2 225 at ef 64 on 20M × 128 b1, 2 281 at ef 80 on
-        // 20M × 96 i8), every byte of the wave's share handed to the set. Outliers go through the retry ladder.
-        if (!tuning.next_cap && !env_size("USEARCH_AMD_NEXT_CAP", 0))
-            next_cap = (std::uint32_t)std::min<std::uint64_t>(ef * 5 + 64, view_.size + 64);
-        if (!tuning.hash_cap && !env_size("USEARCH_AMD_HASH_CAP", 0)) {
-            const std::uint32_t need = (std::uint32_t)((1700ull + 9ull * ef) * 8 / 7);
-            const std::uint32_t fixed = pair_wave_lds_bytes(next_cap, 0);
-            std::uint32_t chosen = 0;
-            for (std::uint32_t waves = std::min<std::uint32_t>(8, tuning.waves_per_cu ? tuning.waves_per_cu : 8); waves >= 1 && !chosen; --waves) {
-                const std::uint32_t share = lds_budget / waves / 1280 * 1280; // LDS is handed out in granules
-                if (share <= fixed)
-                    continue;
-                const std::uint32_t cells = (share - fixed) / 8 / pair_hash_granule_k * pair_hash_granule_k;
-                if (cells >= need)
-                    chosen = cells;
-            }
-            if (!chosen)
-                pair = 0; // does not fit LDS at all: the one-query kernel with its global slab
-            else
-                hash_cap = std::min<std::uint32_t>(chosen, 4 * need);
-        } else {
-            hash_cap = std::max<std::uint32_t>(pair_hash_granule_k, hash_cap / pair_hash_granule_k * pair_hash_granule_k);
-        }
-    }
-    call.pair = pair;
+    if (mode_request > 3)
+        return "Unknown scratch mode";
     // `top` lives in registers (1 / 4 / 8 / 16 entries per lane) while the expansion allows it
     const bool top_in_memory = tuning.top_in_memory || env_size("USEARCH_AMD_TOP_IN_MEMORY", 0) != 0;
     const bool two_cells = lanes_ <= 2 && ef <= 128 && !env_size("USEARCH_AMD_NO_TWO_CELLS", 0); // short rows: see kernel_waves()
@@ -829,7 +786,7 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
     }
     // A batch that cannot give every CU two queries to walk (a `usearch_search` caller's single query above all) over long rows: four
     // waves per query — the hop's rows split four ways, everything else as ever (kernels.hpp team_search_kernel)
-    const bool team = every_build && chunks_per_lane >= 8 && !variant_request && !pair && mode_request != 3 &&
+    const bool team = every_build && chunks_per_lane >= 8 && !variant_request && mode_request != 3 &&
                       count <= 2ull * compute_units_ && !(extras && extras->descent_only) && !env_size("USEARCH_AMD_NO_TEAM", 0) &&
                       !tuning.waves_per_cu;
     if (team)
@@ -837,7 +794,7 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
     const std::uint32_t variant_waves_per_cu = 4u * (std::uint32_t)kernel_waves(variant, (int)entries_per_lane, frontier, (int)lanes_);
     const std::uint32_t waves_cap = tuning.waves_per_cu ? tuning.waves_per_cu
                                                         : (std::uint32_t)env_size("USEARCH_AMD_WAVES_PER_CU", 32);
-    call.waves_cap = std::min(waves_cap, pair ? 4u * USEARCH_AMD_PAIR_WAVES : variant_waves_per_cu);
+    call.waves_cap = std::min(waves_cap, variant_waves_per_cu);
 
     auto lds_bytes_for = [&](int mode, std::uint32_t cap_next, std::uint32_t cap_hash) -> std::uint64_t {
         if (mode == scratch_global_k)
@@ -972,35 +929,6 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
     };
 
     const std::uint32_t pending = call.have_todo ? (std::uint32_t)call.todo.size() : (std::uint32_t)call.count;
-    if (call.pair) { // first rung of a short-row search: two queries per wave
-        const std::uint64_t lds_bytes = pair_wave_lds_bytes(call.next_cap, call.hash_cap);
-        if (lds_bytes > lds_budget)
-            return "The two-queries-per-wave walk does not fit LDS with these scratch sizes";
-        const std::uint64_t granule = (lds_bytes + 1279) / 1280 * 1280;
-        const std::uint32_t waves = (std::uint32_t)std::max<std::uint64_t>(1, std::min<std::uint64_t>(call.waves_cap, lds_budget / granule));
-        const std::uint32_t grid = (std::uint32_t)std::min<std::uint64_t>((pending + 1) / 2, (std::uint64_t)waves * compute_units_);
-        if (const char* e = ws.reserve(call.count, 0))
-            return e;
-        args.status = ws.d_status, args.peaks = ws.d_peaks;
-        args.hash_cap = call.hash_cap;
-        args.next_cap = call.next_cap;
-        args.todo = call.have_todo ? ws.d_todo : nullptr;
-        args.count = pending;
-        args.scratch = nullptr;
-        args.scratch_stride = 0;
-        args.wave_clock = nullptr;
-        params.pair = 1;
-        params.pair_cells = (std::uint32_t)pair_cells_for(ef);
-        params.mode = 3; // reported as 4 (search_stats_t::mode)
-        params.entries_per_lane = params.pair_cells;
-        params.grid = grid;
-        params.lds_bytes = (std::uint32_t)lds_bytes;
-        if (const char* e = timed_launch())
-            return e;
-        ++call.passes;
-        return nullptr;
-    }
-    params.pair = 0;
     if (call.mode != scratch_global_k) {
         if (lds_bytes_for(call.mode, call.next_cap, call.hash_cap) > lds_budget) {
             if (call.mode == scratch_lds_k)
@@ -1082,7 +1010,7 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
                 std::fprintf(stderr, " ms\n");
             }
             for (; drawn < scratch_draws && !failure; ++drawn) {
-                if (hipMalloc(&candidates[drawn], slab * grid) != hipSuccess) {
+                if (block_malloc(&candidates[drawn], slab * grid) != hipSuccess) {
                     (void)hipGetLastError();
                     candidates[drawn] = nullptr;
                     break;
@@ -1232,8 +1160,6 @@ const char* snapshot_t::search_finish(search_call_t& call, search_stats_t* stats
             break;
         if (rung == 0) {
             call.stats.retried_lds = (std::uint32_t)call.todo.size();
-            if (call.pair) // the outgrown queries go to the one-query kernel, which wants a power of two
-                call.pair = 0, call.hash_cap = pow2_ceil(call.hash_cap);
             call.mode = scratch_hash_k;
             call.hash_cap = std::min<std::uint32_t>(call.hash_cap * 4, pow2_ceil((std::uint32_t)std::min<std::uint64_t>(view_.size * 2 + 128, 1u << 30)));
             if (call.next_cap) {
@@ -1252,20 +1178,7 @@ const char* snapshot_t::search_finish(search_call_t& call, search_stats_t* stats
             return e;
     }
 
-    if (call.want_phases && first_mode == 3 && call.params.pair_cells) { // the two-queries-per-wave walk keeps its own clock (pair_kernels.hpp)
-        unsigned long long ticks[16] = {0};
-        UA_HIP(hipMemcpy(ticks, call.args.phases, 128, hipMemcpyDeviceToHost));
-        double total = 0;
-        for (int i = 0; i < 7; ++i)
-            total += (double)ticks[i];
-        const double steps = (double)std::max<unsigned long long>(ticks[7], 1);
-        std::fprintf(stderr, "[usearch_amd] pair phases ef=%u grid=%u: dump+ticket %.1f%% list %.1f%% visited %.1f%% rows+pop %.1f%% "
-                             "distances+min %.1f%% next-root+descent %.1f%% commit %.1f%% (%.0f ticks per step); steps %llu, both halves in the "
-                             "beam %.1f%%, per step: commits %.2f pop levels %.2f extra probe rounds %.2f\n",
-                     call.ef, first_grid, 100 * ticks[0] / total, 100 * ticks[1] / total, 100 * ticks[2] / total,
-                     100 * ticks[3] / total, 100 * ticks[4] / total, 100 * ticks[5] / total, 100 * ticks[6] / total,
-                     total / steps, ticks[7], 100.0 * ticks[8] / steps, ticks[9] / steps, ticks[10] / steps, ticks[11] / steps);
-    } else if (call.want_phases) {
+    if (call.want_phases) {
         unsigned long long ticks[16] = {0};
         UA_HIP(hipMemcpy(ticks, call.args.phases, 128, hipMemcpyDeviceToHost));
         double total = 0;
@@ -1480,7 +1393,8 @@ static hipError_t launch_exact(metric_kind_t metric, scalar_kind_t scalar, const
 const char* exact_search_device(metric_kind_t metric, scalar_kind_t scalar, std::uint32_t lanes,
                                 const snapshot_view_t& view, const void* queries, std::size_t count,
                                 std::size_t stride_bytes, std::size_t wanted, bool map_keys, std::uint64_t* keys,
-                                float* distances, std::uint64_t* counts, hipStream_t stream, float* kernel_ms) {
+                                float* distances, std::uint64_t* counts, hipStream_t stream, float* kernel_ms,
+                                const std::uint32_t* allow_bits) {
     if (kernel_ms)
         *kernel_ms = 0.f;
     if (!count || !wanted)
@@ -1532,6 +1446,7 @@ const char* exact_search_device(metric_kind_t metric, scalar_kind_t scalar, std:
         p.partitions = (std::uint32_t)partitions;
         p.rows_per_partition = rows_per_partition;
         p.map_keys = map_keys ? 1u : 0u;
+        p.allow_bits = allow_bits;
         p.out_distances = partial_distances;
         p.out_keys = partial_keys;
         p.out_counts = partial_counts;
@@ -1558,7 +1473,7 @@ const char* exact_search_device(metric_kind_t metric, scalar_kind_t scalar, std:
 
 const char* snapshot_t::exact_device(const void* queries, std::size_t count, std::size_t stride_bytes,
                                      std::size_t wanted, std::uint64_t* keys, float* distances, std::uint64_t* counts,
-                                     hipStream_t stream, float* kernel_ms, bool tiled) {
+                                     hipStream_t stream, float* kernel_ms, bool tiled, const std::uint32_t* allow_bits) {
     if (!count || !wanted)
         return nullptr;
     UA_HIP(hipSetDevice(device_));
@@ -1570,14 +1485,14 @@ const char* snapshot_t::exact_device(const void* queries, std::size_t count, std
     }
     if (tiled)
         return exact_search_tiled_device(kernel_metric(metric_), scalar_, view_, queries, count, stride_bytes, wanted, true, keys,
-                                         distances, counts, stream, kernel_ms);
+                                         distances, counts, stream, kernel_ms, allow_bits);
     return exact_search_device(metric_, scalar_, lanes_, view_, queries, count, stride_bytes, wanted, true, keys,
-                               distances, counts, stream, kernel_ms);
+                               distances, counts, stream, kernel_ms, allow_bits);
 }
 
 const char* snapshot_t::exact_host(const void* queries, scalar_kind_t query_kind, std::size_t count,
                                    std::size_t stride_bytes, std::size_t wanted, std::uint64_t* keys, float* distances,
-                                   std::uint64_t* counts, float* kernel_ms, bool tiled) {
+                                   std::uint64_t* counts, float* kernel_ms, bool tiled, const std::uint32_t* allow_bits) {
     if (!count || !wanted)
         return nullptr;
     const std::size_t bpv = view_.bytes_per_vector, dims = view_.dimensions;
@@ -1605,10 +1520,10 @@ const char* snapshot_t::exact_host(const void* queries, scalar_kind_t query_kind
     UA_HIP(hipMemcpy(d_queries, dense.data(), bpv * count, hipMemcpyHostToDevice));
     if (tiled) {
         if (const char* e = exact_search_tiled_device(kernel_metric(metric_), scalar_, view_, d_queries, count, bpv, wanted,
-                                                      true, d_keys, d_distances, d_counts, ws.stream, kernel_ms))
+                                                      true, d_keys, d_distances, d_counts, ws.stream, kernel_ms, allow_bits))
             return e;
     } else if (const char* e = exact_search_device(metric_, scalar_, lanes_, view_, d_queries, count, bpv, wanted, true, d_keys,
-                                                   d_distances, d_counts, ws.stream, kernel_ms)) {
+                                                   d_distances, d_counts, ws.stream, kernel_ms, allow_bits)) {
         return e;
     }
     if (keys)

@@ -26,8 +26,7 @@ struct search_tuning_t {
     std::uint32_t hash_cap = 0;     ///< visited-set cells per query (power of two)
     std::uint32_t next_cap = 0;     ///< frontier capacity per query
     std::uint32_t variant = 0;      ///< 0 = auto, else 1 + kernel_variant_t (loads in flight per lane vs waves per SIMD)
-    std::uint32_t mode = 0;         ///< 0 = auto, 1 = visited set in LDS, 2 = visited set in a global hash, 3 = all-global fallback,
-                                    ///< 4 = the two-queries-per-wave short-row walk (pair_kernels.hpp; refused where it does not apply)
+    std::uint32_t mode = 0;         ///< 0 = auto, 1 = visited set in LDS, 2 = visited set in a global hash, 3 = all-global fallback
     std::uint32_t waves_per_cu = 0; ///< persistent waves per compute unit (0 = as many as LDS / registers admit)
     std::uint32_t top_in_memory = 0; ///< 1 = keep `top` in scratch memory even when it would fit registers
     std::uint32_t frontier = 0;     ///< 0 = auto, 1 = the reference's heap (its pop order among equal distances), 2 = the open
@@ -40,8 +39,7 @@ struct search_stats_t {
     std::uint32_t retried_lds = 0;       ///< queries rerun with the enlarged LDS scratch
     std::uint32_t retried_global = 0;    ///< queries rerun with the global-memory scratch
     float kernel_ms = 0.f;               ///< HIP-event time of the search launches of this call (when `timed`)
-    std::uint32_t mode = 0;              ///< scratch mode of the last launch (1 = LDS, 2 = global hash, 3 = all global; 4 = the
-                                         ///< two-queries-per-wave walk, visited set in LDS)
+    std::uint32_t mode = 0;              ///< scratch mode of the last launch (1 = LDS, 2 = global hash, 3 = all global)
     std::uint32_t grid = 0;              ///< persistent waves of the last launch
     std::uint32_t lds_bytes = 0;         ///< LDS per wave of the last launch
     std::uint32_t frontier = 0;          ///< 1 = heap, 2 = open cells of `top` (first launch)
@@ -73,8 +71,6 @@ struct launch_params_t {
     std::uint32_t grid;
     std::uint32_t lds_bytes;
     hipStream_t stream;
-    std::uint32_t pair = 0;       ///< 0 = one query per wave; 1 = two (pair_kernels.hpp)
-    std::uint32_t pair_cells = 0; ///< register cells of `top` per lane in that kernel (2 or 4)
     std::uint32_t team = 0;       ///< 1 = four waves per query (team_search_kernel): small batches over long rows
 };
 
@@ -156,7 +152,6 @@ class snapshot_t {
         std::size_t count = 0;
         std::uint32_t ef = 0, hash_cap = 0, next_cap = 0, query_lds = 0, entries_per_lane = 0, waves_cap = 0;
         int mode = 0;
-        std::uint32_t pair = 0; ///< 1 = the first rung runs the two-queries-per-wave walk
         bool timed = false, want_phases = false, want_clock = false, done = false, reran = false;
         bool keep_workspace = false; ///< search_finish leaves the workspace with the caller (who gives it back)
         float total_ms = 0.f;
@@ -229,15 +224,16 @@ class snapshot_t {
     const char* last_peaks(std::uint32_t* out, std::size_t queries);
 
     /// `search(…, exact = true)` for a batch (index_dense.hpp:767-772 with exact, index.hpp:3046-3049): device buffers,
-    /// queries in the storage kind.
+    /// queries in the storage kind. `allow_bits` (device, one bit per slot): the caller's predicate, which the brute-force scan
+    /// applies too (index.hpp:4260-4263).
     const char* exact_device(const void* queries, std::size_t count, std::size_t stride_bytes, std::size_t wanted,
                              std::uint64_t* keys, float* distances, std::uint64_t* counts, hipStream_t stream,
-                             float* kernel_ms, bool tiled = false);
+                             float* kernel_ms, bool tiled = false, const std::uint32_t* allow_bits = nullptr);
     /// Same with host buffers and any query scalar kind. `tiled`: the matrix-unit kernel where one exists for the pair
     /// (exact_tiled.hip; an error otherwise) instead of the bit-exact wave-per-query one.
     const char* exact_host(const void* queries, scalar_kind_t query_kind, std::size_t count, std::size_t stride_bytes,
                            std::size_t wanted, std::uint64_t* keys, float* distances, std::uint64_t* counts,
-                           float* kernel_ms, bool tiled = false);
+                           float* kernel_ms, bool tiled = false, const std::uint32_t* allow_bits = nullptr);
 
     /// out[q][j] = metric(query q, stored row slots[q][j]); host buffers, queries in storage kind.
     const char* distances_host(const void* queries, std::size_t count, std::size_t stride_bytes,
@@ -363,6 +359,7 @@ struct exact_params_t {
     std::uint32_t partitions;
     std::uint64_t rows_per_partition;
     std::uint32_t map_keys;
+    const std::uint32_t* allow_bits; ///< optional, device: one bit per slot, 0 = the caller's predicate rejects that member
     float* out_distances;      ///< [partitions][queries][wanted]
     std::uint64_t* out_keys;
     std::uint64_t* out_counts; ///< [partitions][queries]
@@ -376,7 +373,8 @@ struct exact_params_t {
 const char* exact_search_device(metric_kind_t metric, scalar_kind_t scalar, std::uint32_t lanes,
                                 const snapshot_view_t& view, const void* queries, std::size_t count,
                                 std::size_t stride_bytes, std::size_t wanted, bool map_keys, std::uint64_t* keys,
-                                float* distances, std::uint64_t* counts, hipStream_t stream, float* kernel_ms);
+                                float* distances, std::uint64_t* counts, hipStream_t stream, float* kernel_ms,
+                                const std::uint32_t* allow_bits = nullptr);
 
 /// Is there a tiled (matrix-unit) exact-search kernel for this pair and result count? (exact_tiled.hip: cos / ip over f16 and
 /// bf16 — float tolerance — and cos / ip / l2sq over i8 — bit-identical to the wave-per-query kernel.)
@@ -387,7 +385,7 @@ bool exact_tiled_available(metric_kind_t metric, scalar_kind_t scalar, std::size
 const char* exact_search_tiled_device(metric_kind_t metric, scalar_kind_t scalar, const snapshot_view_t& view,
                                       const void* queries, std::size_t count, std::size_t stride_bytes, std::size_t wanted,
                                       bool map_keys, std::uint64_t* keys, float* distances, std::uint64_t* counts,
-                                      hipStream_t stream, float* kernel_ms);
+                                      hipStream_t stream, float* kernel_ms, const std::uint32_t* allow_bits = nullptr);
 
 /// Host-buffer exact search of a raw dataset — `usearch_exact_search` (c/usearch.h:467-474): keys are dataset offsets.
 const char* exact_search_dataset_host(metric_kind_t metric, scalar_kind_t scalar, std::size_t dimensions,

@@ -143,8 +143,9 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const snapshot_view_t 
                                                           std::uint64_t query_stride, std::uint32_t query_count,
                                                           std::uint32_t wanted, std::uint64_t rows_per_partition,
                                                           const std::uint32_t* row_norms, const std::uint32_t* query_norms,
-                                                          std::uint32_t map_keys, float* out_distances,
-                                                          std::uint64_t* out_keys, std::uint64_t* out_counts) {
+                                                          std::uint32_t map_keys, const std::uint32_t* allow_bits,
+                                                          float* out_distances, std::uint64_t* out_keys,
+                                                          std::uint64_t* out_counts) {
     using accumulator_t = typename accumulator_gt<scalar_ak>::type;
     extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
     std::uint8_t* stage_q = lds;                                      // [64][pitch]
@@ -184,7 +185,10 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const snapshot_view_t 
             const std::uint64_t row = tile_row + thread;
             const bool inside = row < last_row;
             norms_r[thread] = inside ? row_norms[row] : 0u;
-            valid_r[thread] = inside && (!ix.has_tombstones || ix.keys[row] != free_key_k) ? 1u : 0u;
+            bool member = inside && (!ix.has_tombstones || ix.keys[row] != free_key_k);
+            if (allow_bits && member) // the caller's predicate, one bit per slot (index.hpp:4260-4263)
+                member = ((allow_bits[row >> 5] >> (row & 31)) & 1u) != 0;
+            valid_r[thread] = member ? 1u : 0u;
         }
         for (std::uint32_t chunk = 0; chunk < chunks; ++chunk) {
             // ---- stage 128 bytes of every query and of every row of the tile: 8 consecutive threads fetch one row's 128 bytes
@@ -314,7 +318,8 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const snapshot_view_t 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-//  The wide tile: 256 queries × 128 rows per workgroup of 8 waves, both operands double-buffered through LDS, register epilogue
+//  The wide tile: 256 queries × 128 rows per workgroup of 8 waves; both operands go global → LDS by LDS-DMA
+//  (`global_load_lds_dwordx4`, no staging registers, no `ds_write`) into two XOR-swizzled buffers; register epilogue
 // ---------------------------------------------------------------------------------------------------------------------
 
 constexpr int wide_queries_k = 256; ///< queries per workgroup: a row is read once per 256 queries
@@ -322,8 +327,8 @@ constexpr int wide_rows_k = 128;    ///< dataset rows per tile
 constexpr int wide_threads_k = 512; ///< 8 waves; wave w multiplies queries [32w, 32w + 32) with the tile's 128 rows
 constexpr int wide_wanted_k = 16;   ///< results per query this kernel keeps (its lists share LDS with two staging buffers)
 constexpr int wide_stage_rows_k = wide_queries_k + wide_rows_k;
-constexpr int wide_loads_k = wide_stage_rows_k * (chunk_bytes_k / 16) / wide_threads_k; ///< 16-byte loads per thread per chunk: 6
-constexpr std::uint32_t wide_stage_bytes_k = wide_stage_rows_k * pitch_k;
+constexpr int wide_loads_k = wide_stage_rows_k * (chunk_bytes_k / 16) / wide_threads_k; ///< LDS-DMA instructions per wave per chunk: 6
+constexpr std::uint32_t wide_stage_bytes_k = wide_stage_rows_k * chunk_bytes_k;         ///< a buffer: [384][128] bytes, no padding
 
 inline std::uint64_t wide_padded_stride(std::uint64_t bytes_per_vector) {
     return (bytes_per_vector + chunk_bytes_k - 1) / chunk_bytes_k * chunk_bytes_k;
@@ -332,15 +337,26 @@ constexpr std::uint32_t wide_lds_bytes() {
     return 2 * wide_stage_bytes_k + wide_queries_k * wide_wanted_k * 8 + wide_queries_k * 4 * 3 + 2 * wide_rows_k * 4;
 }
 
+/// Where the 16-byte piece `piece` of staged row `row` sits inside the row's 128 bytes. A `ds_read_b128` is served in groups of 16
+/// lanes — 16 different rows at one piece index — and rows 128 bytes apart fall on the same banks every second row; XOR-ing the
+/// piece index with bits 1…3 of the row spreads each group over all sixteen 16-byte bank slots (no conflict). The DMA writes lanes
+/// linearly, so the swizzle is applied to the SOURCE: lane i of a fill instruction fetches the piece that belongs in slot i.
+__device__ __forceinline__ std::uint32_t wide_swizzle(std::uint32_t row, std::uint32_t piece) { return piece ^ ((row >> 1) & 7u); }
+
+using global_bytes_t = const __attribute__((address_space(1))) void*;
+using lds_bytes_t = __attribute__((address_space(3))) void*;
+
 /**
  *  grid = 1-D. Workgroups are dealt to the 8 XCDs round-robin by their linear index; inside an XCD, 32 consecutive workgroups
  *  (one per CU) are 4 query tiles × 8 row partitions, so what the XCD's L2 holds at any time is 4 query tiles (1.5 MB for
  *  768-d f16) and the row tiles 8 partitions are streaming, each shared by 4 workgroups.
  *
- *  Per 128-byte chunk of the summation: 6 global loads per thread issued TWO chunks ahead into registers, 4 × (1 query
- *  fragment + 4 row fragments → 4 MFMAs) per wave out of the current LDS buffer, the chunk after next written to the other
- *  buffer, one barrier. The accumulators never visit LDS: a lane tests its 64 sums against the queries' current k-th best
- *  with a cheap conservative bound, and only the few that may enter a list (≈ k·ln(rows/k) per query over the whole scan,
+ *  Per 128-byte chunk of the summation: every wave issues 6 LDS-DMA fills (8 rows × 128 bytes each) of the NEXT chunk into the
+ *  other buffer, multiplies the current one — 4 × (1 query fragment + 4 row fragments → 4 MFMAs) — waits for its own fills and
+ *  meets the others at one barrier. Nothing is staged through registers and nothing is written to LDS by an instruction of the
+ *  wave. The accumulators never visit LDS: a lane tests its 64 sums against the queries' current k-th best with one multiply and
+ *  one compare per sum (cos: Σab·rsq(Σb²) against (1 − k-th best − 10⁻⁵)·√Σa², kept per query register), the wave ORs the
+ *  compares' masks on the scalar unit, and only the few sums that may enter a list (≈ k·ln(rows/k) per query over the whole scan,
  *  after the first tile) take the exact closing arithmetic and the ordered insert, one at a time, by the wave that owns the
  *  query's list. Same lists as the 64-query kernel: the best `wanted` under (distance ↑, slot ↓), whatever the order of arrival.
  */
@@ -350,18 +366,19 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                                                                     std::uint32_t wanted, std::uint64_t rows_per_partition,
                                                                     std::uint32_t query_tiles, std::uint32_t local_partitions,
                                                                     const std::uint32_t* row_norms, const std::uint32_t* query_norms,
-                                                                    std::uint32_t map_keys, float* out_distances,
-                                                                    std::uint64_t* out_keys, std::uint64_t* out_counts) {
+                                                                    std::uint32_t map_keys, const std::uint32_t* allow_bits,
+                                                                    float* out_distances, std::uint64_t* out_keys,
+                                                                    std::uint64_t* out_counts) {
     using accumulator_t = typename accumulator_gt<scalar_ak>::type;
     constexpr bool integers = scalar_ak == scalar_i8_k;
     using sum_t = typename std::conditional<integers, int, float>::type;
-    extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
+    extern __shared__ __attribute__((aligned(1024))) std::uint8_t lds[];
     float* list_d = reinterpret_cast<float*>(lds + 2 * wide_stage_bytes_k);                   // [256][16]
     std::uint32_t* list_s = reinterpret_cast<std::uint32_t*>(list_d + wide_queries_k * wide_wanted_k);
     std::uint32_t* top_n = list_s + wide_queries_k * wide_wanted_k;                              // [256]
     float* limit = reinterpret_cast<float*>(top_n + wide_queries_k);                            // [256] k-th best, +inf while filling
     std::uint32_t* norms_q = reinterpret_cast<std::uint32_t*>(limit + wide_queries_k);          // [256]
-    std::uint32_t* norms_r = norms_q + wide_queries_k; // [2][128] Σb² of the rows staged in either buffer
+    std::uint32_t* norms_r = norms_q + wide_queries_k; // [2][128] Σb² of the rows of the tile being multiplied / being fetched
 
     const std::uint32_t thread = threadIdx.x, wave = thread / 64, lane = thread % 64;
     // ---- which (query tile, partition) this workgroup is
@@ -388,66 +405,67 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
 
     // ---- per lane: the 16 queries its accumulator registers belong to (register r ↔ query 32·wave + (r&3) + 8(r>>2) + 4(lane>>5))
     std::uint32_t exists = 0;   // bit r: that query is inside the batch
-    float query_scale[16];      // cos: 1/√Σa² (the conservative bound only; the exact arithmetic reads norms_q)
+    float query_root[16];       // cos: √Σa² (NaN for a zero norm = "always take the exact path"); the fast test's scale
     std::uint32_t query_norm[16];
     float bound[16];            // copy of limit[] for those queries, refreshed after this wave changed a list
+    float threshold[16];        // cos: (1 − bound − 10⁻⁵)·√Σa², what Σab·rsq(Σb²) has to reach; +inf for a query outside the batch
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const std::uint32_t i = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        exists |= (first_query + i < query_count ? 1u : 0u) << r;
+        const bool inside = first_query + i < query_count;
+        exists |= (inside ? 1u : 0u) << r;
         query_norm[r] = norms_q[i];
-        query_scale[r] = metric_ak == metric_cos_k ? bound_scale<integers>(query_norm[r]) : 1.f;
+        const float a2 = integers ? (float)(int)query_norm[r] : __builtin_bit_cast(float, query_norm[r]);
+        query_root[r] = a2 > 1e-30f ? __builtin_sqrtf(a2) : __builtin_nanf("");
         bound[r] = __builtin_inff();
+        threshold[r] = inside ? -__builtin_inff() : __builtin_inff();
     }
+    auto refresh_thresholds = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            bound[r] = limit[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+            if constexpr (metric_ak == metric_cos_k) // −inf while the list is filling (bound = +inf): everything may enter
+                threshold[r] = (exists >> r) & 1u ? (1.f - (bound[r] + 1e-5f)) * query_root[r] : __builtin_inff();
+        }
+    };
 
-    // ---- staging: 8 consecutive threads move one row's 128 bytes; thread t owns rows t/8 + 64·pass (4 passes of queries, 2 of
-    //      rows) and, with them, one row's Σb². No branch anywhere (addresses are clamped into the arrays, what lies outside is
-    //      replaced by zeros afterwards), so the loads of two chunks stay in flight across the barriers: the compiler counts them.
-    const std::uint32_t segment = thread % 8, stage_row = thread / 8;
-    const std::uint8_t* my_queries = padded_queries + (std::uint64_t)(first_query + stage_row) * padded_stride + segment * 16;
-    struct staged_t { // named members, no array: the chunk in flight must live in registers, not in a private-memory array
-        uint4 q0, q1, q2, q3, r0, r1;
-        std::uint32_t norm;
-    };
-    static_assert(wide_loads_k == 6 && wide_queries_k == 256 && wide_rows_k == 128, "staged_t is written out for this shape");
+    // ---- LDS-DMA fills. A fill instruction of a wave writes 1 024 consecutive bytes = 8 staged rows; wave w fills rows
+    //      64·pass + 8w … + 8 (4 passes of queries, 2 of dataset rows); lane i brings the piece that belongs in slot i of "its" row
+    //      (wide_swizzle). No branch on the data path: addresses are clamped into the arrays — a row past the partition's end
+    //      re-reads the last row (the epilogue drops it: `live`), bytes past a row's last 16-byte chunk re-read that chunk and meet
+    //      the zeros the padded queries hold there.
+    const std::uint32_t fill_row = wave * 8 + lane / 8; // + 64·pass
     std::uint32_t fetch_tile = 0, fetch_chunk = 0;
-    // Nothing is computed on a loaded value before it is written to LDS (a select here would make the wave wait for the load
-    // right away): a row past the partition's end re-reads the last row (the epilogue drops it: `live`), bytes past a row's
-    // last 16-byte chunk re-read that chunk and meet the zeros the padded queries hold there.
-    auto fetch_row = [&](std::uint64_t row, std::uint32_t byte) -> uint4 {
-        const std::uint32_t byte_inside = byte < row_bytes ? byte : row_bytes - 16; // stored rows: 16-byte aligned, zero padded to 16
-        const std::uint64_t row_inside = row < last_row ? row : last_row - 1;
-        return *reinterpret_cast<const uint4*>(ix.vectors + row_inside * ix.row_stride + byte_inside);
-    };
-    auto fetch = [&]() -> staged_t {
-        staged_t regs;
-        const std::uint32_t byte = fetch_chunk * chunk_bytes_k + segment * 16;
+    auto issue_fills = [&](std::uint32_t buffer) {
+        std::uint8_t* stage = lds + buffer * wide_stage_bytes_k;
         const std::uint64_t tile_row = first_row + (std::uint64_t)fetch_tile * wide_rows_k;
-        const std::uint8_t* source = my_queries + fetch_chunk * chunk_bytes_k; // the padded copy: every chunk of every query of the tile exists
-        regs.q0 = *reinterpret_cast<const uint4*>(source);
-        regs.q1 = *reinterpret_cast<const uint4*>(source + 64 * padded_stride);
-        regs.q2 = *reinterpret_cast<const uint4*>(source + 128 * padded_stride);
-        regs.q3 = *reinterpret_cast<const uint4*>(source + 192 * padded_stride);
-        regs.r0 = fetch_row(tile_row + stage_row, byte);
-        regs.r1 = fetch_row(tile_row + 64 + stage_row, byte);
-        {
-            const std::uint64_t row = tile_row + (thread % wide_rows_k);
-            regs.norm = row_norms[row < last_row ? row : last_row - 1];
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const std::uint32_t row = pass * 64 + fill_row;
+            const std::uint32_t piece = wide_swizzle(row, lane & 7u);
+            const std::uint8_t* source = padded_queries + (std::uint64_t)(first_query + row) * padded_stride +
+                                         fetch_chunk * chunk_bytes_k + piece * 16;
+            __builtin_amdgcn_global_load_lds((global_bytes_t)source, (lds_bytes_t)(stage + (pass * 64 + wave * 8) * chunk_bytes_k), 16, 0, 0);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const std::uint32_t local = pass * 64 + fill_row, row = wide_queries_k + local;
+            const std::uint32_t piece = wide_swizzle(row, lane & 7u);
+            const std::uint32_t byte = fetch_chunk * chunk_bytes_k + piece * 16;
+            const std::uint32_t byte_inside = byte < row_bytes ? byte : row_bytes - 16; // stored rows: 16-byte aligned, zero padded to 16
+            const std::uint64_t wanted_row = tile_row + local;
+            const std::uint64_t row_inside = wanted_row < last_row ? wanted_row : last_row - 1;
+            __builtin_amdgcn_global_load_lds((global_bytes_t)(ix.vectors + row_inside * ix.row_stride + byte_inside),
+                                             (lds_bytes_t)(stage + (wide_queries_k + pass * 64 + wave * 8) * chunk_bytes_k), 16, 0, 0);
+        }
+        if (fetch_chunk == 0 && wave < 2) { // the tile's Σb², 64 per wave, by the same DMA (4 bytes per lane): nothing else is in the VM queue
+            const std::uint64_t wanted_row = tile_row + wave * 64 + lane;
+            const std::uint64_t row_inside = wanted_row < last_row ? wanted_row : last_row - 1;
+            __builtin_amdgcn_global_load_lds((global_bytes_t)(row_norms + row_inside),
+                                             (lds_bytes_t)(norms_r + (fetch_tile & 1u) * wide_rows_k + wave * 64), 4, 0, 0);
         }
         if (++fetch_chunk == chunks)
             fetch_chunk = 0, ++fetch_tile;
-        return regs;
-    };
-    auto commit = [&](std::uint32_t buffer, const staged_t regs) {
-        std::uint8_t* cell = lds + buffer * wide_stage_bytes_k + stage_row * pitch_k + segment * 16;
-        *reinterpret_cast<uint4*>(cell) = regs.q0;
-        *reinterpret_cast<uint4*>(cell + 64 * pitch_k) = regs.q1;
-        *reinterpret_cast<uint4*>(cell + 128 * pitch_k) = regs.q2;
-        *reinterpret_cast<uint4*>(cell + 192 * pitch_k) = regs.q3;
-        *reinterpret_cast<uint4*>(cell + 256 * pitch_k) = regs.r0;
-        *reinterpret_cast<uint4*>(cell + 320 * pitch_k) = regs.r1;
-        if (thread < wide_rows_k)
-            norms_r[buffer * wide_rows_k + thread] = regs.norm;
     };
 
     accumulator_t acc[4];
@@ -458,24 +476,31 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
             acc[u][r] = 0;
     std::uint32_t work_tile = 0, work_chunk = 0;
 
+    // fragment addresses: lane L reads row (base + (L & 31)), piece 2·step + (L >> 5), through the swizzle of that row. Row bases are
+    // multiples of 32, so the swizzle only depends on the lane
+    const std::uint32_t lane_swizzle = ((lane & 31u) >> 1) & 7u, lane_half = lane >> 5;
     auto multiply_chunk = [&](std::uint32_t buffer) {
         const std::uint8_t* stage = lds + buffer * wide_stage_bytes_k;
-        const std::uint8_t* mine = stage + (wave * 32 + (lane & 31)) * pitch_k + (lane >> 5) * 16;
-        const std::uint8_t* theirs = stage + (wide_queries_k + (lane & 31)) * pitch_k + (lane >> 5) * 16;
+        const std::uint8_t* mine = stage + (wave * 32 + (lane & 31)) * chunk_bytes_k;
+        const std::uint8_t* theirs = stage + (wide_queries_k + (lane & 31)) * chunk_bytes_k;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int step = 0; step < chunk_bytes_k / 32; ++step) {
-            const uint4 a = *reinterpret_cast<const uint4*>(mine + step * 32);
+            const std::uint32_t offset = ((2u * step + lane_half) ^ lane_swizzle) * 16u;
+            const uint4 a = *reinterpret_cast<const uint4*>(mine + offset);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const uint4 b = *reinterpret_cast<const uint4*>(theirs + u * 32 * pitch_k + step * 32);
+                const uint4 b = *reinterpret_cast<const uint4*>(theirs + u * 32 * chunk_bytes_k + offset);
                 acc[u] = multiply<scalar_ak>(a, b, acc[u]);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     };
 
     /// The tile's 32 × 128 sums of this wave against its queries' lists; the accumulators are cleared for the next tile.
-    auto fold_tile = [&](std::uint32_t buffer) {
+    auto fold_tile = [&]() {
         const std::uint64_t tile_row = first_row + (std::uint64_t)work_tile * wide_rows_k;
+        const std::uint32_t* tile_norms = norms_r + (work_tile & 1u) * wide_rows_k;
         bool changed = false;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -483,9 +508,29 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
             bool live = my_row < last_row;
             if (ix.has_tombstones && live)
                 live = ix.keys[my_row] != free_key_k;
-            const std::uint32_t b2 = norms_r[buffer * wide_rows_k + u * 32 + (lane & 31)];
+            if (allow_bits && live) // the caller's predicate, one bit per slot (index.hpp:4260-4263)
+                live = ((allow_bits[my_row >> 5] >> (my_row & 31)) & 1u) != 0;
+            const std::uint32_t b2 = tile_norms[u * 32 + (lane & 31)];
             const float row_scale = metric_ak == metric_cos_k ? bound_scale<integers>(b2) : 1.f;
-            // conservative: never false for a sum whose exact distance is ≤ the bound (NaN — a zero norm — compares "may")
+            // ---- the fast test, conservative: never false for a sum whose exact distance is ≤ the bound (NaN — a zero norm —
+            //      compares "may"). One multiply and one compare per sum; the compares' lane masks are ORed on the scalar unit.
+            std::uint64_t any = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                bool candidate;
+                if constexpr (metric_ak == metric_l2sq_k) {
+                    candidate = closing_distance<metric_ak, scalar_ak>(acc[u][r], query_norm[r], b2) <= bound[r];
+                } else if constexpr (metric_ak == metric_ip_k) {
+                    candidate = 1.f - (float)acc[u][r] <= bound[r];
+                } else { // cos: 1 − Σab/(√Σa²·√Σb²) ≤ bound + 10⁻⁵; an integer Σab = 0 closes to 0 whatever the norms
+                    candidate = !((float)acc[u][r] * row_scale < threshold[r]) || (integers && acc[u][r] == 0);
+                }
+                any |= __ballot(candidate);
+            }
+            any &= __ballot(live);
+            if (any == 0)
+                continue;
+            // ---- the rare path: which sums exactly, then one ordered insert at a time
             std::uint32_t may = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -494,16 +539,13 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                     candidate = closing_distance<metric_ak, scalar_ak>(acc[u][r], query_norm[r], b2) <= bound[r];
                 } else if constexpr (metric_ak == metric_ip_k) {
                     candidate = 1.f - (float)acc[u][r] <= bound[r];
-                } else { // cos: 1 − Σab/(√Σa²·√Σb²) up to a few ulps; an integer Σab = 0 closes to 0 whatever the norms
-                    const float approximate = 1.f - (float)acc[u][r] * query_scale[r] * row_scale;
-                    candidate = !(approximate > bound[r] + 1e-5f) || (integers && acc[u][r] == 0);
+                } else {
+                    candidate = !((float)acc[u][r] * row_scale < threshold[r]) || (integers && acc[u][r] == 0);
                 }
                 may |= (candidate ? 1u : 0u) << r;
             }
             may = live ? may & exists : 0u;
-            if (__ballot(may != 0) == 0)
-                continue;
-            for (int r = 0; r < 16; ++r) { // rare: kept rolled
+            for (int r = 0; r < 16; ++r) { // kept rolled
                 std::uint64_t pending = __ballot((may >> r) & 1u);
                 while (pending) {
                     const std::uint32_t source = (std::uint32_t)__ffsll((long long)pending) - 1;
@@ -546,51 +588,36 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                 }
             }
         }
-        if (__ballot(changed)) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                bound[r] = limit[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
-        }
+        if (__ballot(changed))
+            refresh_thresholds();
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 acc[u][r] = 0;
     };
-    auto finish_chunk = [&](std::uint32_t buffer) {
+
+    // ---- the pipeline: chunk c is multiplied out of buffer c & 1 while the DMA fills the other buffer with chunk c + 1. A wave
+    //      waits for its own fills (the VM counter), then meets the others: what a buffer holds is read one iteration after the
+    //      wait + barrier that completed it, and refilled one barrier after its last read.
+    if (total) {
+        issue_fills(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (std::uint32_t c = 0; c < total; ++c) {
+        if (c + 1 < total)
+            issue_fills((c + 1) & 1u);
+        multiply_chunk(c & 1u);
         if (++work_chunk == chunks) {
-            fold_tile(buffer);
+            fold_tile();
             work_chunk = 0, ++work_tile;
         }
-    };
-
-    // ---- the pipeline: chunk c is multiplied out of buffer c & 1 while chunk c + 1 sits in one register set (on its way to the
-    //      other buffer) and chunk c + 2 is in flight into the other set
-    //      (fetches past the end re-read the last tile into registers nobody commits to a buffer that is multiplied)
-    //      The pipeline fills by running the loop body once with the multiplication switched off, so the loop is entered with
-    //      no load in flight and its own register sets are the only ones the compiler has to count waits for.
-    staged_t even = {}, odd = {};
-    for (std::int64_t c = tiles ? -2 : 0; c < (std::int64_t)total; c += 2) {
-        even = fetch();
-        if (c >= 0) {
-            multiply_chunk(0);
-            finish_chunk(0);
-        }
-        commit(1, odd);
-        __syncthreads();
-        if (c + 1 >= (std::int64_t)total)
-            break;
-        odd = fetch();
-        if (c >= 0) {
-            multiply_chunk(1);
-            finish_chunk(1);
-        }
-        commit(0, even);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
     // ---- this partition's lists, laid out [partition][query][wanted] like the wave-per-query kernel's
-    __syncthreads();
     for (std::uint32_t cell = thread; cell < wide_queries_k * wanted; cell += wide_threads_k) {
         const std::uint32_t i = cell / wanted, position = cell % wanted;
         const std::uint32_t q = first_query + i;
@@ -627,8 +654,8 @@ template <int metric_ak, int scalar_ak>
 hipError_t launch_wide(const snapshot_view_t& view, const std::uint8_t* queries, std::uint64_t query_stride,
                        std::uint8_t* padded, std::uint32_t query_count, std::uint32_t wanted, std::uint32_t local_partitions,
                        std::uint64_t rows_per_partition, const std::uint32_t* row_norms, const std::uint32_t* query_norms,
-                       bool map_keys, float* out_distances, std::uint64_t* out_keys, std::uint64_t* out_counts,
-                       hipStream_t stream) {
+                       bool map_keys, const std::uint32_t* allow_bits, float* out_distances, std::uint64_t* out_keys,
+                       std::uint64_t* out_counts, hipStream_t stream) {
     auto kernel = exact_wide_kernel<metric_ak, scalar_ak>;
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)wide_lds_bytes());
@@ -643,7 +670,7 @@ hipError_t launch_wide(const snapshot_view_t& view, const std::uint8_t* queries,
                        padded_stride, padded_rows);
     hipLaunchKernelGGL(kernel, dim3(groups * 4 * local_partitions * 8), dim3(wide_threads_k), wide_lds_bytes(), stream, view,
                        (const std::uint8_t*)padded, padded_stride, query_count, wanted, rows_per_partition, query_tiles, local_partitions, row_norms,
-                       query_norms, map_keys ? 1u : 0u, out_distances, out_keys, out_counts);
+                       query_norms, map_keys ? 1u : 0u, allow_bits, out_distances, out_keys, out_counts);
     return hipGetLastError();
 }
 
@@ -658,8 +685,8 @@ template <int metric_ak, int scalar_ak>
 hipError_t launch_tiled(const snapshot_view_t& view, const std::uint8_t* queries, std::uint64_t query_stride,
                         std::uint32_t query_count, std::uint32_t wanted, std::uint32_t partitions,
                         std::uint64_t rows_per_partition, const std::uint32_t* row_norms, const std::uint32_t* query_norms,
-                        bool map_keys, float* out_distances, std::uint64_t* out_keys, std::uint64_t* out_counts,
-                        hipStream_t stream) {
+                        bool map_keys, const std::uint32_t* allow_bits, float* out_distances, std::uint64_t* out_keys,
+                        std::uint64_t* out_counts, hipStream_t stream) {
     auto kernel = exact_tiled_kernel<metric_ak, scalar_ak>;
     const std::uint32_t lds = tiled_lds_bytes();
     if (lds > 64 * 1024) {
@@ -670,7 +697,8 @@ hipError_t launch_tiled(const snapshot_view_t& view, const std::uint8_t* queries
     }
     const dim3 grid((query_count + tile_queries_k - 1) / tile_queries_k, partitions);
     hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, view, queries, query_stride, query_count, wanted,
-                       rows_per_partition, row_norms, query_norms, map_keys ? 1u : 0u, out_distances, out_keys, out_counts);
+                       rows_per_partition, row_norms, query_norms, map_keys ? 1u : 0u, allow_bits, out_distances, out_keys,
+                       out_counts);
     return hipGetLastError();
 }
 
@@ -699,7 +727,7 @@ bool exact_tiled_available(metric_kind_t metric, scalar_kind_t scalar, std::size
 const char* exact_search_tiled_device(metric_kind_t metric, scalar_kind_t scalar, const snapshot_view_t& view,
                                       const void* queries, std::size_t count, std::size_t stride_bytes, std::size_t wanted,
                                       bool map_keys, std::uint64_t* keys, float* distances, std::uint64_t* counts,
-                                      hipStream_t stream, float* kernel_ms) {
+                                      hipStream_t stream, float* kernel_ms, const std::uint32_t* allow_bits) {
     if (kernel_ms)
         *kernel_ms = 0.f;
     if (!exact_tiled_available(metric, scalar, wanted))
@@ -784,11 +812,11 @@ const char* exact_search_tiled_device(metric_kind_t metric, scalar_kind_t scalar
         if (e == hipSuccess && wide)                                                                                   \
             e = launch_wide<m, sc>(view, query_bytes, stride_bytes, padded_queries, (std::uint32_t)count,              \
                                    (std::uint32_t)wanted, (std::uint32_t)local_partitions, rows_per_partition, row_norms, query_norms,        \
-                                   map_keys, partial_distances, partial_keys, partial_counts, stream);                 \
+                                   map_keys, allow_bits, partial_distances, partial_keys, partial_counts, stream);     \
         else if (e == hipSuccess)                                                                                      \
             e = launch_tiled<m, sc>(view, query_bytes, stride_bytes, (std::uint32_t)count, (std::uint32_t)wanted,      \
                                     (std::uint32_t)partitions, rows_per_partition, row_norms, query_norms, map_keys,   \
-                                    partial_distances, partial_keys, partial_counts, stream);                          \
+                                    allow_bits, partial_distances, partial_keys, partial_counts, stream);              \
     }
     UA_TILED(metric_cos_k, scalar_f16_k)
     UA_TILED(metric_ip_k, scalar_f16_k)

@@ -1677,8 +1677,9 @@ template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak>
 __global__ __launch_bounds__(64) void exact_kernel(const snapshot_view_t ix, const std::uint8_t* queries,
                                                    std::uint64_t query_stride, std::uint32_t query_count,
                                                    std::uint32_t wanted, std::uint64_t rows_per_partition,
-                                                   std::uint32_t map_keys, float* out_distances,
-                                                   std::uint64_t* out_keys, std::uint64_t* out_counts) {
+                                                   std::uint32_t map_keys, const std::uint32_t* allow_bits,
+                                                   float* out_distances, std::uint64_t* out_keys,
+                                                   std::uint64_t* out_counts) {
     extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
     const std::uint32_t lane = lane_id();
     const std::uint32_t q = blockIdx.x, partition = blockIdx.y;
@@ -1694,9 +1695,12 @@ __global__ __launch_bounds__(64) void exact_kernel(const snapshot_view_t ix, con
     float worst = 0.f;
     for (std::uint64_t base = first; base < last; base += 64) {
         const std::uint32_t span = last - base < 64 ? (std::uint32_t)(last - base) : 64u;
-        // the `allow` predicate of index_dense.hpp:2071-2081 (tombstones), then compaction in slot order
+        // the `allow` predicate of index_dense.hpp:2071-2081 (tombstones, then the caller's predicate as one bit per slot —
+        // `search_exact_` skips `!predicate(member)`, index.hpp:4260-4263), then compaction in slot order
         const std::uint32_t slot = (std::uint32_t)base + lane;
-        const bool allowed = lane < span && (!ix.has_tombstones || ix.keys[slot] != free_key_k);
+        bool allowed = lane < span && (!ix.has_tombstones || ix.keys[slot] != free_key_k);
+        if (allow_bits && allowed)
+            allowed = ((allow_bits[slot >> 5] >> (slot & 31)) & 1u) != 0;
         const std::uint64_t allowed_mask = ballot(allowed);
         const std::uint32_t count = popcount64(allowed_mask);
         if (!count)

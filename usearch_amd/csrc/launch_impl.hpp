@@ -5,7 +5,6 @@
 #pragma once
 #include "engine.hpp"
 #include "kernels.hpp"
-#include "pair_kernels.hpp"
 
 namespace usearch_amd {
 
@@ -105,45 +104,8 @@ hipError_t launch_search_lanes(const launch_params_t& p, const snapshot_view_t& 
     return launch_search_mode<metric_ak, scalar_ak, lanes_ak, variant_u4_w4_k>(p, view, args);
 }
 
-/// The two-queries-per-wave walk (pair_kernels.hpp): integer-valued pairs only.
-template <int metric_ak, int scalar_ak, int cells_ak, bool inline_ak>
-hipError_t launch_pair_one(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
-    auto kernel = pair_search_kernel<metric_ak, scalar_ak, cells_ak, inline_ak>;
-    if (p.lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-        if (e != hipSuccess)
-            return e;
-    }
-    hipLaunchKernelGGL(kernel, dim3(p.grid), dim3(64), p.lds_bytes, p.stream, view, args);
-    return hipGetLastError();
-}
-
-template <int metric_ak, int scalar_ak, int cells_ak>
-hipError_t launch_pair_rows(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
-    // rows that travel with the lists exist for one-chunk rows only; among the integer-valued pairs that is b1 (≤ 128 bits)
-    if constexpr (scalar_ak == scalar_b1x8_k) {
-        if (view.nbr0_rows && view.chunks == 1)
-            return launch_pair_one<metric_ak, scalar_ak, cells_ak, true>(p, view, args);
-    }
-    return launch_pair_one<metric_ak, scalar_ak, cells_ak, false>(p, view, args);
-}
-
-template <int metric_ak, int scalar_ak>
-hipError_t launch_pair_metric(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
-    if constexpr (scalar_ak == scalar_b1x8_k || scalar_ak == scalar_i8_k) {
-        if (p.pair_cells == 2)
-            return launch_pair_rows<metric_ak, scalar_ak, 2>(p, view, args);
-        if (p.pair_cells == 4)
-            return launch_pair_rows<metric_ak, scalar_ak, 4>(p, view, args);
-    }
-    return hipErrorInvalidValue;
-}
-
 template <int metric_ak, int scalar_ak>
 hipError_t launch_search_metric(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
-    if (p.pair)
-        return launch_pair_metric<metric_ak, scalar_ak>(p, view, args);
     switch (p.lanes) {
     case 1: return launch_search_lanes<metric_ak, scalar_ak, 1>(p, view, args);
     case 2: return launch_search_lanes<metric_ak, scalar_ak, 2>(p, view, args);
@@ -184,8 +146,8 @@ template <int metric_ak, int scalar_ak, int lanes_ak>
 hipError_t launch_exact_one(const exact_params_t& p, const snapshot_view_t& view) {
     auto kernel = exact_kernel<metric_ak, scalar_ak, lanes_ak, lanes_ak == 8 ? 8 : 4>;
     hipLaunchKernelGGL(kernel, dim3(p.query_count, p.partitions), dim3(64), p.lds_bytes, p.stream, view, p.queries,
-                       p.query_stride, p.query_count, p.wanted, p.rows_per_partition, p.map_keys, p.out_distances,
-                       p.out_keys, p.out_counts);
+                       p.query_stride, p.query_count, p.wanted, p.rows_per_partition, p.map_keys, p.allow_bits,
+                       p.out_distances, p.out_keys, p.out_counts);
     return hipGetLastError();
 }
 

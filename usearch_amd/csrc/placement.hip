@@ -147,10 +147,24 @@ hipError_t draw(void** out, std::size_t bytes) {
             return hipSuccess;
         (void)hipGetLastError();
     }
-    return hipMalloc(out, bytes);
+    return block_malloc(out, bytes);
 }
 
 } // namespace
+
+hipError_t block_malloc(void** out, std::size_t bytes) {
+    if (env_size("USEARCH_AMD_CONTIGUOUS", 0) && bytes >= ((std::size_t)2 << 20)) {
+        if (hipExtMallocWithFlags(out, bytes, hipDeviceMallocContiguous) == hipSuccess) {
+            if (env_size("USEARCH_AMD_PLACEMENT_LOG", 0))
+                std::fprintf(stderr, "[usearch_amd] %.0f MB physically contiguous @%p\n", bytes / 1e6, *out);
+            return hipSuccess;
+        }
+        (void)hipGetLastError();
+        if (env_size("USEARCH_AMD_PLACEMENT_LOG", 0))
+            std::fprintf(stderr, "[usearch_amd] no contiguous range of %.0f MB: plain allocation\n", bytes / 1e6);
+    }
+    return hipMalloc(out, bytes);
+}
 
 const char* remap_trial(std::size_t bytes, std::size_t views, const std::function<const char*(void*, float&)>& judge,
                         std::vector<float>& view_ms) {
@@ -344,7 +358,7 @@ hipError_t placed_malloc(void** out, std::size_t bytes, std::size_t, placement_t
     *out = nullptr;
     bytes = std::max<std::size_t>(bytes, 16);
     if (bytes < env_size("USEARCH_AMD_PLACEMENT_MIN_BYTES", (std::size_t)1 << 30))
-        return hipMalloc(out, bytes);
+        return block_malloc(out, bytes);
     return draw(out, bytes);
 }
 

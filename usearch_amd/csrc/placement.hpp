@@ -45,6 +45,12 @@ struct placement_t {
  */
 hipError_t placed_malloc(void** out, std::size_t bytes, std::size_t row_bytes, placement_t* report);
 
+/// One block of device memory for something the walk hits at random (the matrix, the lists, the visited-set slabs):
+/// USEARCH_AMD_CONTIGUOUS = 1 asks the driver for PHYSICALLY CONTIGUOUS memory first (`hipDeviceMallocContiguous`: one range of
+/// frames, so the page tables can describe it with the largest fragments the alignment allows and a translation-cache entry covers
+/// far more than 2 MB), plain `hipMalloc` when that is refused. Release with `hipFree` / `placed_free`.
+hipError_t block_malloc(void** out, std::size_t bytes);
+
 /// Releases what `placed_malloc` returned (some placements are mapped through the virtual-memory API, not `hipMalloc`).
 void placed_free(void* pointer);
 

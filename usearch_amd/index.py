@@ -89,6 +89,9 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_exact_search_many", "usearch_amd_exact_search_many_tiled", "usearch_amd_exact_search_dataset",
     "usearch_amd_exact_search_many_device",
     "usearch_amd_cluster_many",
+    "usearch_amd_filter_from_key_range", "usearch_amd_filter_from_keys", "usearch_amd_filter_from_bits",
+    "usearch_amd_filter_allowed", "usearch_amd_filter_device_bits", "usearch_amd_filter_free",
+    "usearch_amd_filtered_search_many", "usearch_amd_filtered_search_many_device", "usearch_amd_filtered_exact_search_many",
     "usearch_amd_cast",
     "usearch_amd_build", "usearch_amd_build_free", "usearch_amd_build_snapshot",
     "usearch_amd_build_serialized_length", "usearch_amd_build_save_buffer", "usearch_amd_build_stats",
@@ -180,6 +183,22 @@ def library() -> C.CDLL:
     L.usearch_amd_exact_search_dataset.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                                    C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p,
                                                    C.c_size_t, C.c_void_p, C.c_size_t, err_p]
+    L.usearch_amd_filter_from_key_range.restype = C.c_void_p
+    L.usearch_amd_filter_from_key_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, err_p]
+    L.usearch_amd_filter_from_keys.restype = C.c_void_p
+    L.usearch_amd_filter_from_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, err_p]
+    L.usearch_amd_filter_from_bits.restype = C.c_void_p
+    L.usearch_amd_filter_from_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, err_p]
+    L.usearch_amd_filter_allowed.restype = C.c_size_t
+    L.usearch_amd_filter_allowed.argtypes = [C.c_void_p]
+    L.usearch_amd_filter_device_bits.restype = C.c_void_p
+    L.usearch_amd_filter_device_bits.argtypes = [C.c_void_p]
+    L.usearch_amd_filter_free.argtypes = [C.c_void_p, err_p]
+    L.usearch_amd_filtered_search_many.argtypes = [C.c_void_p, C.c_void_p] + L.usearch_amd_search_many.argtypes[1:]
+    L.usearch_amd_filtered_search_many_device.argtypes = [C.c_void_p, C.c_void_p] + L.usearch_amd_search_many_device.argtypes[1:]
+    L.usearch_amd_filtered_exact_search_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t,
+                                                         C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                         C.POINTER(C.c_float), err_p]
     L.usearch_amd_last_peaks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, err_p]
     L.usearch_amd_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, err_p]
@@ -256,6 +275,35 @@ class BatchMatches:
 
     def mean_recall(self, expected: np.ndarray, count: Optional[int] = None) -> float:
         return self.count_matches(expected, count=count) / len(expected)
+
+
+class Filter:
+    """A predicate over members as an HBM-resident bitmap (`usearch_amd_filter_t`): made once, reused by any number of batches.
+    Stands in for the `predicate(key)` callable of `index_dense_gt::filtered_search` (index_dense.hpp:774-779)."""
+
+    def __init__(self, handle: int, index: "Index"):
+        self._handle = handle
+        self._index = index  # keeps the snapshot alive
+
+    @property
+    def allowed(self) -> int:
+        return int(library().usearch_amd_filter_allowed(self._handle))
+
+    @property
+    def device_bits(self) -> int:
+        return int(library().usearch_amd_filter_device_bits(self._handle) or 0)
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            err = C.c_char_p()
+            library().usearch_amd_filter_free(self._handle, C.byref(err))
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Index:
@@ -441,10 +489,40 @@ class Index:
     def hardware_acceleration(self) -> str:
         return "gfx950"
 
+    # ---- filters
+    def filter_key_range(self, first: int, last: int) -> Filter:
+        """Members whose key lies in [first, last]."""
+        err = C.c_char_p()
+        handle = library().usearch_amd_filter_from_key_range(self._handle, first, last, C.byref(err))
+        _raise(err, "usearch_amd_filter_from_key_range")
+        return Filter(handle, self)
+
+    def filter_keys(self, keys, allow: bool = True) -> Filter:
+        """Members whose key is (allow) / is not (deny list) among `keys`."""
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        err = C.c_char_p()
+        handle = library().usearch_amd_filter_from_keys(self._handle, _pointer(keys), len(keys), int(allow), C.byref(err))
+        _raise(err, "usearch_amd_filter_from_keys")
+        return Filter(handle, self)
+
+    def filter_bits(self, bits: np.ndarray) -> Filter:
+        """The caller's bitmap: bit `s & 31` of word `s >> 5` = the member in slot `s` passes. A boolean array of one entry per
+        slot is packed first."""
+        bits = np.asarray(bits)
+        if bits.dtype == np.bool_:
+            padded = np.zeros((len(bits) + 31) // 32 * 32, dtype=np.uint8)
+            padded[:len(bits)] = bits
+            bits = np.packbits(padded.reshape(-1, 8), axis=1, bitorder="little").reshape(-1).view(np.uint32)
+        bits = np.ascontiguousarray(bits, dtype=np.uint32)
+        err = C.c_char_p()
+        handle = library().usearch_amd_filter_from_bits(self._handle, _pointer(bits), len(bits), C.byref(err))
+        _raise(err, "usearch_amd_filter_from_bits")
+        return Filter(handle, self)
+
     # ---- search
     def search(self, vectors: np.ndarray, count: int = 10, *, expansion: Optional[int] = None,
                dtype: Optional[str] = None, tuning: Optional[Tuning] = None,
-               exact: Union[bool, str] = False) -> Union[Matches, BatchMatches]:
+               exact: Union[bool, str] = False, filter: Optional[Filter] = None) -> Union[Matches, BatchMatches]:
         """`Index.search` (index.py:700-748): one vector → `Matches`, a 2-D batch → `BatchMatches`.
 
         `dtype` names the scalar kind of `vectors` when numpy cannot tell (bit-packed `b1` rows are `uint8`);
@@ -470,6 +548,16 @@ class Index:
         computed = np.zeros(q, dtype=np.uint64)
         stats = Stats()
         err = C.c_char_p()
+        if exact and filter is not None:  # brute force over the members the filter lets through (index.hpp:4260-4263)
+            kernel_ms = C.c_float()
+            library().usearch_amd_filtered_exact_search_many(
+                self._handle, filter._handle, _pointer(vectors), SCALAR_KINDS[dtype], q,
+                vectors.shape[1] * vectors.itemsize if q <= 1 else vectors.strides[0], count, _pointer(keys), _pointer(distances),
+                _pointer(counts), int(exact == "tiled"), C.byref(kernel_ms), C.byref(err))
+            _raise(err, "usearch_amd_filtered_exact_search_many")
+            stats.kernel_ms = kernel_ms.value
+            batch = BatchMatches(keys, distances, counts, 0, 0, visited, computed, stats)
+            return batch[0] if single else batch
         if exact:  # brute force over every stored vector (Index.search(..., exact=True), index.py:700-748)
             kernel_ms = C.c_float()
             # exact="tiled": the matrix-unit kernel (f16 / bf16 cos, ip within float tolerance; i8 bit-identical)
@@ -485,6 +573,15 @@ class Index:
             batch = BatchMatches(keys, distances, counts, 0, int(computed.sum()), visited, computed, stats)
             return batch[0] if single else batch
         ef = self.expansion_search if expansion is None else expansion
+        if filter is not None:
+            library().usearch_amd_filtered_search_many(self._handle, filter._handle, _pointer(vectors), SCALAR_KINDS[dtype], q,
+                                                       vectors.shape[1] * vectors.itemsize if q <= 1 else vectors.strides[0],
+                                                       count, ef, _pointer(keys), _pointer(distances), _pointer(counts),
+                                                       _pointer(visited), _pointer(computed),
+                                                       C.byref(tuning) if tuning is not None else None, C.byref(stats), C.byref(err))
+            _raise(err, "usearch_amd_filtered_search_many")
+            batch = BatchMatches(keys, distances, counts, int(visited.sum()), int(computed.sum()), visited, computed, stats)
+            return batch[0] if single else batch
         library().usearch_amd_search_many(self._handle, _pointer(vectors), SCALAR_KINDS[dtype], q,
                                           vectors.shape[1] * vectors.itemsize if q <= 1 else vectors.strides[0],
                                           count, ef, _pointer(keys),
@@ -498,10 +595,19 @@ class Index:
 
     def search_device(self, queries_ptr: int, queries_count: int, queries_stride: int, count: int, expansion: int,
                       keys_ptr: int, distances_ptr: int, counts_ptr: int, visited_ptr: int, computed_ptr: int,
-                      stream: int = 0, timed: bool = False, tuning: Optional[Tuning] = None) -> Stats:
+                      stream: int = 0, timed: bool = False, tuning: Optional[Tuning] = None,
+                      filter: Optional[Filter] = None) -> Stats:
         """HBM-resident batch: raw device addresses in and out (e.g. `torch.Tensor.data_ptr()`), storage scalar kind."""
         stats = Stats()
         err = C.c_char_p()
+        if filter is not None:
+            library().usearch_amd_filtered_search_many_device(
+                self._handle, filter._handle, C.c_void_p(queries_ptr), queries_count, queries_stride, count, expansion,
+                C.c_void_p(keys_ptr), C.c_void_p(distances_ptr), C.c_void_p(counts_ptr), C.c_void_p(visited_ptr),
+                C.c_void_p(computed_ptr), C.c_void_p(stream), C.byref(tuning) if tuning is not None else None, int(timed),
+                C.byref(stats), C.byref(err))
+            _raise(err, "usearch_amd_filtered_search_many_device")
+            return stats
         library().usearch_amd_search_many_device(self._handle, C.c_void_p(queries_ptr), queries_count, queries_stride,
                                                  count, expansion, C.c_void_p(keys_ptr), C.c_void_p(distances_ptr),
                                                  C.c_void_p(counts_ptr), C.c_void_p(visited_ptr),
