@@ -325,16 +325,25 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const snapshot_view_t 
 constexpr int wide_queries_k = 256; ///< queries per workgroup: a row is read once per 256 queries
 constexpr int wide_rows_k = 128;    ///< dataset rows per tile
 constexpr int wide_threads_k = 512; ///< 8 waves; wave w multiplies queries [32w, 32w + 32) with the tile's 128 rows
-constexpr int wide_wanted_k = 16;   ///< results per query this kernel keeps (its lists share LDS with two staging buffers)
+constexpr int wide_wanted_k = 16;   ///< results per query this kernel keeps (a lane per entry in the ordered insert, entries in the output arrays)
+constexpr int wide_buffers_k = 3;   ///< staging buffers: one being multiplied, two being filled
 constexpr int wide_stage_rows_k = wide_queries_k + wide_rows_k;
-constexpr int wide_loads_k = wide_stage_rows_k * (chunk_bytes_k / 16) / wide_threads_k; ///< LDS-DMA instructions per wave per chunk: 6
 constexpr std::uint32_t wide_stage_bytes_k = wide_stage_rows_k * chunk_bytes_k;         ///< a buffer: [384][128] bytes, no padding
 
 inline std::uint64_t wide_padded_stride(std::uint64_t bytes_per_vector) {
     return (bytes_per_vector + chunk_bytes_k - 1) / chunk_bytes_k * chunk_bytes_k;
 }
 constexpr std::uint32_t wide_lds_bytes() {
-    return 2 * wide_stage_bytes_k + wide_queries_k * wide_wanted_k * 8 + wide_queries_k * 4 * 3 + 2 * wide_rows_k * 4;
+    return wide_buffers_k * wide_stage_bytes_k + wide_queries_k * 4 * 3 + 4 * wide_rows_k * 4 + 4 * 512 * 4;
+}
+
+/// A float as an unsigned integer of the same order (negative distances exist: 1 − Σab), so that `atomicMin` keeps the smallest.
+__device__ __forceinline__ std::uint32_t ordered_bits(float x) {
+    const std::uint32_t bits = __builtin_bit_cast(std::uint32_t, x);
+    return bits ^ ((bits >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(std::uint32_t ordered) {
+    return __builtin_bit_cast(float, ordered ^ ((ordered >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
 /// Where the 16-byte piece `piece` of staged row `row` sits inside the row's 128 bytes. A `ds_read_b128` is served in groups of 16
@@ -367,18 +376,22 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                                                                     std::uint32_t query_tiles, std::uint32_t local_partitions,
                                                                     const std::uint32_t* row_norms, const std::uint32_t* query_norms,
                                                                     std::uint32_t map_keys, const std::uint32_t* allow_bits,
-                                                                    float* out_distances, std::uint64_t* out_keys,
-                                                                    std::uint64_t* out_counts) {
+                                                                    std::uint32_t* shared_bounds, float* out_distances,
+                                                                    std::uint64_t* out_keys, std::uint64_t* out_counts) {
     using accumulator_t = typename accumulator_gt<scalar_ak>::type;
     constexpr bool integers = scalar_ak == scalar_i8_k;
     using sum_t = typename std::conditional<integers, int, float>::type;
     extern __shared__ __attribute__((aligned(1024))) std::uint8_t lds[];
-    float* list_d = reinterpret_cast<float*>(lds + 2 * wide_stage_bytes_k);                   // [256][16]
-    std::uint32_t* list_s = reinterpret_cast<std::uint32_t*>(list_d + wide_queries_k * wide_wanted_k);
-    std::uint32_t* top_n = list_s + wide_queries_k * wide_wanted_k;                              // [256]
+    // The lists themselves live where they end up: this partition's cells of the output arrays (distances as they are, the slot in
+    // the low half of the key cell until the end). After the first tiles they are touched a few times per query (≈ k·ln(rows/k)
+    // inserts over the whole scan), and LDS has room for a third staging buffer instead.
+    std::uint32_t* top_n = reinterpret_cast<std::uint32_t*>(lds + wide_buffers_k * wide_stage_bytes_k); // [256]
     float* limit = reinterpret_cast<float*>(top_n + wide_queries_k);                            // [256] k-th best, +inf while filling
     std::uint32_t* norms_q = reinterpret_cast<std::uint32_t*>(limit + wide_queries_k);          // [256]
-    std::uint32_t* norms_r = norms_q + wide_queries_k; // [2][128] Σb² of the rows of the tile being multiplied / being fetched
+    std::uint32_t* norms_r = norms_q + wide_queries_k; // [4][128] Σb² of the rows of the tiles being multiplied / being fetched (a
+                                                       // tile of one chunk is fetched two tiles ahead): slot = tile mod 4
+    std::uint32_t* others = norms_r + 4 * wide_rows_k; // [4][8][64] the queries' SHARED bounds as fetched with the tile (same slots):
+                                                       // a fill writes 64 cells, a wave's 32 queries twice
 
     const std::uint32_t thread = threadIdx.x, wave = thread / 64, lane = thread % 64;
     // ---- which (query tile, partition) this workgroup is
@@ -407,7 +420,12 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
     std::uint32_t exists = 0;   // bit r: that query is inside the batch
     float query_root[16];       // cos: √Σa² (NaN for a zero norm = "always take the exact path"); the fast test's scale
     std::uint32_t query_norm[16];
-    float bound[16];            // copy of limit[] for those queries, refreshed after this wave changed a list
+    float own_bound[16];        // copy of limit[] for those queries (this partition's k-th best), refreshed after this wave changed a list
+    float bound[16];            // what a sum is tested against: the smaller of that and the query's SHARED bound — the k-th best any
+                                // partition has published (`shared_bounds`, atomicMin): a row farther than k rows some other
+                                // partition already holds cannot be among the query's k nearest, whichever partition it is in.
+                                // Without it every partition rebuilds the whole top-k race: k·ln(rows/k) inserts per query AND
+                                // partition; with it, per query
     float threshold[16];        // cos: (1 − bound − 10⁻⁵)·√Σa², what Σab·rsq(Σb²) has to reach; +inf for a query outside the batch
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -417,14 +435,21 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
         query_norm[r] = norms_q[i];
         const float a2 = integers ? (float)(int)query_norm[r] : __builtin_bit_cast(float, query_norm[r]);
         query_root[r] = a2 > 1e-30f ? __builtin_sqrtf(a2) : __builtin_nanf("");
-        bound[r] = __builtin_inff();
+        own_bound[r] = bound[r] = __builtin_inff();
         threshold[r] = inside ? -__builtin_inff() : __builtin_inff();
     }
-    auto refresh_thresholds = [&]() {
+    auto refresh_own_bounds = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            own_bound[r] = limit[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+    };
+    /// `shared[r]`: the ordered bits of the shared bound of register r's query, as fetched with the tile
+    auto refresh_thresholds = [&](const std::uint32_t (&shared)[16]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            bound[r] = limit[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
-            if constexpr (metric_ak == metric_cos_k) // −inf while the list is filling (bound = +inf): everything may enter
+            const float other = from_ordered_bits(shared[r]);
+            bound[r] = other < own_bound[r] ? other : own_bound[r]; // all ones decode to a NaN: "nothing published" keeps our own
+            if constexpr (metric_ak == metric_cos_k) // −inf while nobody has k results yet (bound = +inf): everything may enter
                 threshold[r] = (exists >> r) & 1u ? (1.f - (bound[r] + 1e-5f)) * query_root[r] : __builtin_inff();
         }
     };
@@ -434,39 +459,63 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
     //      (wide_swizzle). No branch on the data path: addresses are clamped into the arrays — a row past the partition's end
     //      re-reads the last row (the epilogue drops it: `live`), bytes past a row's last 16-byte chunk re-read that chunk and meet
     //      the zeros the padded queries hold there.
+    //      A chunk's fills are issued in four parts between the MFMA groups of the chunk being multiplied (their address
+    //      arithmetic runs in the shadow of the matrix unit); sources are kept as running pointers — a lane's piece of "its" rows
+    //      is the same in every pass (row bases are multiples of 64), a chunk is 128 bytes further on, a tile starts its rows anew.
     const std::uint32_t fill_row = wave * 8 + lane / 8; // + 64·pass
-    std::uint32_t fetch_tile = 0, fetch_chunk = 0;
-    auto issue_fills = [&](std::uint32_t buffer) {
-        std::uint8_t* stage = lds + buffer * wide_stage_bytes_k;
+    const std::uint32_t fill_piece = wide_swizzle(fill_row, lane & 7u);
+    const std::uint64_t query_pass_bytes = 64 * padded_stride;
+    const std::uint8_t* query_source = padded_queries + (std::uint64_t)(first_query + fill_row) * padded_stride + fill_piece * 16; // pass 0, this chunk
+    const std::uint8_t* row_source[2] = {ix.vectors, ix.vectors}; // start of "my" two dataset rows of the tile being fetched
+    std::uint32_t fetch_tile = 0, fetch_chunk = 0, fetch_byte = fill_piece * 16;
+    auto begin_tile = [&]() {
         const std::uint64_t tile_row = first_row + (std::uint64_t)fetch_tile * wide_rows_k;
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const std::uint32_t row = pass * 64 + fill_row;
-            const std::uint32_t piece = wide_swizzle(row, lane & 7u);
-            const std::uint8_t* source = padded_queries + (std::uint64_t)(first_query + row) * padded_stride +
-                                         fetch_chunk * chunk_bytes_k + piece * 16;
-            __builtin_amdgcn_global_load_lds((global_bytes_t)source, (lds_bytes_t)(stage + (pass * 64 + wave * 8) * chunk_bytes_k), 16, 0, 0);
-        }
-#pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
-            const std::uint32_t local = pass * 64 + fill_row, row = wide_queries_k + local;
-            const std::uint32_t piece = wide_swizzle(row, lane & 7u);
-            const std::uint32_t byte = fetch_chunk * chunk_bytes_k + piece * 16;
-            const std::uint32_t byte_inside = byte < row_bytes ? byte : row_bytes - 16; // stored rows: 16-byte aligned, zero padded to 16
-            const std::uint64_t wanted_row = tile_row + local;
-            const std::uint64_t row_inside = wanted_row < last_row ? wanted_row : last_row - 1;
-            __builtin_amdgcn_global_load_lds((global_bytes_t)(ix.vectors + row_inside * ix.row_stride + byte_inside),
-                                             (lds_bytes_t)(stage + (wide_queries_k + pass * 64 + wave * 8) * chunk_bytes_k), 16, 0, 0);
+            const std::uint64_t wanted_row = tile_row + pass * 64 + fill_row;
+            row_source[pass] = ix.vectors + (wanted_row < last_row ? wanted_row : last_row - 1) * ix.row_stride;
         }
-        if (fetch_chunk == 0 && wave < 2) { // the tile's Σb², 64 per wave, by the same DMA (4 bytes per lane): nothing else is in the VM queue
-            const std::uint64_t wanted_row = tile_row + wave * 64 + lane;
-            const std::uint64_t row_inside = wanted_row < last_row ? wanted_row : last_row - 1;
-            __builtin_amdgcn_global_load_lds((global_bytes_t)(row_norms + row_inside),
-                                             (lds_bytes_t)(norms_r + (fetch_tile & 1u) * wide_rows_k + wave * 64), 4, 0, 0);
-        }
-        if (++fetch_chunk == chunks)
-            fetch_chunk = 0, ++fetch_tile;
     };
+    auto fill_queries = [&](std::uint32_t buffer, int first_pass) { // two of the four query passes
+        std::uint8_t* stage = lds + buffer * wide_stage_bytes_k;
+#pragma unroll
+        for (int pass = first_pass; pass < first_pass + 2; ++pass)
+            __builtin_amdgcn_global_load_lds((global_bytes_t)(query_source + pass * query_pass_bytes),
+                                             (lds_bytes_t)(stage + (pass * 64 + wave * 8) * chunk_bytes_k), 16, 0, 0);
+    };
+    auto fill_rows = [&](std::uint32_t buffer) {
+        std::uint8_t* stage = lds + buffer * wide_stage_bytes_k;
+        const std::uint32_t byte_inside = fetch_byte < row_bytes ? fetch_byte : row_bytes - 16; // stored rows: 16-byte aligned, zero padded to 16
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass)
+            __builtin_amdgcn_global_load_lds((global_bytes_t)(row_source[pass] + byte_inside),
+                                             (lds_bytes_t)(stage + (wide_queries_k + pass * 64 + wave * 8) * chunk_bytes_k), 16, 0, 0);
+    };
+    auto fill_tile_head_and_advance = [&]() {
+        if (fetch_chunk == 0) { // this wave's 32 queries' shared bounds as they stand now (lanes 32 … 63 repeat them), same DMA
+            const std::uint32_t q = first_query + wave * 32 + (lane & 31);
+            __builtin_amdgcn_global_load_lds((global_bytes_t)(shared_bounds + (q < query_count ? q : query_count - 1)),
+                                             (lds_bytes_t)(others + (fetch_tile & 3u) * 512 + wave * 64), 4, 0, 0);
+            if (wave < 2) { // the tile's Σb², 64 per wave
+                const std::uint64_t wanted_row = first_row + (std::uint64_t)fetch_tile * wide_rows_k + wave * 64 + lane;
+                __builtin_amdgcn_global_load_lds((global_bytes_t)(row_norms + (wanted_row < last_row ? wanted_row : last_row - 1)),
+                                                 (lds_bytes_t)(norms_r + (fetch_tile & 3u) * wide_rows_k + wave * 64), 4, 0, 0);
+            }
+        }
+        query_source += chunk_bytes_k, fetch_byte += chunk_bytes_k;
+        if (++fetch_chunk == chunks) {
+            fetch_chunk = 0, ++fetch_tile;
+            query_source -= (std::uint64_t)chunks * chunk_bytes_k, fetch_byte = fill_piece * 16;
+            begin_tile();
+        }
+    };
+    auto issue_fills = [&](std::uint32_t buffer) { // all four parts at once: the prologue
+        fill_queries(buffer, 0);
+        fill_queries(buffer, 2);
+        fill_rows(buffer);
+        fill_tile_head_and_advance();
+    };
+    begin_tile();
 
     accumulator_t acc[4];
 #pragma unroll
@@ -476,31 +525,103 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
             acc[u][r] = 0;
     std::uint32_t work_tile = 0, work_chunk = 0;
 
-    // fragment addresses: lane L reads row (base + (L & 31)), piece 2·step + (L >> 5), through the swizzle of that row. Row bases are
-    // multiples of 32, so the swizzle only depends on the lane
+    // ---- fragment reads. Lane L reads row (base + (L & 31)), piece 2·step + (L >> 5), through the swizzle of that row; row bases
+    //      are multiples of 32, so the swizzled piece only depends on the lane and the step: four byte offsets, computed once.
+    //      The reads are written as inline assembly with hand-counted `lgkmcnt` waits: the compiler cannot tell a fragment read of
+    //      THIS buffer from the DMA fill of the OTHER one (both are "LDS + something"), and puts `s_waitcnt vmcnt(0)` — wait for the
+    //      fills just issued — in front of the first compiler-visible `ds_read` of every chunk, which serialises fill and multiply.
+    //      Step s + 1's five fragments are requested before step s's four MFMAs are issued (two register sets).
     const std::uint32_t lane_swizzle = ((lane & 31u) >> 1) & 7u, lane_half = lane >> 5;
-    auto multiply_chunk = [&](std::uint32_t buffer) {
-        const std::uint8_t* stage = lds + buffer * wide_stage_bytes_k;
-        const std::uint8_t* mine = stage + (wave * 32 + (lane & 31)) * chunk_bytes_k;
-        const std::uint8_t* theirs = stage + (wide_queries_k + (lane & 31)) * chunk_bytes_k;
+    const std::uint32_t lds_base = (std::uint32_t)(std::uintptr_t)(lds_bytes_t)lds;
+    const std::uint32_t query_fragments = lds_base + (wave * 32 + (lane & 31)) * chunk_bytes_k;
+    const std::uint32_t row_fragments = lds_base + (wide_queries_k + (lane & 31)) * chunk_bytes_k;
+    std::uint32_t step_offset[4];
+#pragma unroll
+    for (int step = 0; step < 4; ++step)
+        step_offset[step] = ((2u * step + lane_half) ^ lane_swizzle) * 16u;
+    static_assert(chunk_bytes_k / 32 == 4 && wide_rows_k == 128, "multiply_chunk is written out for four steps of four row blocks");
+    using u32x4_t = std::uint32_t __attribute__((ext_vector_type(4))); // a native 128-bit register operand for the assembler
+    auto product = [&](u32x4_t a, u32x4_t b, accumulator_t c) -> accumulator_t {
+        return multiply<scalar_ak>(__builtin_bit_cast(uint4, a), __builtin_bit_cast(uint4, b), c);
+    };
+#define UA_REQUEST_FRAGMENTS(set, step)                                                                                                \
+    {                                                                                                                                  \
+        const std::uint32_t qa = query_fragments + buffer_bytes + step_offset[step];                                                   \
+        const std::uint32_t ra = row_fragments + buffer_bytes + step_offset[step];                                                     \
+        asm volatile("ds_read_b128 %0, %5\n\t"                                                                                         \
+                     "ds_read_b128 %1, %6\n\t"                                                                                         \
+                     "ds_read_b128 %2, %6 offset:4096\n\t"                                                                             \
+                     "ds_read_b128 %3, %6 offset:8192\n\t"                                                                             \
+                     "ds_read_b128 %4, %6 offset:12288"                                                                                \
+                     : "=&v"(set##_a), "=&v"(set##_b0), "=&v"(set##_b1), "=&v"(set##_b2), "=&v"(set##_b3)                              \
+                     : "v"(qa), "v"(ra));                                                                                              \
+    }
+#define UA_AWAIT_FRAGMENTS(set, still_in_flight)                                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(" #still_in_flight ")" : "+v"(set##_a), "+v"(set##_b0), "+v"(set##_b1), "+v"(set##_b2), "+v"(set##_b3));
+#define UA_MULTIPLY_FRAGMENTS(set)                                                                                                     \
+    acc[0] = product(set##_a, set##_b0, acc[0]);                                                                                       \
+    acc[1] = product(set##_a, set##_b1, acc[1]);                                                                                       \
+    acc[2] = product(set##_a, set##_b2, acc[2]);                                                                                       \
+    acc[3] = product(set##_a, set##_b3, acc[3]);
+    /// Multiplies the chunk in `buffer`; with `filling`, the chunk after next goes into `target` meanwhile, a part of its fills
+    /// behind each group of four MFMAs.
+    auto multiply_chunk = [&](std::uint32_t buffer, bool filling, std::uint32_t target) {
+        const std::uint32_t buffer_bytes = buffer * wide_stage_bytes_k;
+        u32x4_t even_a, even_b0, even_b1, even_b2, even_b3, odd_a, odd_b0, odd_b1, odd_b2, odd_b3;
+        UA_REQUEST_FRAGMENTS(even, 0)
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int step = 0; step < chunk_bytes_k / 32; ++step) {
-            const std::uint32_t offset = ((2u * step + lane_half) ^ lane_swizzle) * 16u;
-            const uint4 a = *reinterpret_cast<const uint4*>(mine + offset);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint4 b = *reinterpret_cast<const uint4*>(theirs + u * 32 * chunk_bytes_k + offset);
-                acc[u] = multiply<scalar_ak>(a, b, acc[u]);
-            }
-        }
+        UA_REQUEST_FRAGMENTS(odd, 1)
+        UA_AWAIT_FRAGMENTS(even, 5)
+        UA_MULTIPLY_FRAGMENTS(even)
+        if (filling)
+            fill_queries(target, 0);
+        UA_REQUEST_FRAGMENTS(even, 2)
+        UA_AWAIT_FRAGMENTS(odd, 5)
+        UA_MULTIPLY_FRAGMENTS(odd)
+        if (filling)
+            fill_queries(target, 2);
+        UA_REQUEST_FRAGMENTS(odd, 3)
+        UA_AWAIT_FRAGMENTS(even, 5)
+        UA_MULTIPLY_FRAGMENTS(even)
+        if (filling)
+            fill_rows(target);
+        UA_AWAIT_FRAGMENTS(odd, 0)
+        UA_MULTIPLY_FRAGMENTS(odd)
+        if (filling)
+            fill_tile_head_and_advance();
         __builtin_amdgcn_s_setprio(0);
     };
+#undef UA_REQUEST_FRAGMENTS
+#undef UA_AWAIT_FRAGMENTS
+#undef UA_MULTIPLY_FRAGMENTS
 
     /// The tile's 32 × 128 sums of this wave against its queries' lists; the accumulators are cleared for the next tile.
     auto fold_tile = [&]() {
         const std::uint64_t tile_row = first_row + (std::uint64_t)work_tile * wide_rows_k;
-        const std::uint32_t* tile_norms = norms_r + (work_tile & 1u) * wide_rows_k;
+        // the tile's Σb² by hand-waited reads, like the fragments: a compiler-visible LDS read here would drain the fills in flight
+        const std::uint32_t tile_norms = lds_base + (std::uint32_t)((std::uint8_t*)(norms_r + (work_tile & 3u) * wide_rows_k + (lane & 31)) - lds);
+        std::uint32_t tile_b2[4];
+        asm volatile("ds_read_b32 %0, %4\n\t"
+                     "ds_read_b32 %1, %4 offset:128\n\t"
+                     "ds_read_b32 %2, %4 offset:256\n\t"
+                     "ds_read_b32 %3, %4 offset:384\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(tile_b2[0]), "=&v"(tile_b2[1]), "=&v"(tile_b2[2]), "=&v"(tile_b2[3])
+                     : "v"(tile_norms));
+        {   // what the other partitions have published since the last tile: registers 4j … 4j + 3 ↔ queries 8j + 4·(lane >> 5) + 0 … 3
+            const std::uint32_t cells = lds_base + (std::uint32_t)((std::uint8_t*)(others + (work_tile & 3u) * 512 + wave * 64 + 4 * (lane >> 5)) - lds);
+            u32x4_t s0, s1, s2, s3;
+            asm volatile("ds_read_b128 %0, %4\n\t"
+                         "ds_read_b128 %1, %4 offset:32\n\t"
+                         "ds_read_b128 %2, %4 offset:64\n\t"
+                         "ds_read_b128 %3, %4 offset:96\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3)
+                         : "v"(cells));
+            const std::uint32_t shared[16] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3],
+                                              s2[0], s2[1], s2[2], s2[3], s3[0], s3[1], s3[2], s3[3]};
+            refresh_thresholds(shared);
+        }
         bool changed = false;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -510,7 +631,7 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                 live = ix.keys[my_row] != free_key_k;
             if (allow_bits && live) // the caller's predicate, one bit per slot (index.hpp:4260-4263)
                 live = ((allow_bits[my_row >> 5] >> (my_row & 31)) & 1u) != 0;
-            const std::uint32_t b2 = tile_norms[u * 32 + (lane & 31)];
+            const std::uint32_t b2 = tile_b2[u];
             const float row_scale = metric_ak == metric_cos_k ? bound_scale<integers>(b2) : 1.f;
             // ---- the fast test, conservative: never false for a sum whose exact distance is ≤ the bound (NaN — a zero norm —
             //      compares "may"). One multiply and one compare per sum; the compares' lane masks are ORed on the scalar unit.
@@ -559,37 +680,46 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                     sum = __shfl(sum, (int)source, 64);
                     const std::uint32_t source_b2 = (std::uint32_t)__shfl((int)b2, (int)source, 64);
                     const float d = closing_distance<metric_ak, scalar_ak>(sum, norms_q[i], source_b2);
-                    float* entries_d = list_d + i * wide_wanted_k;
-                    std::uint32_t* entries_s = list_s + i * wide_wanted_k;
-                    std::uint32_t size = top_n[i];
-                    if (size == wanted && !goes_before(d, s, entries_d[size - 1], entries_s[size - 1]))
-                        continue;
-                    // position = entries that go before the newcomer; the ones at and after it move one cell down
+                    const std::uint64_t cells = ((std::uint64_t)partition * query_count + first_query + i) * wanted;
+                    float* entries_d = out_distances + cells;
+                    std::uint32_t* entries_s = reinterpret_cast<std::uint32_t*>(out_keys + cells); // entry e: word 2e
+                    const std::uint32_t size = top_n[i];
+                    // the whole list in registers, a lane per entry (read once: what follows never re-reads what it wrote)
                     const bool mine = lane < size;
                     const float my_d = mine ? entries_d[lane] : 0.f;
-                    const std::uint32_t my_s = mine ? entries_s[lane] : 0u;
+                    const std::uint32_t my_s = mine ? entries_s[2 * lane] : 0u;
+                    if (size == wanted) { // full: the newcomer has to beat the last entry
+                        const float last_d = __shfl(my_d, (int)(size - 1), 64);
+                        const std::uint32_t last_s = (std::uint32_t)__shfl((int)my_s, (int)(size - 1), 64);
+                        if (!goes_before(d, s, last_d, last_s))
+                            continue;
+                    }
+                    // position = entries that go before the newcomer; the ones at and after it move one cell down
                     const std::uint32_t position = (std::uint32_t)__popcll(__ballot(mine && goes_before(my_d, my_s, d, s)));
                     const std::uint32_t grown = size < wanted ? size + 1 : size;
                     if (mine && lane >= position && lane + 1 < grown)
-                        entries_d[lane + 1] = my_d, entries_s[lane + 1] = my_s;
+                        entries_d[lane + 1] = my_d, entries_s[2 * (lane + 1)] = my_s;
                     if (lane == position)
-                        entries_d[position] = d, entries_s[position] = s;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                        entries_d[position] = d, entries_s[2 * position] = s;
+                    // the new k-th best: the newcomer if it went last, else what was second to last (or last, while growing)
+                    const std::uint32_t new_last = grown - 1;
+                    const float shifted_from = __shfl(my_d, (int)(new_last ? new_last - 1 : 0), 64), stayed = __shfl(my_d, (int)new_last, 64);
+                    const float kth = position == new_last ? d : (position < new_last ? shifted_from : stayed);
                     if (lane == 0) {
                         top_n[i] = grown;
-                        limit[i] = grown == wanted ? entries_d[grown - 1] : __builtin_inff();
+                        limit[i] = grown == wanted ? kth : __builtin_inff();
+                        if (grown == wanted) // k rows at most this far exist: no partition needs anything farther for this query
+                            atomicMin(shared_bounds + first_query + i, ordered_bits(kth));
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // this wave's next insert into the list reads these cells
                     __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     changed = true;
                 }
             }
         }
         if (__ballot(changed))
-            refresh_thresholds();
+            refresh_own_bounds(); // the thresholds follow at the head of the next tile
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -597,42 +727,57 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                 acc[u][r] = 0;
     };
 
-    // ---- the pipeline: chunk c is multiplied out of buffer c & 1 while the DMA fills the other buffer with chunk c + 1. A wave
-    //      waits for its own fills (the VM counter), then meets the others: what a buffer holds is read one iteration after the
-    //      wait + barrier that completed it, and refilled one barrier after its last read.
+    // ---- the pipeline: chunk c is multiplied out of buffer c mod 3 while the DMA fills the two others with chunks c + 1 and
+    //      c + 2. A wave waits until ITS fills of chunk c + 1 have landed — a counted wait: the six (seven at the head of a tile)
+    //      fills of chunk c + 2, issued later, may stay in flight — then meets the others at a bare barrier: what a buffer holds is
+    //      read one iteration after the wait + barrier that completed it, and refilled one barrier after its last read. Nothing
+    //      between the fills and the wait may make the compiler wait for the whole VM queue: no `__syncthreads()` (its fence drains
+    //      it), no compiler-visible LDS read outside `fold_tile` (once per tile).
+    std::uint32_t work_buffer = 0, fill_buffer = 0;
     if (total) {
         issue_fills(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (total > 1)
+            issue_fills(1);
+        fill_buffer = 2;
+        if (total > 1)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
     for (std::uint32_t c = 0; c < total; ++c) {
-        if (c + 1 < total)
-            issue_fills((c + 1) & 1u);
-        multiply_chunk(c & 1u);
+        const bool filling = c + 2 < total;
+        multiply_chunk(work_buffer, filling, fill_buffer);
+        if (filling)
+            fill_buffer = fill_buffer == wide_buffers_k - 1 ? 0 : fill_buffer + 1;
+        work_buffer = work_buffer == wide_buffers_k - 1 ? 0 : work_buffer + 1;
         if (++work_chunk == chunks) {
             fold_tile();
             work_chunk = 0, ++work_tile;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (filling)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
-    // ---- this partition's lists, laid out [partition][query][wanted] like the wave-per-query kernel's
+    // ---- this partition's lists are already where the merge reads them, [partition][query][wanted] like the wave-per-query
+    //      kernel's: slots become keys, unused cells the padding
+    __syncthreads();
     for (std::uint32_t cell = thread; cell < wide_queries_k * wanted; cell += wide_threads_k) {
         const std::uint32_t i = cell / wanted, position = cell % wanted;
         const std::uint32_t q = first_query + i;
         if (q >= query_count)
             continue;
         const std::uint64_t out = ((std::uint64_t)partition * query_count + q) * wanted + position;
-        std::uint64_t key = 0;
-        std::uint32_t bits = signaling_nan_bits_k;
         if (position < top_n[i]) {
-            const std::uint32_t slot = list_s[i * wide_wanted_k + position];
-            key = map_keys ? ix.keys[slot] : (std::uint64_t)slot;
-            bits = __builtin_bit_cast(std::uint32_t, list_d[i * wide_wanted_k + position]);
+            const std::uint32_t slot = (std::uint32_t)out_keys[out];
+            out_keys[out] = map_keys ? ix.keys[slot] : (std::uint64_t)slot;
+        } else {
+            out_keys[out] = 0;
+            reinterpret_cast<std::uint32_t*>(out_distances)[out] = signaling_nan_bits_k;
         }
-        out_keys[out] = key;
-        reinterpret_cast<std::uint32_t*>(out_distances)[out] = bits;
     }
     for (std::uint32_t i = thread; i < wide_queries_k; i += wide_threads_k)
         if (first_query + i < query_count)
@@ -654,8 +799,8 @@ template <int metric_ak, int scalar_ak>
 hipError_t launch_wide(const snapshot_view_t& view, const std::uint8_t* queries, std::uint64_t query_stride,
                        std::uint8_t* padded, std::uint32_t query_count, std::uint32_t wanted, std::uint32_t local_partitions,
                        std::uint64_t rows_per_partition, const std::uint32_t* row_norms, const std::uint32_t* query_norms,
-                       bool map_keys, const std::uint32_t* allow_bits, float* out_distances, std::uint64_t* out_keys,
-                       std::uint64_t* out_counts, hipStream_t stream) {
+                       bool map_keys, const std::uint32_t* allow_bits, std::uint32_t* shared_bounds, float* out_distances,
+                       std::uint64_t* out_keys, std::uint64_t* out_counts, hipStream_t stream) {
     auto kernel = exact_wide_kernel<metric_ak, scalar_ak>;
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)wide_lds_bytes());
@@ -670,7 +815,7 @@ hipError_t launch_wide(const snapshot_view_t& view, const std::uint8_t* queries,
                        padded_stride, padded_rows);
     hipLaunchKernelGGL(kernel, dim3(groups * 4 * local_partitions * 8), dim3(wide_threads_k), wide_lds_bytes(), stream, view,
                        (const std::uint8_t*)padded, padded_stride, query_count, wanted, rows_per_partition, query_tiles, local_partitions, row_norms,
-                       query_norms, map_keys ? 1u : 0u, allow_bits, out_distances, out_keys, out_counts);
+                       query_norms, map_keys ? 1u : 0u, allow_bits, shared_bounds, out_distances, out_keys, out_counts);
     return hipGetLastError();
 }
 
@@ -794,9 +939,14 @@ const char* exact_search_tiled_device(metric_kind_t metric, scalar_kind_t scalar
     UA_HIP(scratch.allocate((void**)&partial_keys, partitions * count * wanted * 8));
     UA_HIP(scratch.allocate((void**)&partial_counts, partitions * count * 8));
     std::uint8_t* padded_queries = nullptr;
-    if (wide)
+    std::uint32_t* shared_bounds = nullptr;
+    if (wide) {
         UA_HIP(scratch.allocate((void**)&padded_queries, (count + wide_queries_k - 1) / wide_queries_k * wide_queries_k *
                                                               wide_padded_stride(view.bytes_per_vector)));
+        // per query, the smallest k-th best any partition has reached so far, as ordered bits: all ones = nobody has k results yet
+        UA_HIP(scratch.allocate((void**)&shared_bounds, count * 4));
+        UA_HIP(hipMemsetAsync(shared_bounds, 0xFF, count * 4, stream));
+    }
     if (kernel_ms) {
         UA_HIP(hipEventCreate(&scratch.begin));
         UA_HIP(hipEventCreate(&scratch.end));
@@ -812,7 +962,8 @@ const char* exact_search_tiled_device(metric_kind_t metric, scalar_kind_t scalar
         if (e == hipSuccess && wide)                                                                                   \
             e = launch_wide<m, sc>(view, query_bytes, stride_bytes, padded_queries, (std::uint32_t)count,              \
                                    (std::uint32_t)wanted, (std::uint32_t)local_partitions, rows_per_partition, row_norms, query_norms,        \
-                                   map_keys, allow_bits, partial_distances, partial_keys, partial_counts, stream);     \
+                                   map_keys, allow_bits, shared_bounds, partial_distances, partial_keys, partial_counts,  \
+                                   stream);                                                                         \
         else if (e == hipSuccess)                                                                                      \
             e = launch_tiled<m, sc>(view, query_bytes, stride_bytes, (std::uint32_t)count, (std::uint32_t)wanted,      \
                                     (std::uint32_t)partitions, rows_per_partition, row_norms, query_norms, map_keys,   \
