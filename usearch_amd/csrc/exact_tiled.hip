@@ -20,6 +20,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <type_traits>
 
 #include "common.hpp"
@@ -318,23 +319,25 @@ __global__ __launch_bounds__(256) void exact_tiled_kernel(const snapshot_view_t 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-//  The wide tile: 256 queries × 128 rows per workgroup of 8 waves; both operands go global → LDS by LDS-DMA
+//  The wide tile: 256 queries × 256 rows per workgroup of 8 waves; both operands go global → LDS by LDS-DMA
 //  (`global_load_lds_dwordx4`, no staging registers, no `ds_write`) into two XOR-swizzled buffers; register epilogue
 // ---------------------------------------------------------------------------------------------------------------------
 
 constexpr int wide_queries_k = 256; ///< queries per workgroup: a row is read once per 256 queries
-constexpr int wide_rows_k = 128;    ///< dataset rows per tile
-constexpr int wide_threads_k = 512; ///< 8 waves; wave w multiplies queries [32w, 32w + 32) with the tile's 128 rows
+constexpr int wide_rows_k = 256;    ///< dataset rows per tile: a query chunk is read once per 256 rows
+constexpr int wide_blocks_k = wide_rows_k / 32; ///< 32-row blocks of a tile = accumulators of a wave
+constexpr int wide_threads_k = 512; ///< 8 waves; wave w multiplies queries [32w, 32w + 32) with the tile's 256 rows
 constexpr int wide_wanted_k = 16;   ///< results per query this kernel keeps (a lane per entry in the ordered insert, entries in the output arrays)
-constexpr int wide_buffers_k = 3;   ///< staging buffers: one being multiplied, two being filled
+constexpr int wide_buffers_k = 2;   ///< staging buffers: one being multiplied, one being filled
 constexpr int wide_stage_rows_k = wide_queries_k + wide_rows_k;
-constexpr std::uint32_t wide_stage_bytes_k = wide_stage_rows_k * chunk_bytes_k;         ///< a buffer: [384][128] bytes, no padding
+constexpr std::uint32_t wide_stage_bytes_k = wide_stage_rows_k * chunk_bytes_k;         ///< a buffer: [512][128] bytes, no padding
+constexpr int wide_fills_k = wide_stage_rows_k / 8 / (wide_threads_k / 64);              ///< fill instructions per wave per chunk: 8
 
 inline std::uint64_t wide_padded_stride(std::uint64_t bytes_per_vector) {
     return (bytes_per_vector + chunk_bytes_k - 1) / chunk_bytes_k * chunk_bytes_k;
 }
 constexpr std::uint32_t wide_lds_bytes() {
-    return wide_buffers_k * wide_stage_bytes_k + wide_queries_k * 4 * 3 + 4 * wide_rows_k * 4 + 4 * 512 * 4;
+    return wide_buffers_k * wide_stage_bytes_k + wide_queries_k * 4 * 4 + 4 * wide_rows_k * 4 + 4 * 512 * 4;
 }
 
 /// A float as an unsigned integer of the same order (negative distances exist: 1 − Σab), so that `atomicMin` keeps the smallest.
@@ -342,6 +345,7 @@ __device__ __forceinline__ std::uint32_t ordered_bits(float x) {
     const std::uint32_t bits = __builtin_bit_cast(std::uint32_t, x);
     return bits ^ ((bits >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
+/// All ones ("nothing published yet") decode to a NaN.
 __device__ __forceinline__ float from_ordered_bits(std::uint32_t ordered) {
     return __builtin_bit_cast(float, ordered ^ ((ordered >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
@@ -352,28 +356,54 @@ __device__ __forceinline__ float from_ordered_bits(std::uint32_t ordered) {
 /// linearly, so the swizzle is applied to the SOURCE: lane i of a fill instruction fetches the piece that belongs in slot i.
 __device__ __forceinline__ std::uint32_t wide_swizzle(std::uint32_t row, std::uint32_t piece) { return piece ^ ((row >> 1) & 7u); }
 
+#ifdef USEARCH_AMD_EXACT_PHASES
+/// Diagnostic build (`make EXTRA=-DUSEARCH_AMD_EXACT_PHASES`): shader-clock ticks of wave 0 of every workgroup, summed — [0] multiply
+/// (fragment reads, MFMAs, the fills issued between them), [1] fold, [2] waiting for the own fills, [3] at the barrier, [4] chunks
+__device__ unsigned long long exact_phase_ticks[8];
+#define UA_PHASE_TICK(phase)                                                                                                           \
+    {                                                                                                                                  \
+        const std::uint64_t now = __builtin_amdgcn_s_memtime();                                                                        \
+        phase_ticks[phase] += now - phase_mark;                                                                                        \
+        phase_mark = now;                                                                                                              \
+    }
+#else
+#define UA_PHASE_TICK(phase)
+#endif
+
 using global_bytes_t = const __attribute__((address_space(1))) void*;
 using lds_bytes_t = __attribute__((address_space(3))) void*;
 
 /**
- *  grid = 1-D. Workgroups are dealt to the 8 XCDs round-robin by their linear index; inside an XCD, 32 consecutive workgroups
- *  (one per CU) are 4 query tiles × 8 row partitions, so what the XCD's L2 holds at any time is 4 query tiles (1.5 MB for
- *  768-d f16) and the row tiles 8 partitions are streaming, each shared by 4 workgroups.
+ *  grid = 1-D, ONE round of the chip where the batch allows (`wide_plan`): 10 000 queries = 40 query tiles = 5 per XCD × 6
+ *  partitions = 240 workgroups; what an XCD's L2 holds is its 5 query tiles (2 MB for 768-d f16) and the row tiles its 6
+ *  partitions are streaming, each shared by 5 workgroups. Few partitions matter: every partition rebuilds the top-k race of its
+ *  queries from scratch — k·ln(rows/k) inserts per query AND partition (the 64 partitions of round 3: 6 200 inserts per query, 5 per
+ *  tile and wave at ≈ 3 500 cycles each = three quarters of the epilogue; 6 partitions: 720).
  *
- *  Per 128-byte chunk of the summation: every wave issues 6 LDS-DMA fills (8 rows × 128 bytes each) of the NEXT chunk into the
- *  other buffer, multiplies the current one — 4 × (1 query fragment + 4 row fragments → 4 MFMAs) — waits for its own fills and
- *  meets the others at one barrier. Nothing is staged through registers and nothing is written to LDS by an instruction of the
- *  wave. The accumulators never visit LDS: a lane tests its 64 sums against the queries' current k-th best with one multiply and
- *  one compare per sum (cos: Σab·rsq(Σb²) against (1 − k-th best − 10⁻⁵)·√Σa², kept per query register), the wave ORs the
- *  compares' masks on the scalar unit, and only the few sums that may enter a list (≈ k·ln(rows/k) per query over the whole scan,
- *  after the first tile) take the exact closing arithmetic and the ordered insert, one at a time, by the wave that owns the
- *  query's list. Same lists as the 64-query kernel: the best `wanted` under (distance ↑, slot ↓), whatever the order of arrival.
+ *  What bounds this kernel is the path global → LDS of a compute unit (PMC, profiles/r04_exact/: matrix unit 31 % busy, vector
+ *  ALU 26 %, LDS 21 %, the texture path waiting on L2 43 % of the time with a 256 × 128 tile). Hence the shape: the tile is as
+ *  square as two LDS buffers allow — 256 queries × 256 rows stage 256 bytes per MFMA where 256 × 128 staged 384 — every wave
+ *  multiplies ITS 32 queries with all 256 rows (eight 32 × 32 accumulators: nothing about a query is shared between waves), and
+ *  nothing but the staged bytes crosses that path:
+ *    · fills are LDS-DMA (8 rows × 128 bytes per instruction, 8 instructions per wave and chunk), issued in four parts in the
+ *      shadow of the chunk's MFMA groups, sources kept as running pointers;
+ *    · fragment reads are inline assembly with hand-counted `lgkmcnt` waits: the compiler cannot tell a read of THIS buffer from the
+ *      fill of the OTHER one and would put `s_waitcnt vmcnt(0)` in front of every chunk's first read;
+ *    · the accumulators never visit LDS: a lane tests its 128 sums against the queries' bounds with one multiply and one compare
+ *      per sum (cos: Σab·rsq(Σb²) against (1 − bound − 10⁻⁵)·√Σa², kept per query register), the compares' lane masks are ORed on
+ *      the scalar unit, and only sums that may enter a list take the exact closing arithmetic and the ordered insert;
+ *    · a query's bound is SHARED by all partitions (`shared_bounds`: the smallest k-th best any partition has reached, atomicMin
+ *      of ordered bits, fetched by DMA with every tile): a row farther than k rows some partition already holds cannot be among
+ *      the query's k nearest, whichever partition it lies in. Inserts drop from k·ln(rows/k) per query AND partition to per query,
+ *      which is what lets the lists live where they end up — this partition's cells of the output arrays — instead of in LDS.
+ *  Same lists as the 64-query kernel: the best `wanted` under (distance ↑, slot ↓), whatever the order of arrival; a partition may
+ *  hold fewer than `wanted` of them (the merge takes counts).
  */
 template <int metric_ak, int scalar_ak>
 __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapshot_view_t ix, const std::uint8_t* padded_queries,
                                                                     std::uint64_t padded_stride, std::uint32_t query_count,
                                                                     std::uint32_t wanted, std::uint64_t rows_per_partition,
-                                                                    std::uint32_t query_tiles, std::uint32_t local_partitions,
+                                                                    std::uint32_t query_tiles, std::uint32_t tiles_per_xcd,
                                                                     const std::uint32_t* row_norms, const std::uint32_t* query_norms,
                                                                     std::uint32_t map_keys, const std::uint32_t* allow_bits,
                                                                     std::uint32_t* shared_bounds, float* out_distances,
@@ -381,25 +411,27 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
     using accumulator_t = typename accumulator_gt<scalar_ak>::type;
     constexpr bool integers = scalar_ak == scalar_i8_k;
     using sum_t = typename std::conditional<integers, int, float>::type;
+    using u32x4_t = std::uint32_t __attribute__((ext_vector_type(4))); // a native 128-bit register operand for the assembler
     extern __shared__ __attribute__((aligned(1024))) std::uint8_t lds[];
-    // The lists themselves live where they end up: this partition's cells of the output arrays (distances as they are, the slot in
-    // the low half of the key cell until the end). After the first tiles they are touched a few times per query (≈ k·ln(rows/k)
-    // inserts over the whole scan), and LDS has room for a third staging buffer instead.
-    std::uint32_t* top_n = reinterpret_cast<std::uint32_t*>(lds + wide_buffers_k * wide_stage_bytes_k); // [256]
-    float* limit = reinterpret_cast<float*>(top_n + wide_queries_k);                            // [256] k-th best, +inf while filling
-    std::uint32_t* norms_q = reinterpret_cast<std::uint32_t*>(limit + wide_queries_k);          // [256]
-    std::uint32_t* norms_r = norms_q + wide_queries_k; // [4][128] Σb² of the rows of the tiles being multiplied / being fetched (a
-                                                       // tile of one chunk is fetched two tiles ahead): slot = tile mod 4
-    std::uint32_t* others = norms_r + 4 * wide_rows_k; // [4][8][64] the queries' SHARED bounds as fetched with the tile (same slots):
-                                                       // a fill writes 64 cells, a wave's 32 queries twice
+    std::uint32_t* top_n = reinterpret_cast<std::uint32_t*>(lds + wide_buffers_k * wide_stage_bytes_k); // [256] entries per list
+    std::uint32_t* norms_q = top_n + wide_queries_k;   // [256] Σa²
+    float* roots_q = reinterpret_cast<float*>(norms_q + wide_queries_k); // [256] cos: √Σa², NaN for a zero norm ("always the exact path")
+    float* limit = roots_q + wide_queries_k; // [256] THIS partition's k-th best per query (+inf while its list is filling): felt from
+                                             // the next tile on, where the shared bound arrives a tile or two late
+    std::uint32_t* norms_r = reinterpret_cast<std::uint32_t*>(limit + wide_queries_k); // [4][256] Σb² of the rows of the tile being multiplied / being fetched (a
+                                                       // tile of one chunk is fetched a tile ahead): slot = tile mod 4
+    std::uint32_t* others = norms_r + 4 * wide_rows_k; // [4][8][64] the queries' shared bounds as fetched with the tile (same
+                                                       // slots): a fill writes 64 cells, a wave's 32 queries twice
 
     const std::uint32_t thread = threadIdx.x, wave = thread / 64, lane = thread % 64;
-    // ---- which (query tile, partition) this workgroup is
+    // ---- which (query tile, partition) this workgroup is (wide_plan): workgroups go to the XCDs round-robin by their linear
+    //      index; an XCD's `tiles_per_xcd` consecutive workgroups work on ONE partition for different query tiles (the row tile
+    //      they stream is shared through the XCD's L2). A batch of ≥ 8 query tiles is dealt over the XCDs (tile = 8·g + xcd, every
+    //      XCD sees every partition); a smaller one is handled whole by every XCD (partitions ≡ xcd mod 8).
     const std::uint32_t xcd = blockIdx.x % 8, sequence = blockIdx.x / 8;
-    const std::uint32_t per_group = 4 * local_partitions;
-    const std::uint32_t query_tile = sequence / per_group * 4 + sequence % 4;
-    const std::uint32_t partition = sequence % per_group / 4 * 8 + xcd;
-    if (query_tile >= query_tiles) // uniform: the grid is padded to whole groups of 4 query tiles
+    const std::uint32_t query_tile = query_tiles >= 8 ? (sequence % tiles_per_xcd) * 8 + xcd : sequence % tiles_per_xcd;
+    const std::uint32_t partition = query_tiles >= 8 ? sequence / tiles_per_xcd : sequence / tiles_per_xcd * 8 + xcd;
+    if (query_tile >= query_tiles) // uniform: the last round of tiles may be short
         return;
     const std::uint32_t first_query = query_tile * wide_queries_k;
     const std::uint64_t first_row = (std::uint64_t)partition * rows_per_partition;
@@ -413,19 +445,15 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
         top_n[i] = 0;
         limit[i] = __builtin_inff();
         norms_q[i] = first_query + i < query_count ? query_norms[first_query + i] : 0u;
+        const float a2 = integers ? (float)(int)norms_q[i] : __builtin_bit_cast(float, norms_q[i]);
+        roots_q[i] = a2 > 1e-30f ? __builtin_sqrtf(a2) : __builtin_nanf("");
     }
     __syncthreads();
 
     // ---- per lane: the 16 queries its accumulator registers belong to (register r ↔ query 32·wave + (r&3) + 8(r>>2) + 4(lane>>5))
     std::uint32_t exists = 0;   // bit r: that query is inside the batch
-    float query_root[16];       // cos: √Σa² (NaN for a zero norm = "always take the exact path"); the fast test's scale
     std::uint32_t query_norm[16];
-    float own_bound[16];        // copy of limit[] for those queries (this partition's k-th best), refreshed after this wave changed a list
-    float bound[16];            // what a sum is tested against: the smaller of that and the query's SHARED bound — the k-th best any
-                                // partition has published (`shared_bounds`, atomicMin): a row farther than k rows some other
-                                // partition already holds cannot be among the query's k nearest, whichever partition it is in.
-                                // Without it every partition rebuilds the whole top-k race: k·ln(rows/k) inserts per query AND
-                                // partition; with it, per query
+    float bound[16];            // the query's shared bound as of the last tile head (+inf: nobody has k results yet)
     float threshold[16];        // cos: (1 − bound − 10⁻⁵)·√Σa², what Σab·rsq(Σb²) has to reach; +inf for a query outside the batch
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -433,45 +461,37 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
         const bool inside = first_query + i < query_count;
         exists |= (inside ? 1u : 0u) << r;
         query_norm[r] = norms_q[i];
-        const float a2 = integers ? (float)(int)query_norm[r] : __builtin_bit_cast(float, query_norm[r]);
-        query_root[r] = a2 > 1e-30f ? __builtin_sqrtf(a2) : __builtin_nanf("");
-        own_bound[r] = bound[r] = __builtin_inff();
+        bound[r] = __builtin_inff();
         threshold[r] = inside ? -__builtin_inff() : __builtin_inff();
     }
-    auto refresh_own_bounds = [&]() {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            own_bound[r] = limit[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
-    };
-    /// `shared[r]`: the ordered bits of the shared bound of register r's query, as fetched with the tile
-    auto refresh_thresholds = [&](const std::uint32_t (&shared)[16]) {
+    /// `shared[r]`: the ordered bits of the shared bound of register r's query, as fetched with the tile; `own[r]`: this partition's
+    /// k-th best; `roots[r]`: the query's √Σa²
+    auto refresh_thresholds = [&](const std::uint32_t (&shared)[16], const float (&own)[16], const float (&roots)[16]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float other = from_ordered_bits(shared[r]);
-            bound[r] = other < own_bound[r] ? other : own_bound[r]; // all ones decode to a NaN: "nothing published" keeps our own
-            if constexpr (metric_ak == metric_cos_k) // −inf while nobody has k results yet (bound = +inf): everything may enter
-                threshold[r] = (exists >> r) & 1u ? (1.f - (bound[r] + 1e-5f)) * query_root[r] : __builtin_inff();
+            bound[r] = other < own[r] ? other : own[r]; // a NaN ("nothing published") keeps our own
+            if constexpr (metric_ak == metric_cos_k) // −inf while nobody has k results yet: everything may enter
+                threshold[r] = (exists >> r) & 1u ? (1.f - (bound[r] + 1e-5f)) * roots[r] : __builtin_inff();
         }
     };
 
     // ---- LDS-DMA fills. A fill instruction of a wave writes 1 024 consecutive bytes = 8 staged rows; wave w fills rows
-    //      64·pass + 8w … + 8 (4 passes of queries, 2 of dataset rows); lane i brings the piece that belongs in slot i of "its" row
-    //      (wide_swizzle). No branch on the data path: addresses are clamped into the arrays — a row past the partition's end
-    //      re-reads the last row (the epilogue drops it: `live`), bytes past a row's last 16-byte chunk re-read that chunk and meet
-    //      the zeros the padded queries hold there.
-    //      A chunk's fills are issued in four parts between the MFMA groups of the chunk being multiplied (their address
-    //      arithmetic runs in the shadow of the matrix unit); sources are kept as running pointers — a lane's piece of "its" rows
-    //      is the same in every pass (row bases are multiples of 64), a chunk is 128 bytes further on, a tile starts its rows anew.
+    //      64·pass + 8w … + 8 (4 passes of queries, 4 of dataset rows); lane i brings the piece that belongs in slot i of "its" row
+    //      (wide_swizzle; the same piece in every pass: row bases are multiples of 64). No branch on the data path: addresses are
+    //      clamped into the arrays — a row past the partition's end re-reads the last row (the epilogue drops it: `live`), bytes
+    //      past a row's last 16-byte chunk re-read that chunk and meet the zeros the padded queries hold there. Sources are
+    //      running pointers: a chunk is 128 bytes further on, a tile starts its rows anew.
     const std::uint32_t fill_row = wave * 8 + lane / 8; // + 64·pass
     const std::uint32_t fill_piece = wide_swizzle(fill_row, lane & 7u);
     const std::uint64_t query_pass_bytes = 64 * padded_stride;
     const std::uint8_t* query_source = padded_queries + (std::uint64_t)(first_query + fill_row) * padded_stride + fill_piece * 16; // pass 0, this chunk
-    const std::uint8_t* row_source[2] = {ix.vectors, ix.vectors}; // start of "my" two dataset rows of the tile being fetched
+    const std::uint8_t* row_source[4] = {ix.vectors, ix.vectors, ix.vectors, ix.vectors}; // start of "my" four rows of the tile being fetched
     std::uint32_t fetch_tile = 0, fetch_chunk = 0, fetch_byte = fill_piece * 16;
     auto begin_tile = [&]() {
         const std::uint64_t tile_row = first_row + (std::uint64_t)fetch_tile * wide_rows_k;
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int pass = 0; pass < 4; ++pass) {
             const std::uint64_t wanted_row = tile_row + pass * 64 + fill_row;
             row_source[pass] = ix.vectors + (wanted_row < last_row ? wanted_row : last_row - 1) * ix.row_stride;
         }
@@ -483,11 +503,11 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
             __builtin_amdgcn_global_load_lds((global_bytes_t)(query_source + pass * query_pass_bytes),
                                              (lds_bytes_t)(stage + (pass * 64 + wave * 8) * chunk_bytes_k), 16, 0, 0);
     };
-    auto fill_rows = [&](std::uint32_t buffer) {
+    auto fill_rows = [&](std::uint32_t buffer, int first_pass) { // two of the four row passes
         std::uint8_t* stage = lds + buffer * wide_stage_bytes_k;
         const std::uint32_t byte_inside = fetch_byte < row_bytes ? fetch_byte : row_bytes - 16; // stored rows: 16-byte aligned, zero padded to 16
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass)
+        for (int pass = first_pass; pass < first_pass + 2; ++pass)
             __builtin_amdgcn_global_load_lds((global_bytes_t)(row_source[pass] + byte_inside),
                                              (lds_bytes_t)(stage + (wide_queries_k + pass * 64 + wave * 8) * chunk_bytes_k), 16, 0, 0);
     };
@@ -496,7 +516,7 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
             const std::uint32_t q = first_query + wave * 32 + (lane & 31);
             __builtin_amdgcn_global_load_lds((global_bytes_t)(shared_bounds + (q < query_count ? q : query_count - 1)),
                                              (lds_bytes_t)(others + (fetch_tile & 3u) * 512 + wave * 64), 4, 0, 0);
-            if (wave < 2) { // the tile's Σb², 64 per wave
+            if (wave < wide_rows_k / 64) { // the tile's Σb², 64 per wave
                 const std::uint64_t wanted_row = first_row + (std::uint64_t)fetch_tile * wide_rows_k + wave * 64 + lane;
                 __builtin_amdgcn_global_load_lds((global_bytes_t)(row_norms + (wanted_row < last_row ? wanted_row : last_row - 1)),
                                                  (lds_bytes_t)(norms_r + (fetch_tile & 3u) * wide_rows_k + wave * 64), 4, 0, 0);
@@ -509,17 +529,11 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
             begin_tile();
         }
     };
-    auto issue_fills = [&](std::uint32_t buffer) { // all four parts at once: the prologue
-        fill_queries(buffer, 0);
-        fill_queries(buffer, 2);
-        fill_rows(buffer);
-        fill_tile_head_and_advance();
-    };
     begin_tile();
 
-    accumulator_t acc[4];
+    accumulator_t acc[wide_blocks_k];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < wide_blocks_k; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             acc[u][r] = 0;
@@ -527,10 +541,9 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
 
     // ---- fragment reads. Lane L reads row (base + (L & 31)), piece 2·step + (L >> 5), through the swizzle of that row; row bases
     //      are multiples of 32, so the swizzled piece only depends on the lane and the step: four byte offsets, computed once.
-    //      The reads are written as inline assembly with hand-counted `lgkmcnt` waits: the compiler cannot tell a fragment read of
-    //      THIS buffer from the DMA fill of the OTHER one (both are "LDS + something"), and puts `s_waitcnt vmcnt(0)` — wait for the
-    //      fills just issued — in front of the first compiler-visible `ds_read` of every chunk, which serialises fill and multiply.
-    //      Step s + 1's five fragments are requested before step s's four MFMAs are issued (two register sets).
+    //      Per step a wave needs its query fragment and eight row fragments for eight MFMAs. Registers: the query fragment twice
+    //      (the next step's is requested while this step's is still being multiplied), the row fragments once, in two halves of
+    //      four — a half is requested again as soon as its four MFMAs are issued, and lands while the other half is multiplied.
     const std::uint32_t lane_swizzle = ((lane & 31u) >> 1) & 7u, lane_half = lane >> 5;
     const std::uint32_t lds_base = (std::uint32_t)(std::uintptr_t)(lds_bytes_t)lds;
     const std::uint32_t query_fragments = lds_base + (wave * 32 + (lane & 31)) * chunk_bytes_k;
@@ -539,76 +552,73 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
 #pragma unroll
     for (int step = 0; step < 4; ++step)
         step_offset[step] = ((2u * step + lane_half) ^ lane_swizzle) * 16u;
-    static_assert(chunk_bytes_k / 32 == 4 && wide_rows_k == 128, "multiply_chunk is written out for four steps of four row blocks");
-    using u32x4_t = std::uint32_t __attribute__((ext_vector_type(4))); // a native 128-bit register operand for the assembler
+    static_assert(chunk_bytes_k / 32 == 4 && wide_blocks_k == 8, "multiply_chunk is written out for four steps of eight row blocks");
     auto product = [&](u32x4_t a, u32x4_t b, accumulator_t c) -> accumulator_t {
         return multiply<scalar_ak>(__builtin_bit_cast(uint4, a), __builtin_bit_cast(uint4, b), c);
     };
-#define UA_REQUEST_FRAGMENTS(set, step)                                                                                                \
-    {                                                                                                                                  \
-        const std::uint32_t qa = query_fragments + buffer_bytes + step_offset[step];                                                   \
-        const std::uint32_t ra = row_fragments + buffer_bytes + step_offset[step];                                                     \
-        asm volatile("ds_read_b128 %0, %5\n\t"                                                                                         \
-                     "ds_read_b128 %1, %6\n\t"                                                                                         \
-                     "ds_read_b128 %2, %6 offset:4096\n\t"                                                                             \
-                     "ds_read_b128 %3, %6 offset:8192\n\t"                                                                             \
-                     "ds_read_b128 %4, %6 offset:12288"                                                                                \
-                     : "=&v"(set##_a), "=&v"(set##_b0), "=&v"(set##_b1), "=&v"(set##_b2), "=&v"(set##_b3)                              \
-                     : "v"(qa), "v"(ra));                                                                                              \
-    }
-#define UA_AWAIT_FRAGMENTS(set, still_in_flight)                                                                                       \
-    asm volatile("s_waitcnt lgkmcnt(" #still_in_flight ")" : "+v"(set##_a), "+v"(set##_b0), "+v"(set##_b1), "+v"(set##_b2), "+v"(set##_b3));
-#define UA_MULTIPLY_FRAGMENTS(set)                                                                                                     \
-    acc[0] = product(set##_a, set##_b0, acc[0]);                                                                                       \
-    acc[1] = product(set##_a, set##_b1, acc[1]);                                                                                       \
-    acc[2] = product(set##_a, set##_b2, acc[2]);                                                                                       \
-    acc[3] = product(set##_a, set##_b3, acc[3]);
-    /// Multiplies the chunk in `buffer`; with `filling`, the chunk after next goes into `target` meanwhile, a part of its fills
-    /// behind each group of four MFMAs.
+#define UA_REQUEST_QUERY(target, step)                                                                                                 \
+    asm volatile("ds_read_b128 %0, %1" : "=&v"(target) : "v"(query_fragments + buffer_bytes + step_offset[step]));
+#define UA_REQUEST_ROWS(b0, b1, b2, b3, first_block, step)                                                                            \
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\t"                                                                                   \
+                 "ds_read_b128 %1, %4 offset:%6\n\t"                                                                                   \
+                 "ds_read_b128 %2, %4 offset:%7\n\t"                                                                                   \
+                 "ds_read_b128 %3, %4 offset:%8"                                                                                       \
+                 : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)                                                                          \
+                 : "v"(row_fragments + buffer_bytes + step_offset[step]), "n"((first_block)*4096), "n"((first_block)*4096 + 4096),     \
+                   "n"((first_block)*4096 + 8192), "n"((first_block)*4096 + 12288));
+#define UA_AWAIT(still_in_flight, a, b0, b1, b2, b3)                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(" #still_in_flight ")" : "+v"(a), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+    /// Multiplies the chunk in `buffer`; with `filling`, the next chunk goes into `target` meanwhile, a part of its fills behind each
+    /// step's MFMAs.
     auto multiply_chunk = [&](std::uint32_t buffer, bool filling, std::uint32_t target) {
         const std::uint32_t buffer_bytes = buffer * wide_stage_bytes_k;
-        u32x4_t even_a, even_b0, even_b1, even_b2, even_b3, odd_a, odd_b0, odd_b1, odd_b2, odd_b3;
-        UA_REQUEST_FRAGMENTS(even, 0)
+        u32x4_t a_even, a_odd, l0, l1, l2, l3, h0, h1, h2, h3;
+        UA_REQUEST_QUERY(a_even, 0)
+        UA_REQUEST_ROWS(l0, l1, l2, l3, 0, 0)
+        UA_REQUEST_ROWS(h0, h1, h2, h3, 4, 0)
         __builtin_amdgcn_s_setprio(1);
-        UA_REQUEST_FRAGMENTS(odd, 1)
-        UA_AWAIT_FRAGMENTS(even, 5)
-        UA_MULTIPLY_FRAGMENTS(even)
-        if (filling)
-            fill_queries(target, 0);
-        UA_REQUEST_FRAGMENTS(even, 2)
-        UA_AWAIT_FRAGMENTS(odd, 5)
-        UA_MULTIPLY_FRAGMENTS(odd)
-        if (filling)
-            fill_queries(target, 2);
-        UA_REQUEST_FRAGMENTS(odd, 3)
-        UA_AWAIT_FRAGMENTS(even, 5)
-        UA_MULTIPLY_FRAGMENTS(even)
-        if (filling)
-            fill_rows(target);
-        UA_AWAIT_FRAGMENTS(odd, 0)
-        UA_MULTIPLY_FRAGMENTS(odd)
-        if (filling)
-            fill_tile_head_and_advance();
+#define UA_STEP(a_now, a_next, step, has_next, fill_statement)                                                                         \
+        UA_AWAIT(4, a_now, l0, l1, l2, l3) /* the query fragment and the low half are there; the high half may be in flight */       \
+        acc[0] = product(a_now, l0, acc[0]);                                                                                           \
+        acc[1] = product(a_now, l1, acc[1]);                                                                                           \
+        acc[2] = product(a_now, l2, acc[2]);                                                                                           \
+        acc[3] = product(a_now, l3, acc[3]);                                                                                           \
+        if (has_next) {                                                                                                                \
+            UA_REQUEST_QUERY(a_next, (step) + 1)                                                                                       \
+            UA_REQUEST_ROWS(l0, l1, l2, l3, 0, (step) + 1)                                                                             \
+            UA_AWAIT(5, a_now, h0, h1, h2, h3) /* the high half is there; the five just requested may be in flight */                  \
+        } else {                                                                                                                       \
+            UA_AWAIT(0, a_now, h0, h1, h2, h3)                                                                                         \
+        }                                                                                                                              \
+        acc[4] = product(a_now, h0, acc[4]);                                                                                           \
+        acc[5] = product(a_now, h1, acc[5]);                                                                                           \
+        acc[6] = product(a_now, h2, acc[6]);                                                                                           \
+        acc[7] = product(a_now, h3, acc[7]);                                                                                           \
+        if (has_next) {                                                                                                                \
+            UA_REQUEST_ROWS(h0, h1, h2, h3, 4, (step) + 1)                                                                             \
+        }                                                                                                                              \
+        if (filling) {                                                                                                                 \
+            fill_statement;                                                                                                            \
+        }
+        // the dataset rows first — they come from HBM, the queries from L2 — and nothing behind the last step: what is issued there
+        // has the whole fold to land, not just the wait in front of the barrier
+        UA_STEP(a_even, a_odd, 0, true, fill_rows(target, 0); fill_rows(target, 2))
+        UA_STEP(a_odd, a_even, 1, true, fill_queries(target, 0))
+        UA_STEP(a_even, a_odd, 2, true, fill_queries(target, 2); fill_tile_head_and_advance())
+        UA_STEP(a_odd, a_even, 3, false, (void)0)
+#undef UA_STEP
         __builtin_amdgcn_s_setprio(0);
     };
-#undef UA_REQUEST_FRAGMENTS
-#undef UA_AWAIT_FRAGMENTS
-#undef UA_MULTIPLY_FRAGMENTS
+#undef UA_REQUEST_QUERY
+#undef UA_REQUEST_ROWS
+#undef UA_AWAIT
 
-    /// The tile's 32 × 128 sums of this wave against its queries' lists; the accumulators are cleared for the next tile.
+    /// The tile's 32 × 256 sums of this wave against its queries' lists; the accumulators are cleared for the next tile.
     auto fold_tile = [&]() {
         const std::uint64_t tile_row = first_row + (std::uint64_t)work_tile * wide_rows_k;
-        // the tile's Σb² by hand-waited reads, like the fragments: a compiler-visible LDS read here would drain the fills in flight
-        const std::uint32_t tile_norms = lds_base + (std::uint32_t)((std::uint8_t*)(norms_r + (work_tile & 3u) * wide_rows_k + (lane & 31)) - lds);
-        std::uint32_t tile_b2[4];
-        asm volatile("ds_read_b32 %0, %4\n\t"
-                     "ds_read_b32 %1, %4 offset:128\n\t"
-                     "ds_read_b32 %2, %4 offset:256\n\t"
-                     "ds_read_b32 %3, %4 offset:384\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(tile_b2[0]), "=&v"(tile_b2[1]), "=&v"(tile_b2[2]), "=&v"(tile_b2[3])
-                     : "v"(tile_norms));
-        {   // what the other partitions have published since the last tile: registers 4j … 4j + 3 ↔ queries 8j + 4·(lane >> 5) + 0 … 3
+        // the tile's Σb² and the shared bounds by hand-waited reads, like the fragments: a compiler-visible LDS read here would
+        // drain the fills in flight. Registers 4j … 4j + 3 ↔ queries 8j + 4·(lane >> 5) + 0 … 3
+        {
             const std::uint32_t cells = lds_base + (std::uint32_t)((std::uint8_t*)(others + (work_tile & 3u) * 512 + wave * 64 + 4 * (lane >> 5)) - lds);
             u32x4_t s0, s1, s2, s3;
             asm volatile("ds_read_b128 %0, %4\n\t"
@@ -620,51 +630,91 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                          : "v"(cells));
             const std::uint32_t shared[16] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3],
                                               s2[0], s2[1], s2[2], s2[3], s3[0], s3[1], s3[2], s3[3]};
-            refresh_thresholds(shared);
-        }
-        bool changed = false;
+            float own[16];
+            {
+                const std::uint32_t own_cells = lds_base + (std::uint32_t)((std::uint8_t*)(limit + wave * 32 + 4 * (lane >> 5)) - lds);
+                u32x4_t o0, o1, o2, o3;
+                asm volatile("ds_read_b128 %0, %4\n\t"
+                             "ds_read_b128 %1, %4 offset:32\n\t"
+                             "ds_read_b128 %2, %4 offset:64\n\t"
+                             "ds_read_b128 %3, %4 offset:96\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+                             : "v"(own_cells));
+                const std::uint32_t bits[16] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3],
+                                                o2[0], o2[1], o2[2], o2[3], o3[0], o3[1], o3[2], o3[3]};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+                for (int r = 0; r < 16; ++r)
+                    own[r] = __builtin_bit_cast(float, bits[r]);
+            }
+            float roots[16] = {};
+            if constexpr (metric_ak == metric_cos_k) {
+                const std::uint32_t root_cells = lds_base + (std::uint32_t)((std::uint8_t*)(roots_q + wave * 32 + 4 * (lane >> 5)) - lds);
+                u32x4_t q0, q1, q2, q3;
+                asm volatile("ds_read_b128 %0, %4\n\t"
+                             "ds_read_b128 %1, %4 offset:32\n\t"
+                             "ds_read_b128 %2, %4 offset:64\n\t"
+                             "ds_read_b128 %3, %4 offset:96\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+                             : "v"(root_cells));
+                const std::uint32_t bits[16] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3],
+                                                q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2], q3[3]};
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    roots[r] = __builtin_bit_cast(float, bits[r]);
+            }
+            refresh_thresholds(shared, own, roots);
+        }
+        const std::uint32_t tile_norms = lds_base + (std::uint32_t)((std::uint8_t*)(norms_r + (work_tile & 3u) * wide_rows_k + (lane & 31)) - lds);
+        std::uint32_t tile_b2[wide_blocks_k];
+        asm volatile("ds_read_b32 %0, %8\n\t"
+                     "ds_read_b32 %1, %8 offset:128\n\t"
+                     "ds_read_b32 %2, %8 offset:256\n\t"
+                     "ds_read_b32 %3, %8 offset:384\n\t"
+                     "ds_read_b32 %4, %8 offset:512\n\t"
+                     "ds_read_b32 %5, %8 offset:640\n\t"
+                     "ds_read_b32 %6, %8 offset:768\n\t"
+                     "ds_read_b32 %7, %8 offset:896\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(tile_b2[0]), "=&v"(tile_b2[1]), "=&v"(tile_b2[2]), "=&v"(tile_b2[3]), "=&v"(tile_b2[4]), "=&v"(tile_b2[5]),
+                       "=&v"(tile_b2[6]), "=&v"(tile_b2[7])
+                     : "v"(tile_norms));
+        const bool check_members = ix.has_tombstones || allow_bits != nullptr;
+#pragma unroll
+        for (int u = 0; u < wide_blocks_k; ++u) {
             const std::uint64_t my_row = tile_row + u * 32 + (lane & 31);
             bool live = my_row < last_row;
-            if (ix.has_tombstones && live)
-                live = ix.keys[my_row] != free_key_k;
-            if (allow_bits && live) // the caller's predicate, one bit per slot (index.hpp:4260-4263)
-                live = ((allow_bits[my_row >> 5] >> (my_row & 31)) & 1u) != 0;
+            if (check_members) {
+                if (ix.has_tombstones && live)
+                    live = ix.keys[my_row] != free_key_k;
+                if (allow_bits && live) // the caller's predicate, one bit per slot (index.hpp:4260-4263)
+                    live = ((allow_bits[my_row >> 5] >> (my_row & 31)) & 1u) != 0;
+            }
             const std::uint32_t b2 = tile_b2[u];
             const float row_scale = metric_ak == metric_cos_k ? bound_scale<integers>(b2) : 1.f;
             // ---- the fast test, conservative: never false for a sum whose exact distance is ≤ the bound (NaN — a zero norm —
             //      compares "may"). One multiply and one compare per sum; the compares' lane masks are ORed on the scalar unit.
+            auto may_enter = [&](int r) -> bool {
+                if constexpr (metric_ak == metric_l2sq_k)
+                    return closing_distance<metric_ak, scalar_ak>(acc[u][r], query_norm[r], b2) <= bound[r];
+                else if constexpr (metric_ak == metric_ip_k)
+                    return 1.f - (float)acc[u][r] <= bound[r];
+                else // cos: 1 − Σab/(√Σa²·√Σb²) ≤ bound + 10⁻⁵; an integer Σab = 0 closes to 0 whatever the norms
+                    return !((float)acc[u][r] * row_scale < threshold[r]) || (integers && acc[u][r] == 0);
+            };
             std::uint64_t any = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                bool candidate;
-                if constexpr (metric_ak == metric_l2sq_k) {
-                    candidate = closing_distance<metric_ak, scalar_ak>(acc[u][r], query_norm[r], b2) <= bound[r];
-                } else if constexpr (metric_ak == metric_ip_k) {
-                    candidate = 1.f - (float)acc[u][r] <= bound[r];
-                } else { // cos: 1 − Σab/(√Σa²·√Σb²) ≤ bound + 10⁻⁵; an integer Σab = 0 closes to 0 whatever the norms
-                    candidate = !((float)acc[u][r] * row_scale < threshold[r]) || (integers && acc[u][r] == 0);
-                }
-                any |= __ballot(candidate);
-            }
+            for (int r = 0; r < 16; ++r)
+                any |= __ballot(may_enter(r));
             any &= __ballot(live);
             if (any == 0)
                 continue;
             // ---- the rare path: which sums exactly, then one ordered insert at a time
             std::uint32_t may = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                bool candidate;
-                if constexpr (metric_ak == metric_l2sq_k) {
-                    candidate = closing_distance<metric_ak, scalar_ak>(acc[u][r], query_norm[r], b2) <= bound[r];
-                } else if constexpr (metric_ak == metric_ip_k) {
-                    candidate = 1.f - (float)acc[u][r] <= bound[r];
-                } else {
-                    candidate = !((float)acc[u][r] * row_scale < threshold[r]) || (integers && acc[u][r] == 0);
-                }
-                may |= (candidate ? 1u : 0u) << r;
-            }
+            for (int r = 0; r < 16; ++r)
+                may |= (may_enter(r) ? 1u : 0u) << r;
             may = live ? may & exists : 0u;
             for (int r = 0; r < 16; ++r) { // kept rolled
                 std::uint64_t pending = __ballot((may >> r) & 1u);
@@ -680,6 +730,8 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                     sum = __shfl(sum, (int)source, 64);
                     const std::uint32_t source_b2 = (std::uint32_t)__shfl((int)b2, (int)source, 64);
                     const float d = closing_distance<metric_ak, scalar_ak>(sum, norms_q[i], source_b2);
+                    if (d > limit[i]) // farther than this partition's k-th best (the test in the registers is a tile old): no list access
+                        continue;
                     const std::uint64_t cells = ((std::uint64_t)partition * query_count + first_query + i) * wanted;
                     float* entries_d = out_distances + cells;
                     std::uint32_t* entries_s = reinterpret_cast<std::uint32_t*>(out_keys + cells); // entry e: word 2e
@@ -701,66 +753,65 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                         entries_d[lane + 1] = my_d, entries_s[2 * (lane + 1)] = my_s;
                     if (lane == position)
                         entries_d[position] = d, entries_s[2 * position] = s;
-                    // the new k-th best: the newcomer if it went last, else what was second to last (or last, while growing)
+                    // the new k-th best: the newcomer if it went last, else what was second to last
                     const std::uint32_t new_last = grown - 1;
-                    const float shifted_from = __shfl(my_d, (int)(new_last ? new_last - 1 : 0), 64), stayed = __shfl(my_d, (int)new_last, 64);
-                    const float kth = position == new_last ? d : (position < new_last ? shifted_from : stayed);
+                    const float shifted = __shfl(my_d, (int)(new_last ? new_last - 1 : 0), 64);
+                    const float kth = position == new_last ? d : shifted;
                     if (lane == 0) {
                         top_n[i] = grown;
-                        limit[i] = grown == wanted ? kth : __builtin_inff();
-                        if (grown == wanted) // k rows at most this far exist: no partition needs anything farther for this query
+                        if (grown == wanted) { // k rows at most this far exist: no partition needs anything farther for this query
+                            limit[i] = kth;
                             atomicMin(shared_bounds + first_query + i, ordered_bits(kth));
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // this wave's next insert into the list reads these cells
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    changed = true;
                 }
             }
         }
-        if (__ballot(changed))
-            refresh_own_bounds(); // the thresholds follow at the head of the next tile
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < wide_blocks_k; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 acc[u][r] = 0;
     };
 
-    // ---- the pipeline: chunk c is multiplied out of buffer c mod 3 while the DMA fills the two others with chunks c + 1 and
-    //      c + 2. A wave waits until ITS fills of chunk c + 1 have landed — a counted wait: the six (seven at the head of a tile)
-    //      fills of chunk c + 2, issued later, may stay in flight — then meets the others at a bare barrier: what a buffer holds is
-    //      read one iteration after the wait + barrier that completed it, and refilled one barrier after its last read. Nothing
-    //      between the fills and the wait may make the compiler wait for the whole VM queue: no `__syncthreads()` (its fence drains
-    //      it), no compiler-visible LDS read outside `fold_tile` (once per tile).
-    std::uint32_t work_buffer = 0, fill_buffer = 0;
+    // ---- the pipeline: chunk c is multiplied out of buffer c & 1 while the DMA fills the other buffer with chunk c + 1. A wave
+    //      waits for ITS fills (the VM counter), then meets the others at a bare barrier: what a buffer holds is read one iteration
+    //      after the wait + barrier that completed it, and refilled one barrier after its last read.
     if (total) {
-        issue_fills(0);
-        if (total > 1)
-            issue_fills(1);
-        fill_buffer = 2;
-        if (total > 1)
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fill_queries(0, 0);
+        fill_queries(0, 2);
+        fill_rows(0, 0);
+        fill_rows(0, 2);
+        fill_tile_head_and_advance();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+#ifdef USEARCH_AMD_EXACT_PHASES
+    std::uint64_t phase_ticks[4] = {0, 0, 0, 0}, phase_mark = __builtin_amdgcn_s_memtime();
+#endif
     for (std::uint32_t c = 0; c < total; ++c) {
-        const bool filling = c + 2 < total;
-        multiply_chunk(work_buffer, filling, fill_buffer);
-        if (filling)
-            fill_buffer = fill_buffer == wide_buffers_k - 1 ? 0 : fill_buffer + 1;
-        work_buffer = work_buffer == wide_buffers_k - 1 ? 0 : work_buffer + 1;
+        multiply_chunk(c & 1u, c + 1 < total, (c + 1) & 1u);
+        UA_PHASE_TICK(0)
         if (++work_chunk == chunks) {
             fold_tile();
             work_chunk = 0, ++work_tile;
         }
-        if (filling)
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        UA_PHASE_TICK(1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        UA_PHASE_TICK(2)
         __builtin_amdgcn_s_barrier();
+        UA_PHASE_TICK(3)
     }
+#ifdef USEARCH_AMD_EXACT_PHASES
+    if (thread == 0) {
+        for (int phase = 0; phase < 4; ++phase)
+            atomicAdd(exact_phase_ticks + phase, (unsigned long long)phase_ticks[phase]);
+        atomicAdd(exact_phase_ticks + 4, (unsigned long long)total);
+    }
+#endif
 
     // ---- this partition's lists are already where the merge reads them, [partition][query][wanted] like the wave-per-query
     //      kernel's: slots become keys, unused cells the padding
@@ -797,7 +848,7 @@ __global__ __launch_bounds__(256) void pad_queries_kernel(const std::uint8_t* qu
 
 template <int metric_ak, int scalar_ak>
 hipError_t launch_wide(const snapshot_view_t& view, const std::uint8_t* queries, std::uint64_t query_stride,
-                       std::uint8_t* padded, std::uint32_t query_count, std::uint32_t wanted, std::uint32_t local_partitions,
+                       std::uint8_t* padded, std::uint32_t query_count, std::uint32_t wanted, std::uint32_t tiles_per_xcd, std::uint32_t workgroups,
                        std::uint64_t rows_per_partition, const std::uint32_t* row_norms, const std::uint32_t* query_norms,
                        bool map_keys, const std::uint32_t* allow_bits, std::uint32_t* shared_bounds, float* out_distances,
                        std::uint64_t* out_keys, std::uint64_t* out_counts, hipStream_t stream) {
@@ -807,14 +858,13 @@ hipError_t launch_wide(const snapshot_view_t& view, const std::uint8_t* queries,
     if (e != hipSuccess)
         return e;
     const std::uint32_t query_tiles = (query_count + wide_queries_k - 1) / wide_queries_k;
-    const std::uint32_t groups = (query_tiles + 3) / 4;
     const std::uint64_t padded_stride = wide_padded_stride(view.bytes_per_vector);
     const std::uint64_t padded_rows = (std::uint64_t)query_tiles * wide_queries_k;
     hipLaunchKernelGGL(pad_queries_kernel, dim3((unsigned)std::min<std::uint64_t>((padded_rows * padded_stride + 255) / 256, 1u << 20)),
                        dim3(256), 0, stream, queries, query_stride, query_count, (std::uint32_t)view.bytes_per_vector, padded,
                        padded_stride, padded_rows);
-    hipLaunchKernelGGL(kernel, dim3(groups * 4 * local_partitions * 8), dim3(wide_threads_k), wide_lds_bytes(), stream, view,
-                       (const std::uint8_t*)padded, padded_stride, query_count, wanted, rows_per_partition, query_tiles, local_partitions, row_norms,
+    hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(wide_threads_k), wide_lds_bytes(), stream, view,
+                       (const std::uint8_t*)padded, padded_stride, query_count, wanted, rows_per_partition, query_tiles, tiles_per_xcd, row_norms,
                        query_norms, map_keys ? 1u : 0u, allow_bits, shared_bounds, out_distances, out_keys, out_counts);
     return hipGetLastError();
 }
@@ -888,14 +938,22 @@ const char* exact_search_tiled_device(metric_kind_t metric, scalar_kind_t scalar
     const std::size_t forced_tile = env_size("USEARCH_AMD_EXACT_TILE", 0);
     const bool wide = forced_tile != 64 && wanted <= (std::size_t)wide_wanted_k && view.size >= 8u * 4u * wide_rows_k &&
                       (forced_tile == 256 || count > 512);
-    std::uint64_t partitions, rows_per_partition, local_partitions = 0;
+    std::uint64_t partitions, rows_per_partition, tiles_per_xcd = 0, workgroups = 0;
     if (wide) {
-        // partitions come in eights (one per XCD at a time, exact_wide_kernel); enough workgroups for four rounds of the chip
-        const std::uint64_t query_tiles = ((count + wide_queries_k - 1) / wide_queries_k + 3) / 4 * 4;
-        local_partitions = std::min<std::uint64_t>(32, std::max<std::uint64_t>(8, (1024 / (8 * query_tiles) + 7) / 8 * 8));
-        while (local_partitions > 1 && view.size / (local_partitions * 8) < 4 * wide_rows_k)
-            local_partitions /= 2;
-        partitions = local_partitions * 8;
+        // ONE round of the chip (32 compute units per XCD) with as few partitions as that takes (exact_wide_kernel)
+        const std::uint64_t query_tiles = (count + wide_queries_k - 1) / wide_queries_k;
+        const std::uint64_t most = std::max<std::uint64_t>(1, view.size / (4 * wide_rows_k)); // a partition is at least four tiles
+        if (query_tiles >= 8) { // tiles dealt over the XCDs, every XCD sees every partition
+            tiles_per_xcd = (query_tiles + 7) / 8;
+            partitions = std::min<std::uint64_t>(std::max<std::uint64_t>(1, 32 / tiles_per_xcd), most);
+            workgroups = 8 * tiles_per_xcd * partitions;
+        } else { // every XCD works on all the tiles, partitions ≡ xcd (mod 8)
+            tiles_per_xcd = query_tiles;
+            partitions = std::max<std::uint64_t>(8, 32 / query_tiles * 8);
+            while (partitions > 8 && partitions > most)
+                partitions -= 8;
+            workgroups = tiles_per_xcd * partitions;
+        }
         rows_per_partition = (view.size + partitions - 1) / partitions;
         rows_per_partition = (rows_per_partition + wide_rows_k - 1) / wide_rows_k * wide_rows_k;
     } else {
@@ -961,7 +1019,8 @@ const char* exact_search_tiled_device(metric_kind_t metric, scalar_kind_t scalar
             e = launch_norms<sc>(query_bytes, count, stride_bytes, view.bytes_per_vector, query_norms, stream);        \
         if (e == hipSuccess && wide)                                                                                   \
             e = launch_wide<m, sc>(view, query_bytes, stride_bytes, padded_queries, (std::uint32_t)count,              \
-                                   (std::uint32_t)wanted, (std::uint32_t)local_partitions, rows_per_partition, row_norms, query_norms,        \
+                                   (std::uint32_t)wanted, (std::uint32_t)tiles_per_xcd, (std::uint32_t)workgroups, rows_per_partition, \
+                                   row_norms, query_norms,                                                              \
                                    map_keys, allow_bits, shared_bounds, partial_distances, partial_keys, partial_counts,  \
                                    stream);                                                                         \
         else if (e == hipSuccess)                                                                                      \
@@ -981,6 +1040,18 @@ const char* exact_search_tiled_device(metric_kind_t metric, scalar_kind_t scalar
 #undef UA_TILED
     if (e != hipSuccess)
         return hip_message(e);
+#ifdef USEARCH_AMD_EXACT_PHASES
+    if (wide) {
+        unsigned long long ticks[8] = {0};
+        UA_HIP(hipStreamSynchronize(stream));
+        UA_HIP(hipMemcpyFromSymbol(ticks, HIP_SYMBOL(exact_phase_ticks), sizeof(ticks)));
+        const double chunks_done = (double)std::max<unsigned long long>(ticks[4], 1);
+        std::fprintf(stderr, "[usearch_amd] exact phases, shader-clock ticks per chunk (wave 0 of every workgroup): multiply %.0f fold %.0f "
+                             "own fills %.0f barrier %.0f\n", ticks[0] / chunks_done, ticks[1] / chunks_done, ticks[2] / chunks_done, ticks[3] / chunks_done);
+        unsigned long long zeros[8] = {0};
+        UA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(exact_phase_ticks), zeros, sizeof(zeros)));
+    }
+#endif
     if (kernel_ms)
         UA_HIP(hipEventRecord(scratch.end, stream));
     if (const char* error = merge_shards_device(partial_distances, partial_keys, partial_counts, partitions, count, wanted,
