@@ -272,6 +272,28 @@ PRESETS = {
 }
 
 
+def memory_plan(n: int, dim: int, dtype: str, connectivity: int, queries: int, k: int) -> dict:
+    """HBM one rank needs for its index of `n` vectors (the flat arrays of `snapshot_view_t`), the builder's transient
+    peak, and the batch — what `--dry` prints and what an N-GPU run is checked against before anything is allocated."""
+    row_bytes = (dim + 7) // 8 if dtype == "b1" else int(dim * DTYPE_BYTES[dtype])
+    chunks = -(-row_bytes // 16)
+    lanes = 1 if chunks == 1 else 2 if chunks <= 8 else 8
+    pitch = 16 * lanes * -(-chunks // lanes)
+    if 16 < row_bytes <= 128:  # rows of <= 128 bytes sit at a power-of-two pitch (no row straddles two lines)
+        pitch = 1 << (row_bytes - 1).bit_length()
+    m0 = 2 * connectivity
+    upper_lists = n / (connectivity - 1)  # levels are geometric with ratio 1 / M: about n / (M - 1) upper-level lists in all
+    plan = {"vectors": n * pitch, "level0_lists": n * m0 * 4, "upper_lists": int(upper_lists * connectivity * 4), "upper_refs": n * 4,
+            "keys": n * 8, "rows_inline_with_lists": n * m0 * 16 if row_bytes <= 16 else 0}
+    index_bytes = sum(plan.values())
+    # the builder holds the caller's matrix next to the index while it links (and the serialized image only on the host)
+    plan["index_bytes"] = index_bytes
+    plan["build_peak_bytes"] = index_bytes + n * row_bytes + (2 << 30)
+    plan["batch_bytes"] = queries * (row_bytes + k * 12 + 32) + (1 << 30)  # queries, results, counters + scratch slabs of a workspace
+    plan["exact_ground_truth_bytes"] = 8 * 256 * queries * k * 12  # partial lists of the exact kernel (recall check)
+    return plan
+
+
 MFMA_PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "i8": 5000.0}  # MI355X_MICROARCH.md: dense f16 / bf16 2.5 PF; i8 at twice that rate
 
 
@@ -439,6 +461,9 @@ def main() -> None:
                         help="skip re-timing the batch with the engine's placement draws switched off (roofline.frac_first_placement)")
     parser.add_argument("--exact", action="store_true",
                         help="time the exact (brute-force) search of the batch through the matrix-unit kernel instead of the graph walk")
+    parser.add_argument("--dry", action="store_true",
+                        help="no GPU work: print the per-rank memory plan of this configuration against 288 GB of HBM and the exact "
+                             "command line an N-GPU run is launched with, then exit (what the 8 x 125M recipe is checked with)")
     parser.add_argument("--config", default=None, choices=sorted(PRESETS),
                         help="one of BASELINE.json's configurations by name: " + "; ".join(f"{k} = {v['what']}" for k, v in sorted(PRESETS.items())))
     args = parser.parse_args()
@@ -446,6 +471,20 @@ def main() -> None:
         for name, value in PRESETS[args.config]["set"].items():
             if getattr(args, name) == parser.get_default(name):
                 setattr(args, name, value)
+    if args.dry:
+        plan = memory_plan(args.n, args.dim, args.dtype, args.connectivity, args.queries, args.k)
+        hbm = 288 * 10**9
+        need = max(plan["build_peak_bytes"], plan["index_bytes"] + plan["batch_bytes"] + plan["exact_ground_truth_bytes"])
+        forwarded = [a for a in sys.argv[1:] if a != "--dry"]
+        command = (f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 "
+                   f"bench.py {' '.join(forwarded)}") if args.gpus > 1 else f"python bench.py {' '.join(forwarded)}"
+        print(json.dumps({"dry_run": True, "ranks": args.gpus, "mode": "shards" if args.sharded else "replicas",
+                          "vectors_per_rank": args.n, "vectors_in_all": args.n * (args.gpus if args.sharded else 1),
+                          "per_rank_gigabytes": {name: round(value / 1e9, 2) for name, value in plan.items()},
+                          "per_rank_peak_gigabytes": round(need / 1e9, 1), "hbm_gigabytes": hbm / 1e9, "fits": need < 0.92 * hbm,
+                          "exchange_bytes_per_rank_and_step": args.queries * args.k * 12 + args.queries * 8 + 8 if args.sharded else 0,
+                          "command": command}))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_with_ranks(args.gpus)
     if args.exact:

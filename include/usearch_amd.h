@@ -113,12 +113,14 @@ USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_bytes_per_vector(usearch_amd_snap
 USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_row_stride(usearch_amd_snapshot_t snapshot);
 /** Bytes of HBM the snapshot occupies (cf. `usearch_memory_usage`, c/usearch.h:139). */
 USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_device_bytes(usearch_amd_snapshot_t snapshot);
-/** How the matrix of stored rows was placed in HBM. Where a multi-gigabyte array lands decides how fast random rows can be
- *  gathered from it (the headline walk: 45.4 … 51.9 ms for the same bytes), so the loader and the builder draw a few placements,
- *  time a dependency-free gather on each and keep the fastest (csrc/placement.hpp; USEARCH_AMD_PLACEMENT_DRAWS, default 6; arrays
- *  under USEARCH_AMD_PLACEMENT_MIN_BYTES = 1 GiB take the first). `gather_gbps` receives up to 8 rates, `*kept` which draw won. */
+/** How the matrix of stored rows was placed in HBM. Where a multi-gigabyte array lands decides how fast the walk runs over it
+ *  (the headline batch: 45.4 … 51.9 ms for the same bytes), and no synthetic probe tells the placements apart, so the loader and
+ *  the builder draw a few placements (device-to-device copies), let a short SELF-SEARCH of stored rows judge each and keep the
+ *  fastest (csrc/placement.hpp, `snapshot_t::tune_placement`; USEARCH_AMD_PLACEMENT_DRAWS, default 4, 1 = off; arrays under
+ *  USEARCH_AMD_PLACEMENT_MIN_BYTES = 1 GiB take the first). `judge_ms` receives up to 8 times in MILLISECONDS (lower is better),
+ *  `*kept` which draw won, `*probe_ms` what the draws cost in all. */
 USEARCH_AMD_EXPORT void usearch_amd_snapshot_placement(usearch_amd_snapshot_t snapshot, uint32_t* draws, uint32_t* kept,
-                                                       float* gather_gbps, float* probe_ms);
+                                                       float* judge_ms, float* probe_ms);
 /** The placement probe alone, on the resident matrix or a part of it: GB/s of a dependency-free gather of random stored rows
  *  among rows [first_row, first_row + rows) (`rows` = 0: to the end). Diagnostics (scripts/placement_study.py). */
 USEARCH_AMD_EXPORT float usearch_amd_snapshot_gather_probe(usearch_amd_snapshot_t snapshot, uint64_t first_row, uint64_t rows,

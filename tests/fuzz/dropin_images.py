@@ -4,7 +4,7 @@ import ctypes as C, os, sys
 import numpy as np
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-L = C.CDLL(os.path.join(ROOT, "usearch_amd", "lib", "libusearch_c.so"))
+L = C.CDLL(os.environ.get("USEARCH_AMD_DROPIN_LIBRARY") or os.path.join(ROOT, "usearch_amd", "lib", "libusearch_c.so"))
 err_t = C.POINTER(C.c_char_p)
 L.usearch_init.restype = C.c_void_p; L.usearch_init.argtypes = [C.c_void_p, err_t]
 L.usearch_view_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, err_t]

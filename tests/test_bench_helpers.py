@@ -44,3 +44,24 @@ def test_gpus_flag_relaunches_itself_as_ranks(monkeypatch):
     assert "--vectors" in options and len(options) > 15
     for option in options:
         get_args_parser().parse_args(["--nproc-per-node=2", bench.__file__, option, "1"])
+
+
+def test_memory_plan_and_dry_run():
+    """`bench.py --dry`: the per-rank memory plan (DESIGN.md §2's arrays) and the launcher command, without touching a GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import bench
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    headline = bench.memory_plan(10_000_000, 768, "f16", 16, 10_000, 10)
+    assert abs(headline["index_bytes"] / 1e9 - 16.8) < 0.1 and headline["rows_inline_with_lists"] == 0
+    shard = bench.memory_plan(125_000_000, 128, "b1", 16, 100_000, 10)
+    assert abs(shard["index_bytes"] / 1e9 - 84.0) < 1.0 and shard["rows_inline_with_lists"] == 125_000_000 * 32 * 16
+    c4 = bench.memory_plan(100_000_000, 96, "i8", 16, 100_000, 10)
+    assert c4["vectors"] == 100_000_000 * 128  # 96-byte rows at pitch 128
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--sharded", "--config", "c5", "--dry"],
+                         capture_output=True, text=True, timeout=120)
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["dry_run"] and line["fits"] and line["vectors_in_all"] == 1_000_000_000
+    assert "--nproc-per-node 8" in line["command"] and "--master-addr 127.0.0.1" in line["command"] and "--dry" not in line["command"]

@@ -154,3 +154,94 @@ def test_single_rank_step_needs_no_exchange():
     for i in range(Q):
         n = int(counts[i])
         assert np.array_equal(keys[i, :n], expected_keys[i, :n]) and np.array_equal(distances[i, :n], expected_distances[i, :n])
+
+
+# ---- world = 8: the shape of BASELINE config 5 (eight shards, one per GPU), uneven shards, fewer than k results in most of them,
+#      a failing rank in the middle
+
+WORLD8 = 8
+
+
+def uneven_shard_results(rank: int, checksum: int):
+    """Shards of very different sizes: rank r can return at most r results per query (rank 0 none at all), so that most queries
+    collect their k results from several shards and some end up with fewer than k in total."""
+    rng = np.random.default_rng(checksum % 1000 + 31 * rank)
+    most = min(K, rank)
+    distances = np.sort(rng.integers(0, 4, size=(Q, K)).astype(np.float32), axis=1)
+    keys = (rng.integers(0, 10_000, size=(Q, K)) * WORLD8 + rank).astype(np.uint64)
+    counts = rng.integers(0, most + 1, size=Q).astype(np.uint64)
+    if rank == 5:
+        counts[: Q // 2] = 0  # half of the queries find nothing in this shard
+    return keys, distances, counts
+
+
+def worker8(rank: int, port: int, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD8)
+    try:
+        from usearch_amd.sharded import Communicator
+        failing = {"rank": -1}
+
+        def all_gather(send: np.ndarray, receive: np.ndarray):
+            dist.all_gather_into_tensor(torch.from_numpy(receive), torch.from_numpy(send))
+
+        def broadcast(buffer: np.ndarray, root: int):
+            dist.broadcast(torch.from_numpy(buffer), src=root)
+
+        def local_search(queries: np.ndarray, count: int, wanted: int, expansion: int):
+            if rank == failing["rank"]:
+                raise MemoryError("injected: shard 3 lost its device")
+            return uneven_shard_results(rank, int(queries.astype(np.int64).sum()))
+
+        communicator = Communicator.on_host(rank, WORLD8, all_gather, broadcast, local_search)
+        queries = np.full((Q, STRIDE), 7 if rank == 2 else 1, dtype=np.uint8)  # the batch comes from rank 2 this time
+        keys = np.zeros((Q, K), dtype=np.uint64)
+        distances = np.zeros((Q, K), dtype=np.float32)
+        counts = np.zeros(Q, dtype=np.uint64)
+        stats, step = communicator.search_raw(None, queries.ctypes.data, Q, STRIDE, K, 64, 2, keys.ctypes.data,
+                                              distances.ctypes.data, counts.ctypes.data, 0, 0)
+        assert step.gathered_bytes == WORLD8 * step.block_bytes and step.exchanges == 1
+        parts = [uneven_shard_results(r, Q * STRIDE * 7) for r in range(WORLD8)]
+        expected_keys, expected_distances, expected_counts = oracle_merge(parts)
+        assert np.array_equal(counts, expected_counts)
+        assert (counts < K).any() and (counts == K).any(), "the case is meant to hold both short and full lists"
+        for i in range(Q):
+            n = int(counts[i])
+            assert n == min(K, sum(int(p[2][i]) for p in parts))
+            assert np.array_equal(keys[i, :n], expected_keys[i, :n]) and np.array_equal(distances[i, :n], expected_distances[i, :n])
+            assert np.all(keys[i, n:] == 0) and np.all(np.isnan(distances[i, n:]))
+        # a rank in the MIDDLE fails: all eight leave the step with an error, seven of them naming rank 3; then a clean step
+        failing["rank"] = 3
+        try:
+            communicator.search_raw(None, queries.ctypes.data, Q, STRIDE, K, 64, 2, keys.ctypes.data, distances.ctypes.data,
+                                    counts.ctypes.data, 0, 0)
+            raise AssertionError("the step succeeded although rank 3 failed")
+        except RuntimeError as error:
+            text = str(error)
+            assert ("injected" in text) if rank == 3 else (f"aborted by rank 3 of {WORLD8}" in text), text
+        failing["rank"] = -1
+        communicator.search_raw(None, queries.ctypes.data, Q, STRIDE, K, 64, 2, keys.ctypes.data, distances.ctypes.data,
+                                counts.ctypes.data, 0, 0)
+        assert np.array_equal(counts, expected_counts)
+        results[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_step_eight_ranks_gloo_uneven_shards_and_a_failing_middle_rank():
+    manager = mp.Manager()
+    for attempt in range(2):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        results = manager.dict()
+        try:
+            mp.spawn(worker8, args=(port, results), nprocs=WORLD8, join=True)
+            break
+        except Exception as error:  # noqa: BLE001
+            if attempt or "AssertionError" in str(error):
+                raise
+            print(f"eight-rank rendezvous failed, trying once more: {str(error)[-2000:]}", flush=True)
+    assert dict(results) == {r: True for r in range(WORLD8)}

@@ -158,7 +158,7 @@ const char* snapshot_t::grow_for_build(std::uint64_t capacity, std::uint64_t lis
     view_.upper = static_cast<const std::uint32_t*>(d_upper_);
     view_.keys = static_cast<const std::uint64_t*>(d_keys_);
     if (d_nbr0_rows_) { // laid out for the old arrays: rebuilt by the next finalize_layout
-        (void)hipFree(d_nbr0_rows_);
+        placed_free(d_nbr0_rows_); // finalize_layout allocates it with placed_malloc (possibly a mapped range)
         d_nbr0_rows_ = nullptr;
         view_.nbr0_rows = nullptr;
     }

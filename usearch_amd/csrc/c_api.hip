@@ -255,15 +255,15 @@ float usearch_amd_snapshot_latency_probe(usearch_amd_snapshot_t s, int which, us
         fail(error, hipGetErrorString(e));
     return nanoseconds;
 }
-void usearch_amd_snapshot_placement(usearch_amd_snapshot_t s, uint32_t* draws, uint32_t* kept, float* gather_gbps, float* probe_ms) {
+void usearch_amd_snapshot_placement(usearch_amd_snapshot_t s, uint32_t* draws, uint32_t* kept, float* judge_ms, float* probe_ms) {
     const placement_t& placement = as_snapshot(s)->placement();
     if (draws)
         *draws = placement.draws;
     if (kept)
         *kept = placement.kept;
-    if (gather_gbps)
+    if (judge_ms)
         for (int i = 0; i < placement_max_draws_k; ++i)
-            gather_gbps[i] = placement.gather_gbps[i];
+            judge_ms[i] = placement.judge_ms[i];
     if (probe_ms)
         *probe_ms = placement.probe_ms;
 }

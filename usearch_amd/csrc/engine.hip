@@ -318,7 +318,7 @@ const char* snapshot_t::tune_placement() {
     float best_ms = 0.f;
     if (!judge(best_ms))
         return nullptr; // cannot judge: the matrix stays where it is
-    placement_.gather_gbps[0] = best_ms;
+    placement_.judge_ms[0] = best_ms;
     placement_.draws = 1, placement_.kept = 0;
     std::vector<void*> losers; // held until the end, so that every further draw has to land somewhere else
     for (std::size_t d = 1; d < draws; ++d) {
@@ -340,7 +340,7 @@ const char* snapshot_t::tune_placement() {
         view_.vectors = static_cast<const std::uint8_t*>(candidate);
         float ms = 0.f;
         const bool judged = judge(ms);
-        placement_.gather_gbps[d] = ms;
+        placement_.judge_ms[d] = ms;
         placement_.draws = (std::uint32_t)d + 1;
         if (judged && ms < best_ms) {
             best_ms = ms;
@@ -361,7 +361,7 @@ const char* snapshot_t::tune_placement() {
     if (env_size("USEARCH_AMD_PLACEMENT_LOG", 0)) {
         std::fprintf(stderr, "[usearch_amd] matrix placement of %.2f GB, judged by a self-search of %zu stored rows: ", vectors_bytes_ / 1e9, queries);
         for (std::uint32_t i = 0; i < placement_.draws; ++i)
-            std::fprintf(stderr, "%s%.3f%s", i ? " " : "", placement_.gather_gbps[i], i == placement_.kept ? "*" : "");
+            std::fprintf(stderr, "%s%.3f%s", i ? " " : "", placement_.judge_ms[i], i == placement_.kept ? "*" : "");
         std::fprintf(stderr, " ms, %.0f ms in all\n", placement_.probe_ms);
     }
     return nullptr;
@@ -929,6 +929,13 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
     };
 
     const std::uint32_t pending = call.have_todo ? (std::uint32_t)call.todo.size() : (std::uint32_t)call.count;
+    // a team's workgroup adds its shared control block (16-byte alignment + 64 bytes) to the leader's areas: a size that only just
+    // fits the budget alone must not become a launch failure — such a batch walks with one wave per query
+    if (params.team && call.mode != scratch_global_k &&
+        (lds_bytes_for(call.mode, call.next_cap, call.hash_cap) + 15) / 16 * 16 + 64 > lds_budget) {
+        params.team = 0;
+        call.stats.variant = (std::uint32_t)params.variant + 1;
+    }
     if (call.mode != scratch_global_k) {
         if (lds_bytes_for(call.mode, call.next_cap, call.hash_cap) > lds_budget) {
             if (call.mode == scratch_lds_k)
@@ -973,7 +980,10 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
             params.lds_bytes = (std::uint32_t)lds_bytes;
             hipEvent_t begin = nullptr, end = nullptr;
             UA_HIP(hipEventCreate(&begin));
-            UA_HIP(hipEventCreate(&end));
+            if (hipError_t created = hipEventCreate(&end); created != hipSuccess) {
+                (void)hipEventDestroy(begin);
+                return hip_message(created);
+            }
             void* candidates[8] = {nullptr};
             float trial_ms[8] = {0};
             std::size_t drawn = 0;

@@ -35,7 +35,7 @@ constexpr int placement_max_draws_k = 8;
 struct placement_t {
     std::uint32_t draws = 0;                        ///< placements of the matrix tried (0 = too small to bother, or not tuned)
     std::uint32_t kept = 0;                         ///< which one was kept
-    float gather_gbps[placement_max_draws_k] = {0}; ///< milliseconds the self-search took on each draw (lower is better)
+    float judge_ms[placement_max_draws_k] = {0};    ///< milliseconds the judging self-search took on each draw (lower is better)
     float probe_ms = 0.f;                           ///< wall time the draws cost, allocation and copies included
 };
 

@@ -413,7 +413,7 @@ class Index:
         rates = (C.c_float * 8)()
         library().usearch_amd_snapshot_placement(self._handle, C.byref(draws), C.byref(kept), rates, C.byref(probe_ms))
         return {"draws": int(draws.value), "kept": int(kept.value), "probe_ms": round(float(probe_ms.value), 2),
-                "gather_gbps": [round(float(rates[i]), 1) for i in range(draws.value)]}
+                "judge_ms": [round(float(rates[i]), 3) for i in range(draws.value)]}
 
     def latency_probe(self, lists: bool = False) -> float:
         """Nanoseconds per DEPENDENT read of a random stored row (or, `lists`, of a random level-0 neighbour list)."""
