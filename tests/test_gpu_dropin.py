@@ -327,6 +327,68 @@ def test_made_filters_answer_like_the_callback(lib):
     lib.usearch_free(index, C.byref(err))
 
 
+def test_removed_slots_are_recycled(lib, reference):
+    """`usearch_add` after `usearch_remove` takes the freed slot, oldest first, and links the new member in place (index_dense.hpp:
+    1479-1511 → index_gt::update, index.hpp:2916-2999) instead of growing the index: same size, same serialized length as the
+    reference after the same calls, the new members findable, the removed ones gone — before and after the first device build."""
+    from oracle import refbind
+    err = C.c_char_p()
+    n, dims, k = 3000, 32, 10
+    data = util.make_vectors(n + 600, dims, "f32", seed=7)
+    options = Options(METRIC["cos"], None, SCALAR["f32"], dims, 16, 128, 64, False)
+    index, _ = filled_index(lib, n, dims, options=options, data=data[:n])
+    ref = refbind.RefIndex(dims, "cos", "f32", connectivity=16, expansion_add=128)
+    ref.add(np.arange(n, dtype=np.uint64), data[:n], threads=1)
+    keys = np.zeros(k, dtype=np.uint64)
+    distances = np.zeros(k, dtype=np.float32)
+    lib.usearch_search(index, ptr(data[0]), SCALAR["f32"], k, ptr(keys), ptr(distances), C.byref(err))  # the first device build
+    ok(err)
+    length_before = lib.usearch_serialized_length(index, C.byref(err))
+    reference_length_before = len(ref.save_buffer())
+    removed = list(range(100, 400))
+    for round_, (first_new, count) in enumerate([(n, 300), (n + 300, 300)]):
+        victims = removed if round_ == 0 else list(range(n, n + 300))  # second round: remove what the first round added
+        for key in victims:
+            assert lib.usearch_remove(index, key, C.byref(err)) == 1
+            ok(err)
+            ref.remove(key)
+        assert lib.usearch_size(index, C.byref(err)) == n - 300 == len(ref)
+        for i in range(count):
+            lib.usearch_add(index, first_new + i, ptr(data[first_new + i]), SCALAR["f32"], C.byref(err))
+            ok(err)  # no `usearch_reserve` beyond n: the freed slots are the room
+        ref.add(np.arange(first_new, first_new + count, dtype=np.uint64), data[first_new:first_new + count], threads=1)
+        assert lib.usearch_size(index, C.byref(err)) == n == len(ref)
+        assert lib.usearch_serialized_length(index, C.byref(err)) == length_before, "the index grew"
+        assert len(ref.save_buffer()) == reference_length_before, "the reference's did not either (levels stay with the slots)"
+        gone = set(victims)
+        found_self = 0
+        for i in range(count):
+            found = lib.usearch_search(index, ptr(data[first_new + i]), SCALAR["f32"], k, ptr(keys), ptr(distances), C.byref(err))
+            ok(err)
+            assert found == k and not (set(keys.tolist()) & gone)
+            found_self += int(keys[0] == first_new + i and distances[0] < 1e-4)
+        assert found_self >= 0.98 * count, f"only {found_self} of {count} recycled members find themselves"
+        for key in victims[:50]:
+            assert not lib.usearch_contains(index, key, C.byref(err))
+        # the rest of the index still answers like a graph: recall against brute force over the same members
+        probes = data[500:700]
+        exact_keys = np.zeros((len(probes), k), dtype=np.uint64)
+        exact_distances = np.zeros((len(probes), k), dtype=np.float32)
+        exact_counts = np.zeros(len(probes), dtype=np.uint64)
+        lib.usearch_search_exact_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                                                  C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_char_p)]
+        lib.usearch_search_exact_many(index, ptr(probes), SCALAR["f32"], len(probes), probes.strides[0], k, ptr(exact_keys),
+                                      exact_keys.strides[0], ptr(exact_distances), exact_distances.strides[0], ptr(exact_counts),
+                                      C.byref(err))
+        ok(err)
+        hits = 0
+        for i in range(len(probes)):
+            lib.usearch_search(index, ptr(probes[i]), SCALAR["f32"], k, ptr(keys), ptr(distances), C.byref(err))
+            hits += len(set(keys.tolist()) & set(exact_keys[i].tolist()))
+        assert hits / (len(probes) * k) > 0.9
+    lib.usearch_free(index, C.byref(err))
+
+
 def test_filtered_search_and_rename(lib):
     """cpp/test.cpp:1105-1145: predicate key != 0 → 10 results none 0; `false` → 0; key == 10 → exactly [10]."""
     err = C.c_char_p()

@@ -196,6 +196,18 @@ const char* snapshot_t::append_for_build(std::uint64_t first, std::uint64_t coun
     return nullptr;
 }
 
+const char* snapshot_t::overwrite_member(std::uint64_t slot, const void* vector, std::uint64_t key) {
+    if (slot >= view_.size)
+        return "No such member";
+    UA_HIP(hipSetDevice(device_));
+    std::uint8_t* row = static_cast<std::uint8_t*>(d_vectors_) + slot * view_.row_stride; // the padding behind the row stays zero
+    if (const char* e = upload_rows(row, view_.row_stride, static_cast<const std::uint8_t*>(vector), view_.bytes_per_vector,
+                                    view_.bytes_per_vector, 1))
+        return e;
+    UA_HIP(hipMemcpy(static_cast<std::uint64_t*>(d_keys_) + slot, &key, 8, hipMemcpyHostToDevice));
+    return nullptr;
+}
+
 const char* snapshot_t::set_key(std::uint64_t slot, std::uint64_t key) {
     if (slot >= view_.size && slot >= build_capacity_)
         return "No such member";
@@ -344,6 +356,38 @@ const char* builder_t::extend(const void* vectors, std::uint64_t count, std::siz
     return nullptr;
 }
 
+const char* builder_t::update(const std::uint32_t* slots, std::uint64_t count, const void* vectors, std::size_t stride,
+                              const std::uint64_t* keys) {
+    if (!count)
+        return nullptr;
+    if (!slots || !vectors || !keys)
+        return "Nothing to update";
+    if (stride < bytes_per_vector(scalar_, dimensions_))
+        return "Stride is smaller than one vector";
+    if (identity_keys_) {
+        keys_.resize(size_);
+        for (std::uint64_t i = 0; i < size_; ++i)
+            keys_[i] = i;
+        identity_keys_ = false;
+    }
+    for (std::uint64_t i = 0; i < count; ++i) {
+        if (slots[i] >= size_)
+            return "No such member";
+        keys_[slots[i]] = keys[i];
+        if (const char* e = snapshot_.overwrite_member(slots[i], static_cast<const std::uint8_t*>(vectors) + i * stride, keys[i]))
+            return e;
+    }
+    snapshot_.suspend_layout(); // lists change from here on
+    if (const char* e = link_range(size_, size_, slots, count))
+        return e;
+    snapshot_.set_frontier(size_, entry_slot_, max_level_);
+    bool tombstones = false;
+    for (std::uint64_t key : keys_)
+        tombstones |= key == free_key_k;
+    snapshot_.set_tombstones(tombstones);
+    return snapshot_.finalize_layout();
+}
+
 const char* builder_t::set_key(std::uint64_t slot, std::uint64_t key) {
     if (slot >= size_)
         return "No such member";
@@ -358,8 +402,9 @@ const char* builder_t::set_key(std::uint64_t slot, std::uint64_t key) {
 }
 
 /// Links members [begin, end) into the graph of the members before them, batch by batch.
-const char* builder_t::link_range(std::uint64_t begin, const std::uint64_t end_total) {
-    if (begin >= end_total)
+const char* builder_t::link_range(std::uint64_t begin, const std::uint64_t end_total, const std::uint32_t* relinked,
+                                  std::uint64_t relinked_count) {
+    if (begin >= end_total && !relinked_count)
         return nullptr;
     const metric_kind_t metric = metric_;
     const scalar_kind_t scalar = scalar_;
@@ -430,21 +475,22 @@ const char* builder_t::link_range(std::uint64_t begin, const std::uint64_t end_t
     std::vector<std::uint64_t> host_counters(max_batch);
     const std::uint32_t resident = (std::uint32_t)snapshot_.compute_units() * 8;
 
-    while (begin < end_total) {
-        const std::uint64_t limit = std::max<std::uint64_t>(1, std::min<std::uint64_t>(max_batch, begin / config_.batch_divisor));
-        const std::uint64_t end = std::min<std::uint64_t>(end_total, begin + limit);
+    /// One batch: `batch` slots are linked into the graph of the first `frontier` members, level by level. `relink` = the members
+    /// exist already (their slots are being recycled, index_gt::update, index.hpp:2916-2999): each keeps its level, routes through
+    /// its own stale inbound links but never becomes its own candidate (`search_to_update_`).
+    auto link_batch = [&](const std::vector<std::uint32_t>& batch, std::uint64_t frontier, bool relink) -> const char* {
         std::uint32_t batch_top = 0;
-        for (std::uint64_t i = begin; i < end; ++i)
+        for (std::uint32_t i : batch)
             batch_top = std::max<std::uint32_t>(batch_top, (std::uint32_t)levels_[i]);
         const std::uint32_t linked_top = std::min(batch_top, max_level_);
-        snapshot_.set_frontier(begin, entry_slot_, max_level_);
+        snapshot_.set_frontier(frontier, entry_slot_, max_level_);
 
         // bottom-up: the search on level l reads level l and the levels above it, none of which this batch has touched yet
         for (std::uint32_t level = 0; level <= linked_top; ++level) {
             nodes.clear();
-            for (std::uint64_t i = begin; i < end; ++i)
+            for (std::uint32_t i : batch)
                 if ((std::uint32_t)levels_[i] >= level)
-                    nodes.push_back((std::uint32_t)i);
+                    nodes.push_back(i);
             if (nodes.empty())
                 continue;
             const std::uint32_t pass_count = (std::uint32_t)nodes.size();
@@ -457,6 +503,7 @@ const char* builder_t::link_range(std::uint64_t begin, const std::uint64_t end_t
             extras.beam_level = level;
             extras.emit_slots = true;
             extras.reference_frontier = true; // builds stay byte-for-byte reproducible against the reference-shaped oracle
+            extras.exclude_own = relink;
             search_stats_t search_stats;
             if (const char* e = snapshot_.search_device(view.vectors, pass_count, view.row_stride, ef, ef, d_cand_slots_,
                                                         d_cand_distances_, d_cand_counts_, d_visited_, d_computed_, stream,
@@ -528,14 +575,33 @@ const char* builder_t::link_range(std::uint64_t begin, const std::uint64_t end_t
             ++stats_.passes;
         }
         if (batch_top > max_level_) { // index.hpp:2874-2877: a taller node becomes the entry point
-            for (std::uint64_t i = begin; i < end; ++i)
+            for (std::uint32_t i : batch)
                 if ((std::uint32_t)levels_[i] == batch_top) {
-                    entry_slot_ = (std::uint32_t)i;
+                    entry_slot_ = i;
                     break;
                 }
             max_level_ = batch_top;
         }
         ++stats_.batches;
+        return nullptr;
+    };
+
+    std::vector<std::uint32_t> batch;
+    if (relinked) { // members whose slots were recycled: they are in the graph already, and see all of it
+        for (std::uint64_t offset = 0; offset < relinked_count; offset += max_batch) {
+            batch.assign(relinked + offset, relinked + std::min<std::uint64_t>(relinked_count, offset + max_batch));
+            if (const char* e = link_batch(batch, size_, true))
+                return e;
+        }
+    }
+    while (begin < end_total) {
+        const std::uint64_t limit = std::max<std::uint64_t>(1, std::min<std::uint64_t>(max_batch, begin / config_.batch_divisor));
+        const std::uint64_t end = std::min<std::uint64_t>(end_total, begin + limit);
+        batch.clear();
+        for (std::uint64_t i = begin; i < end; ++i)
+            batch.push_back((std::uint32_t)i);
+        if (const char* e = link_batch(batch, begin, false))
+            return e;
         begin = end;
     }
     unsigned long long counters[4] = {0, 0, 0, 0};

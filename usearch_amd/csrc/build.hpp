@@ -66,6 +66,16 @@ class builder_t {
     const char* extend(const void* vectors, std::uint64_t count, std::size_t stride, bool vectors_on_device,
                        const std::uint64_t* keys, bool exact_capacity = false);
 
+    /**
+     *  Replaces members in place — what `usearch_add` does with a slot a `usearch_remove` freed (index_dense.hpp:1479-1511 pushes the
+     *  slot into `free_keys_`, `add_` pops it and calls `index_gt::update`, index.hpp:2916-2999): member `slots[i]` gets vector i
+     *  (host memory, `stride` bytes apart) and `keys[i]`, keeps its level, and is linked anew — insertion search that never names
+     *  the member itself (`search_to_update_`), `form_links_to_closest_`, `form_reverse_links_`. Links other members still hold
+     *  to the slot stay, as in the reference.
+     */
+    const char* update(const std::uint32_t* slots, std::uint64_t count, const void* vectors, std::size_t stride,
+                       const std::uint64_t* keys);
+
     /// Renames a member in place; `free_key_k` makes it a tombstone (index_dense.hpp:1479-1511: it keeps routing, stops
     /// matching). No relinking.
     const char* set_key(std::uint64_t slot, std::uint64_t key);
@@ -79,7 +89,8 @@ class builder_t {
     const char* save_buffer(void* buffer, std::size_t length);
 
   private:
-    const char* link_range(std::uint64_t begin, std::uint64_t end);
+    const char* link_range(std::uint64_t begin, std::uint64_t end, const std::uint32_t* relinked = nullptr,
+                           std::uint64_t relinked_count = 0);
     void release_workspace();
 
     snapshot_t snapshot_;

@@ -133,6 +133,9 @@ struct search_args_t {
                                     ///< `beam_level` and report the member it reached (one result per query)
     const std::uint32_t* allow_bits; ///< optional: one bit per slot, 0 = the caller's predicate rejects that member
                                      ///< (`usearch_filtered_search`, index_dense.hpp:2071-2081)
+    std::uint32_t exclude_own;       ///< 1 = query q's own stored row (`query_ids[q]`) routes but never becomes a result candidate:
+                                     ///< `search_to_update_` (index.hpp:4087-4170), the insertion search of a member that is
+                                     ///< being re-linked in place
     unsigned long long* phases;     ///< optional [8] diagnostic: shader-clock ticks per phase summed over all waves
     std::uint32_t team_offset;      ///< team_search_kernel: where in the workgroup's LDS the shared `team_t` sits
     unsigned long long* wave_clock; ///< optional [grid][2] telemetry: 100-MHz wall clock at the start and the exit of every

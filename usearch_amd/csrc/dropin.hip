@@ -150,8 +150,12 @@ struct index_t {
     /// index_dense.hpp:1984-2000); everything that changes the index, or links pending members, takes it alone.
     std::shared_mutex mutex;
     std::size_t threads_search = 0; ///< `usearch_change_threads_search`: batches in flight at once (0 = the engine's default)
-    /// `USEARCH_AMD_COALESCE=1` (read when the index is created): `usearch_search` calls in flight share a launch (combiner.hpp)
-    bool coalesce = env_size("USEARCH_AMD_COALESCE", 0) != 0;
+    /// `usearch_search` calls in flight share a launch (combiner.hpp): whoever finds nobody launching takes every compatible call
+    /// that is waiting and runs them as one batch. A lone caller is untouched (3.5 ms / 0.34 ms per call at ef 608 / 64 on the
+    /// headline index either way); 16 callers at ef 608: 939 → 2 207 calls per second, 64 callers: 1 696 → 8 148 (latency 37.7 →
+    /// 7.9 ms), 64 callers at ef 64: 9.6 k → 47.7 k (profiles/r04_single_query/coalesce.log). `USEARCH_AMD_COALESCE=0` (read when the
+    /// index is created) turns it off.
+    bool coalesce = env_size("USEARCH_AMD_COALESCE", 1) != 0;
     combiner_t combiner;
     // configuration — `usearch_init_options_t`, c/usearch.h:64-110
     metric_kind_t metric = metric_cos_k;
@@ -175,6 +179,11 @@ struct index_t {
     std::vector<std::uint64_t> keys;
     std::vector<std::uint8_t> vectors; ///< storage scalar kind, `bytes_per_vector` per slot
     builder_t* builder = nullptr;      ///< device index linked from the staging arrays (null = stale)
+    /// Slots `usearch_remove` freed, oldest first — the reference's `free_keys_` ring (index_dense.hpp:507, 1479-1511): the next
+    /// `usearch_add` takes the oldest instead of a new slot, and the member is linked anew in place (`builder_t::update`).
+    std::vector<std::uint32_t> free_slots;
+    std::size_t free_head = 0;
+    std::vector<std::uint32_t> recycled; ///< reused slots whose device copy still holds the member that was removed
 
     // key → slots, rebuilt lazily
     std::unordered_multimap<std::uint64_t, std::uint32_t> lookup;
@@ -221,6 +230,7 @@ struct index_t {
         multi = parsed.multi;
         staged = false;
         keys.clear(), vectors.clear();
+        free_slots.clear(), free_head = 0, recycled.clear();
         lookup_valid = false;
         capacity = std::max<std::size_t>(capacity, (std::size_t)parsed.size);
         return nullptr;
@@ -244,6 +254,10 @@ struct index_t {
             image_keys(keys);
             vectors.assign(image.vectors, image.vectors + (std::size_t)image.size * image.cols);
         }
+        free_slots.clear(), free_head = 0, recycled.clear();
+        for (std::size_t slot = 0; slot < keys.size(); ++slot) // what `reindex_keys_` does after a load (index_dense.hpp:2162-2200)
+            if (keys[slot] == free_key_k)
+                free_slots.push_back((std::uint32_t)slot);
         staged = true;
         drop_device();
         drop_image();
@@ -273,7 +287,7 @@ struct index_t {
     /// Is the device index up to date with the host-side content? (Shared lock suffices to ask.)
     bool device_current() const {
         if (staged)
-            return keys.empty() || (builder && builder->size() == keys.size());
+            return keys.empty() || (builder && builder->size() == keys.size() && recycled.empty());
         return !has_image || snapshot != nullptr;
     }
     snapshot_t* device_index() { return staged ? (builder ? &builder->snapshot() : nullptr) : snapshot; }
@@ -297,7 +311,28 @@ struct index_t {
                     return e;
                 }
                 builder = fresh;
-            } else if (builder && builder->size() < keys.size()) {
+                recycled.clear(); // a build from the staging arrays has every member as it is now
+            } else if (builder && !recycled.empty()) {
+                // slots a removal freed and an add took over: the members the device still holds there are replaced and linked anew
+                // (index_gt::update); slots beyond what is linked are simply part of the members still to come
+                std::vector<std::uint32_t> slots;
+                std::vector<std::uint64_t> new_keys;
+                std::vector<std::uint8_t> rows;
+                std::sort(recycled.begin(), recycled.end());
+                recycled.erase(std::unique(recycled.begin(), recycled.end()), recycled.end());
+                for (std::uint32_t slot : recycled)
+                    if (slot < builder->size() && keys[slot] != free_key_k) {
+                        slots.push_back(slot);
+                        new_keys.push_back(keys[slot]);
+                        rows.insert(rows.end(), vectors.data() + (std::size_t)slot * bpv(), vectors.data() + (std::size_t)(slot + 1) * bpv());
+                    }
+                if (const char* e = builder->update(slots.data(), slots.size(), rows.data(), bpv(), new_keys.data())) {
+                    delete builder, builder = nullptr;
+                    return e;
+                }
+                recycled.clear();
+            }
+            if (builder && builder->size() < keys.size()) {
                 const std::size_t linked = (std::size_t)builder->size();
                 if (const char* e = builder->extend(vectors.data() + linked * bpv(), keys.size() - linked, bpv(), false,
                                                     keys.data() + linked)) {
@@ -753,20 +788,31 @@ void usearch_add(usearch_index_t handle, usearch_key_t key, void const* vector, 
             return fail(error, "Free key is reserved");
         if (!index.dimensions || !index.bpv())
             return fail(error, "Index is not initialized");
-        if (index.size() >= index.capacity) // index.hpp:2812-2818: the reference does not grow on its own either
-            return fail(error, "Reserve capacity ahead of insertions!");
+        if (index.size() >= index.capacity && !(index.staged && index.free_head < index.free_slots.size()))
+            return fail(error, "Reserve capacity ahead of insertions!"); // index.hpp:2812-2818: no growth on its own; a freed slot is room
         if (!index.multi && index.key_lookup().count(key))
             return fail(error, "Duplicate keys not allowed in high-level wrappers");
         index.materialize();
-        const std::size_t bpv = index.bpv(), slot = index.keys.size();
+        const std::size_t bpv = index.bpv();
+        // a slot that a removal freed is taken first, oldest first (index_dense.hpp:1479-1511: `free_keys_.try_pop`)
+        const bool reuse = index.free_head < index.free_slots.size();
+        const std::size_t slot = reuse ? index.free_slots[index.free_head++] : index.keys.size();
         if (slot + 1 >= none_slot_k)
             return fail(error, "Index is too large for 32-bit slots");
-        index.vectors.resize((slot + 1) * bpv);
+        if (!reuse)
+            index.vectors.resize((slot + 1) * bpv);
         std::uint8_t* target = index.vectors.data() + slot * bpv;
         std::memset(target, 0, bpv);
         if (!cast_vector(kind, index.scalar, static_cast<const std::uint8_t*>(vector), index.dimensions, target))
             std::memcpy(target, vector, bpv);
-        index.keys.push_back(key);
+        if (reuse) {
+            index.keys[slot] = key;
+            index.recycled.push_back((std::uint32_t)slot);
+            if (index.free_head == index.free_slots.size())
+                index.free_slots.clear(), index.free_head = 0;
+        } else {
+            index.keys.push_back(key);
+        }
         ++index.version;
         if (index.lookup_valid)
             index.lookup.emplace(key, (std::uint32_t)slot);
@@ -1016,6 +1062,7 @@ size_t usearch_remove(usearch_index_t handle, usearch_key_t key, usearch_error_t
         for (auto it = range.first; it != range.second; ++it, ++removed) {
             // a tombstone: the member keeps routing, stops matching (index_dense.hpp:1479-1511)
             index.keys[it->second] = free_key_k;
+            index.free_slots.push_back(it->second);
             ++index.version;
             if (index.builder && it->second < index.builder->size()) // in place on the device too: nothing is relinked
                 if (const char* e = index.builder->set_key(it->second, free_key_k))
@@ -1092,6 +1139,7 @@ void usearch_clear(usearch_index_t handle, usearch_error_t* error) {
         index.drop_device();
         index.drop_image();
         index.keys.clear(), index.vectors.clear();
+        index.free_slots.clear(), index.free_head = 0, index.recycled.clear();
         index.staged = false;
         index.lookup.clear(), index.lookup_valid = false;
     });

@@ -751,7 +751,7 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
     // ---- who holds the frontier (kernels.hpp frontier_mode_t): the open cells of `top` wherever that is exact up to ties —
     // float-valued pair, `top` in registers, every member a result candidate, slots below 2^31 — else the reference's heap
     const std::uint32_t frontier_request = tuning.frontier ? tuning.frontier : (std::uint32_t)env_size("USEARCH_AMD_FRONTIER", 0);
-    const bool filtered = view_.has_tombstones || (extras && extras->allow_bits);
+    const bool filtered = view_.has_tombstones || (extras && (extras->allow_bits || extras->exclude_own));
     const bool in_top_possible = frontier_in_top_capable(scalar_) && entries_per_lane && !filtered && mode_request != 3 &&
                                  view_.size < 0x80000000ull && !(extras && (extras->reference_frontier || extras->descent_only));
     if (frontier_request == 2 && !in_top_possible)
@@ -859,6 +859,7 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
         args.emit_slots = extras->emit_slots ? 1u : 0u;
         args.descent_only = extras->descent_only ? 1u : 0u;
         args.allow_bits = extras->allow_bits;
+        args.exclude_own = extras->exclude_own ? 1u : 0u;
     }
 
     launch_params_t& params = call.params;

@@ -58,6 +58,7 @@ struct search_extras_t {
     bool descent_only = false;                ///< `cluster`: the greedy descent to `beam_level` alone, one result per query
     const std::uint32_t* allow_bits = nullptr; ///< device: one bit per slot, 0 = rejected by the caller's predicate
     bool reference_frontier = false;          ///< keep the reference's heap whatever the pair (index construction does)
+    bool exclude_own = false;                 ///< `search_to_update_`: a query's own stored row routes, never becomes a candidate
 };
 
 /// Per-scalar-kind launchers, one translation unit each (compile time): defined in search_<kind>.hip.
@@ -180,6 +181,8 @@ class snapshot_t {
     /// Uploads members [first, first + count): rows (re-pitched), keys (null = the slot number), upper-list references.
     const char* append_for_build(std::uint64_t first, std::uint64_t count, const std::uint32_t* upper_refs,
                                  const void* vectors, std::size_t stride, bool vectors_on_device, const std::uint64_t* keys);
+    /// Overwrites one member's stored row (host memory, storage kind) and key in HBM: a recycled slot (builder_t::update).
+    const char* overwrite_member(std::uint64_t slot, const void* vector, std::uint64_t key);
     /// Overwrites one member's key in HBM (rename; `free_key_k` = tombstone).
     const char* set_key(std::uint64_t slot, std::uint64_t key);
     std::uint64_t build_capacity() const { return build_capacity_; }

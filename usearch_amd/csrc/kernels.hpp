@@ -1205,10 +1205,10 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     // index_dense.hpp:2071-2081: a member is a result candidate unless it is a tombstone or the caller's predicate
     // (evaluated on the host into one bit per slot) rejects it; it is traversed either way
     auto allowed = [&](std::uint32_t slot) -> bool {
-        if (!ix.has_tombstones && !args.allow_bits)
+        if (!ix.has_tombstones && !args.allow_bits && !args.exclude_own)
             return true;
-        bool ok = true;
-        if (ix.has_tombstones)
+        bool ok = !(args.exclude_own && slot == (std::uint32_t)query_row); // index.hpp:4111, 4161: `updated_slot` never enters `top`
+        if (ok && ix.has_tombstones)
             ok = ix.keys[slot] != free_key_k;
         if (ok && args.allow_bits)
             ok = ((args.allow_bits[slot >> 5] >> (slot & 31)) & 1u) != 0;
