@@ -404,7 +404,7 @@ def run_exact(args) -> None:
             "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic (seeded rank-32 latent + 0.05 noise, out-of-sample queries)",
             "config": {"workload": workload, "vectors": args.n, "dimensions": args.dim, "parallelism": f"replicas{world}",
-                       "kernel": "exact_wide_kernel (256 queries x 128 rows per workgroup) + row / query norms + partition merge",
+                       "kernel": "exact_wide_kernel (256 queries x 256 rows per workgroup, LDS-DMA staging, one round of the chip) + row / query norms + partition merge",
                        "checked_against_bit_exact_kernel": {"queries": checked, "keys_equal": same_keys,
                                                             "distance_bits_equal": same_bits, "max_abs_difference": worst},
                        "sources": source_hash()},
@@ -944,7 +944,10 @@ def main() -> None:
                        "index_build": build_stats, "kernel_passes": passes,
                        "kernel_passes_by_expansion": {str(ef): n for ef, n in sorted(sweep_passes.items())},
                        "scratch_mode": {1: "lds", 2: "global-hash", 3: "global"}.get(stats.mode, "?"),
-                       "frontier": {1: "heap", 2: "in-top"}.get(stats.frontier, "?"), "kernel_build": stats.variant,
+                       "frontier": {1: "heap", 2: "in-top"}.get(stats.frontier, "?"),
+                       # usearch_amd_stats_t::variant: 1 / 2 / 3 = 4 / 8 / 12 row loads in flight per lane, 4 = two rows per lane group
+                       # per round (2 x 12 loads), 5 = four waves per query (small batches)
+                       "kernel_variant": stats.variant,
                        "persistent_waves": stats.grid, "lds_bytes_per_wave": stats.lds_bytes,
                        "rows_inline_with_lists": bool(index.inline_rows),
                        "batch_tail_idle": float(np.mean(tails)) if args.wave_clock else None,
