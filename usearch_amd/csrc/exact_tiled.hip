@@ -336,8 +336,12 @@ constexpr int wide_fills_k = wide_stage_rows_k / 8 / (wide_threads_k / 64);     
 inline std::uint64_t wide_padded_stride(std::uint64_t bytes_per_vector) {
     return (bytes_per_vector + chunk_bytes_k - 1) / chunk_bytes_k * chunk_bytes_k;
 }
-constexpr std::uint32_t wide_lds_bytes() {
-    return wide_buffers_k * wide_stage_bytes_k + wide_queries_k * 4 * 4 + 4 * wide_rows_k * 4 + 4 * 512 * 4;
+/// Results per query up to which the lists fit LDS next to the two staging buffers (an insert is then an LDS affair of a few
+/// hundred cycles instead of a global round trip and a fence: the epilogue and, through it, the barrier shrink).
+constexpr int wide_lds_lists_k = 10;
+constexpr std::uint32_t wide_lds_bytes(bool lds_lists, std::uint32_t wanted) {
+    return wide_buffers_k * wide_stage_bytes_k + wide_queries_k * 4 * 4 + 2 * wide_rows_k * 4 + 2 * 512 * 4 +
+           (lds_lists ? wide_queries_k * wanted * 8 : 0);
 }
 
 /// A float as an unsigned integer of the same order (negative distances exist: 1 − Σab), so that `atomicMin` keeps the smallest.
@@ -399,7 +403,7 @@ using lds_bytes_t = __attribute__((address_space(3))) void*;
  *  Same lists as the 64-query kernel: the best `wanted` under (distance ↑, slot ↓), whatever the order of arrival; a partition may
  *  hold fewer than `wanted` of them (the merge takes counts).
  */
-template <int metric_ak, int scalar_ak>
+template <int metric_ak, int scalar_ak, bool lds_lists_ak>
 __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapshot_view_t ix, const std::uint8_t* padded_queries,
                                                                     std::uint64_t padded_stride, std::uint32_t query_count,
                                                                     std::uint32_t wanted, std::uint64_t rows_per_partition,
@@ -418,10 +422,12 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
     float* roots_q = reinterpret_cast<float*>(norms_q + wide_queries_k); // [256] cos: √Σa², NaN for a zero norm ("always the exact path")
     float* limit = roots_q + wide_queries_k; // [256] THIS partition's k-th best per query (+inf while its list is filling): felt from
                                              // the next tile on, where the shared bound arrives a tile or two late
-    std::uint32_t* norms_r = reinterpret_cast<std::uint32_t*>(limit + wide_queries_k); // [4][256] Σb² of the rows of the tile being multiplied / being fetched (a
-                                                       // tile of one chunk is fetched a tile ahead): slot = tile mod 4
-    std::uint32_t* others = norms_r + 4 * wide_rows_k; // [4][8][64] the queries' shared bounds as fetched with the tile (same
+    std::uint32_t* norms_r = reinterpret_cast<std::uint32_t*>(limit + wide_queries_k); // [2][256] Σb² of the rows of the tile being multiplied / being fetched
+                                                       // (fills run one chunk ahead: the next tile at most): slot = tile mod 2
+    std::uint32_t* others = norms_r + 2 * wide_rows_k; // [2][8][64] the queries' shared bounds as fetched with the tile (same
                                                        // slots): a fill writes 64 cells, a wave's 32 queries twice
+    float* lists_d = reinterpret_cast<float*>(others + 2 * 512);                        // with `lds_lists_ak`: [256][wanted] distances
+    std::uint32_t* lists_s = reinterpret_cast<std::uint32_t*>(lists_d + wide_queries_k * wanted); // … and slots
 
     const std::uint32_t thread = threadIdx.x, wave = thread / 64, lane = thread % 64;
     // ---- which (query tile, partition) this workgroup is (wide_plan): workgroups go to the XCDs round-robin by their linear
@@ -471,8 +477,10 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
         for (int r = 0; r < 16; ++r) {
             const float other = from_ordered_bits(shared[r]);
             bound[r] = other < own[r] ? other : own[r]; // a NaN ("nothing published") keeps our own
-            if constexpr (metric_ak == metric_cos_k) // −inf while nobody has k results yet: everything may enter
-                threshold[r] = (exists >> r) & 1u ? (1.f - (bound[r] + 1e-5f)) * roots[r] : __builtin_inff();
+            if constexpr (metric_ak == metric_cos_k) { // −inf while nobody has k results yet: everything may enter; −inf too for a
+                const float product = (1.f - (bound[r] + 1e-5f)) * roots[r]; // query of zero norm (its root is a NaN): the exact path
+                threshold[r] = (exists >> r) & 1u ? (product == product ? product : -__builtin_inff()) : __builtin_inff();
+            }
         }
     };
 
@@ -515,11 +523,11 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
         if (fetch_chunk == 0) { // this wave's 32 queries' shared bounds as they stand now (lanes 32 … 63 repeat them), same DMA
             const std::uint32_t q = first_query + wave * 32 + (lane & 31);
             __builtin_amdgcn_global_load_lds((global_bytes_t)(shared_bounds + (q < query_count ? q : query_count - 1)),
-                                             (lds_bytes_t)(others + (fetch_tile & 3u) * 512 + wave * 64), 4, 0, 0);
+                                             (lds_bytes_t)(others + (fetch_tile & 1u) * 512 + wave * 64), 4, 0, 0);
             if (wave < wide_rows_k / 64) { // the tile's Σb², 64 per wave
                 const std::uint64_t wanted_row = first_row + (std::uint64_t)fetch_tile * wide_rows_k + wave * 64 + lane;
                 __builtin_amdgcn_global_load_lds((global_bytes_t)(row_norms + (wanted_row < last_row ? wanted_row : last_row - 1)),
-                                                 (lds_bytes_t)(norms_r + (fetch_tile & 3u) * wide_rows_k + wave * 64), 4, 0, 0);
+                                                 (lds_bytes_t)(norms_r + (fetch_tile & 1u) * wide_rows_k + wave * 64), 4, 0, 0);
             }
         }
         query_source += chunk_bytes_k, fetch_byte += chunk_bytes_k;
@@ -569,8 +577,11 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
 #define UA_AWAIT(still_in_flight, a, b0, b1, b2, b3)                                                                                   \
     asm volatile("s_waitcnt lgkmcnt(" #still_in_flight ")" : "+v"(a), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
     /// Multiplies the chunk in `buffer`; with `filling`, the next chunk goes into `target` meanwhile, a part of its fills behind each
-    /// step's MFMAs.
-    auto multiply_chunk = [&](std::uint32_t buffer, bool filling, std::uint32_t target) {
+    /// step's MFMAs. `fresh` (a tile's first chunk): the first step's MFMAs take a literal zero as their addend — the accumulators
+    /// are never cleared by moves.
+    auto multiply_chunk = [&](auto fresh_tag, std::uint32_t buffer, bool filling, std::uint32_t target) {
+        constexpr bool fresh = decltype(fresh_tag)::value;
+        const accumulator_t zero = {};
         const std::uint32_t buffer_bytes = buffer * wide_stage_bytes_k;
         u32x4_t a_even, a_odd, l0, l1, l2, l3, h0, h1, h2, h3;
         UA_REQUEST_QUERY(a_even, 0)
@@ -579,10 +590,10 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
         __builtin_amdgcn_s_setprio(1);
 #define UA_STEP(a_now, a_next, step, has_next, fill_statement)                                                                         \
         UA_AWAIT(4, a_now, l0, l1, l2, l3) /* the query fragment and the low half are there; the high half may be in flight */       \
-        acc[0] = product(a_now, l0, acc[0]);                                                                                           \
-        acc[1] = product(a_now, l1, acc[1]);                                                                                           \
-        acc[2] = product(a_now, l2, acc[2]);                                                                                           \
-        acc[3] = product(a_now, l3, acc[3]);                                                                                           \
+        acc[0] = product(a_now, l0, fresh && (step) == 0 ? zero : acc[0]);                                                             \
+        acc[1] = product(a_now, l1, fresh && (step) == 0 ? zero : acc[1]);                                                             \
+        acc[2] = product(a_now, l2, fresh && (step) == 0 ? zero : acc[2]);                                                             \
+        acc[3] = product(a_now, l3, fresh && (step) == 0 ? zero : acc[3]);                                                             \
         if (has_next) {                                                                                                                \
             UA_REQUEST_QUERY(a_next, (step) + 1)                                                                                       \
             UA_REQUEST_ROWS(l0, l1, l2, l3, 0, (step) + 1)                                                                             \
@@ -590,10 +601,10 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
         } else {                                                                                                                       \
             UA_AWAIT(0, a_now, h0, h1, h2, h3)                                                                                         \
         }                                                                                                                              \
-        acc[4] = product(a_now, h0, acc[4]);                                                                                           \
-        acc[5] = product(a_now, h1, acc[5]);                                                                                           \
-        acc[6] = product(a_now, h2, acc[6]);                                                                                           \
-        acc[7] = product(a_now, h3, acc[7]);                                                                                           \
+        acc[4] = product(a_now, h0, fresh && (step) == 0 ? zero : acc[4]);                                                             \
+        acc[5] = product(a_now, h1, fresh && (step) == 0 ? zero : acc[5]);                                                             \
+        acc[6] = product(a_now, h2, fresh && (step) == 0 ? zero : acc[6]);                                                             \
+        acc[7] = product(a_now, h3, fresh && (step) == 0 ? zero : acc[7]);                                                             \
         if (has_next) {                                                                                                                \
             UA_REQUEST_ROWS(h0, h1, h2, h3, 4, (step) + 1)                                                                             \
         }                                                                                                                              \
@@ -619,7 +630,7 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
         // the tile's Σb² and the shared bounds by hand-waited reads, like the fragments: a compiler-visible LDS read here would
         // drain the fills in flight. Registers 4j … 4j + 3 ↔ queries 8j + 4·(lane >> 5) + 0 … 3
         {
-            const std::uint32_t cells = lds_base + (std::uint32_t)((std::uint8_t*)(others + (work_tile & 3u) * 512 + wave * 64 + 4 * (lane >> 5)) - lds);
+            const std::uint32_t cells = lds_base + (std::uint32_t)((std::uint8_t*)(others + (work_tile & 1u) * 512 + wave * 64 + 4 * (lane >> 5)) - lds);
             u32x4_t s0, s1, s2, s3;
             asm volatile("ds_read_b128 %0, %4\n\t"
                          "ds_read_b128 %1, %4 offset:32\n\t"
@@ -666,7 +677,7 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
             }
             refresh_thresholds(shared, own, roots);
         }
-        const std::uint32_t tile_norms = lds_base + (std::uint32_t)((std::uint8_t*)(norms_r + (work_tile & 3u) * wide_rows_k + (lane & 31)) - lds);
+        const std::uint32_t tile_norms = lds_base + (std::uint32_t)((std::uint8_t*)(norms_r + (work_tile & 1u) * wide_rows_k + (lane & 31)) - lds);
         std::uint32_t tile_b2[wide_blocks_k];
         asm volatile("ds_read_b32 %0, %8\n\t"
                      "ds_read_b32 %1, %8 offset:128\n\t"
@@ -704,10 +715,25 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                     return !((float)acc[u][r] * row_scale < threshold[r]) || (integers && acc[u][r] == 0);
             };
             std::uint64_t any = 0;
+            if constexpr (metric_ak == metric_cos_k && !integers) {
+                // 16 fused multiply-adds Σab·rsq(Σb²) − threshold, their maximum by eight three-way maxima, ONE compare: a NaN — a
+                // row of zero norm — is "may" (`!(m < 0)`); queries of zero norm carry −inf as their threshold
+                float t[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                any |= __ballot(may_enter(r));
-            any &= __ballot(live);
+                for (int r = 0; r < 16; ++r)
+                    t[r] = __builtin_fmaf(acc[u][r], row_scale, -threshold[r]);
+                const float m = __builtin_fmaxf(
+                    __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(t[0], t[1]), __builtin_fmaxf(t[2], t[3])),
+                                    __builtin_fmaxf(__builtin_fmaxf(t[4], t[5]), __builtin_fmaxf(t[6], t[7]))),
+                    __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(t[8], t[9]), __builtin_fmaxf(t[10], t[11])),
+                                    __builtin_fmaxf(__builtin_fmaxf(t[12], t[13]), __builtin_fmaxf(t[14], t[15]))));
+                any = __ballot(!(m < 0.f) && live);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    any |= __ballot(may_enter(r));
+                any &= __ballot(live);
+            }
             if (any == 0)
                 continue;
             // ---- the rare path: which sums exactly, then one ordered insert at a time
@@ -732,14 +758,17 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                     const float d = closing_distance<metric_ak, scalar_ak>(sum, norms_q[i], source_b2);
                     if (d > limit[i]) // farther than this partition's k-th best (the test in the registers is a tile old): no list access
                         continue;
+                    // the list: in LDS when it fits there, else where it ends up — this partition's cells of the output arrays
+                    // (distances as they are, the slot in the low word of the key cell until the end)
                     const std::uint64_t cells = ((std::uint64_t)partition * query_count + first_query + i) * wanted;
-                    float* entries_d = out_distances + cells;
-                    std::uint32_t* entries_s = reinterpret_cast<std::uint32_t*>(out_keys + cells); // entry e: word 2e
+                    float* entries_d = lds_lists_ak ? lists_d + i * wanted : out_distances + cells;
+                    std::uint32_t* entries_s = lds_lists_ak ? lists_s + i * wanted : reinterpret_cast<std::uint32_t*>(out_keys + cells);
+                    constexpr std::uint32_t slot_pitch = lds_lists_ak ? 1u : 2u; // entry e of a key cell list: word 2e
                     const std::uint32_t size = top_n[i];
                     // the whole list in registers, a lane per entry (read once: what follows never re-reads what it wrote)
                     const bool mine = lane < size;
                     const float my_d = mine ? entries_d[lane] : 0.f;
-                    const std::uint32_t my_s = mine ? entries_s[2 * lane] : 0u;
+                    const std::uint32_t my_s = mine ? entries_s[slot_pitch * lane] : 0u;
                     if (size == wanted) { // full: the newcomer has to beat the last entry
                         const float last_d = __shfl(my_d, (int)(size - 1), 64);
                         const std::uint32_t last_s = (std::uint32_t)__shfl((int)my_s, (int)(size - 1), 64);
@@ -750,9 +779,9 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                     const std::uint32_t position = (std::uint32_t)__popcll(__ballot(mine && goes_before(my_d, my_s, d, s)));
                     const std::uint32_t grown = size < wanted ? size + 1 : size;
                     if (mine && lane >= position && lane + 1 < grown)
-                        entries_d[lane + 1] = my_d, entries_s[2 * (lane + 1)] = my_s;
+                        entries_d[lane + 1] = my_d, entries_s[slot_pitch * (lane + 1)] = my_s;
                     if (lane == position)
-                        entries_d[position] = d, entries_s[2 * position] = s;
+                        entries_d[position] = d, entries_s[slot_pitch * position] = s;
                     // the new k-th best: the newcomer if it went last, else what was second to last
                     const std::uint32_t new_last = grown - 1;
                     const float shifted = __shfl(my_d, (int)(new_last ? new_last - 1 : 0), 64);
@@ -764,17 +793,19 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                             atomicMin(shared_bounds + first_query + i, ordered_bits(kth));
                         }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // this wave's next insert into the list reads these cells
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    // this wave's next insert into the list reads these cells
+                    if constexpr (lds_lists_ak) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                    } else {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int u = 0; u < wide_blocks_k; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[u][r] = 0;
     };
 
     // ---- the pipeline: chunk c is multiplied out of buffer c & 1 while the DMA fills the other buffer with chunk c + 1. A wave
@@ -793,7 +824,10 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
     std::uint64_t phase_ticks[4] = {0, 0, 0, 0}, phase_mark = __builtin_amdgcn_s_memtime();
 #endif
     for (std::uint32_t c = 0; c < total; ++c) {
-        multiply_chunk(c & 1u, c + 1 < total, (c + 1) & 1u);
+        if (work_chunk == 0)
+            multiply_chunk(std::true_type{}, c & 1u, c + 1 < total, (c + 1) & 1u);
+        else
+            multiply_chunk(std::false_type{}, c & 1u, c + 1 < total, (c + 1) & 1u);
         UA_PHASE_TICK(0)
         if (++work_chunk == chunks) {
             fold_tile();
@@ -823,8 +857,10 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
             continue;
         const std::uint64_t out = ((std::uint64_t)partition * query_count + q) * wanted + position;
         if (position < top_n[i]) {
-            const std::uint32_t slot = (std::uint32_t)out_keys[out];
+            const std::uint32_t slot = lds_lists_ak ? lists_s[i * wanted + position] : (std::uint32_t)out_keys[out];
             out_keys[out] = map_keys ? ix.keys[slot] : (std::uint64_t)slot;
+            if constexpr (lds_lists_ak)
+                out_distances[out] = lists_d[i * wanted + position];
         } else {
             out_keys[out] = 0;
             reinterpret_cast<std::uint32_t*>(out_distances)[out] = signaling_nan_bits_k;
@@ -852,9 +888,11 @@ hipError_t launch_wide(const snapshot_view_t& view, const std::uint8_t* queries,
                        std::uint64_t rows_per_partition, const std::uint32_t* row_norms, const std::uint32_t* query_norms,
                        bool map_keys, const std::uint32_t* allow_bits, std::uint32_t* shared_bounds, float* out_distances,
                        std::uint64_t* out_keys, std::uint64_t* out_counts, hipStream_t stream) {
-    auto kernel = exact_wide_kernel<metric_ak, scalar_ak>;
+    const bool lds_lists = wanted <= (std::uint32_t)wide_lds_lists_k && !env_size("USEARCH_AMD_EXACT_GLOBAL_LISTS", 0);
+    auto kernel = lds_lists ? exact_wide_kernel<metric_ak, scalar_ak, true> : exact_wide_kernel<metric_ak, scalar_ak, false>;
+    const std::uint32_t lds_bytes = wide_lds_bytes(lds_lists, wanted);
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)wide_lds_bytes());
+                                             (int)lds_bytes);
     if (e != hipSuccess)
         return e;
     const std::uint32_t query_tiles = (query_count + wide_queries_k - 1) / wide_queries_k;
@@ -863,7 +901,7 @@ hipError_t launch_wide(const snapshot_view_t& view, const std::uint8_t* queries,
     hipLaunchKernelGGL(pad_queries_kernel, dim3((unsigned)std::min<std::uint64_t>((padded_rows * padded_stride + 255) / 256, 1u << 20)),
                        dim3(256), 0, stream, queries, query_stride, query_count, (std::uint32_t)view.bytes_per_vector, padded,
                        padded_stride, padded_rows);
-    hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(wide_threads_k), wide_lds_bytes(), stream, view,
+    hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(wide_threads_k), lds_bytes, stream, view,
                        (const std::uint8_t*)padded, padded_stride, query_count, wanted, rows_per_partition, query_tiles, tiles_per_xcd, row_norms,
                        query_norms, map_keys ? 1u : 0u, allow_bits, shared_bounds, out_distances, out_keys, out_counts);
     return hipGetLastError();
