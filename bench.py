@@ -461,6 +461,8 @@ def main() -> None:
                         help="skip re-timing the batch with the engine's placement draws switched off (roofline.frac_first_placement)")
     parser.add_argument("--exact", action="store_true",
                         help="time the exact (brute-force) search of the batch through the matrix-unit kernel instead of the graph walk")
+    parser.add_argument("--max-batch", type=int, default=int(os.environ.get("BENCH_MAX_BATCH", 0)),
+                        help="device builder: most nodes linked per batch (0 = the builder's default)")
     parser.add_argument("--dry", action="store_true",
                         help="no GPU work: print the per-rank memory plan of this configuration against 288 GB of HBM and the exact "
                              "command line an N-GPU run is launched with, then exit (what the 8 x 125M recipe is checked with)")
@@ -546,7 +548,7 @@ def main() -> None:
         t0 = time.time()
         built = usearch_amd.build(None, metric, args.dtype, keys=keys, connectivity=args.connectivity,
                                   expansion_add=args.expansion_add, device=local_rank, device_pointer=data.data_ptr(),
-                                  count=args.n, stride=data.stride(0), ndim=args.dim)
+                                  count=args.n, stride=data.stride(0), ndim=args.dim, max_batch=args.max_batch)
         build_seconds = time.time() - t0
         del data
         torch.cuda.empty_cache()

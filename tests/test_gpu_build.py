@@ -179,9 +179,10 @@ def test_hubs_lose_no_reverse_link(reference):
     assert np.mean(np.sort(found, axis=1) == np.arange(4)[None, :]) > 0.99  # the hubs are everybody's nearest
 
 
-@pytest.mark.parametrize("connectivity,connectivity_base", [(30, 0), (16, 63), (31, 62)])
+@pytest.mark.parametrize("connectivity,connectivity_base", [(30, 0), (16, 63), (31, 62), (32, 0), (48, 0), (64, 0), (20, 100)])
 def test_wide_base_lists_build(reference, connectivity, connectivity_base):
-    """Base lists of 57 ... 63 neighbours leave 7 ... 1 places in the wave that re-prunes a list: more rounds, same graph rules."""
+    """Base lists of 57 ... 63 neighbours leave 7 ... 1 places in the wave that re-prunes a list: more rounds, same graph rules.
+    Lists of 64 … 128 cells (connectivity 32 — HNSW's other popular choice — 48, 64) go through LDS, three candidates per lane."""
     n, ndim = 4000, 48
     vectors = util.make_vectors(n, ndim, "f32", seed=73)
     queries = util.make_vectors(200, ndim, "f32", seed=74)
@@ -233,4 +234,6 @@ def test_build_edge_cases():
     got = few.index.search(util.make_vectors(3, 16, "f32", seed=2), 10)
     assert np.all(got.counts == 7)
     with pytest.raises(RuntimeError):
-        usearch_amd.build(util.make_vectors(10, 16, "f32", seed=1), "cos", "f32", connectivity=40)
+        usearch_amd.build(util.make_vectors(10, 16, "f32", seed=1), "cos", "f32", connectivity=65)
+    with pytest.raises(RuntimeError):
+        usearch_amd.build(util.make_vectors(10, 16, "f32", seed=1), "cos", "f32", connectivity=16, connectivity_base=129)

@@ -248,8 +248,8 @@ const char* builder_t::build(metric_kind_t metric, scalar_kind_t scalar, std::si
     const std::uint32_t widest = std::max(m, config_.connectivity_base);
     // a list and the requests filed against it are re-pruned by one wave (build_reverse_kernel): 64 - widest requests per round;
     // what does not fit waits for the next round (build_refile_kernel), so even a one-request inbox builds, in more rounds
-    if (widest > 63)
-        return "Connectivity is too large for the device builder (base connectivity must not exceed 63)";
+    if (widest > build_max_capacity_k || m > 64)
+        return "Connectivity is too large for the device builder (connectivity ≤ 64, base connectivity ≤ 128)";
     const std::uint32_t ef = std::max<std::uint32_t>(widest + 1, config_.expansion_add); // index.hpp:2799-2800
     if (ef > build_max_candidates_k)
         return "Expansion is too large for the device builder";
@@ -410,7 +410,8 @@ const char* builder_t::link_range(std::uint64_t begin, const std::uint64_t end_t
     const scalar_kind_t scalar = scalar_;
     const std::uint32_t m = config_.connectivity, m0 = config_.connectivity_base;
     const std::uint32_t widest = std::max(m, m0);
-    const std::uint32_t inbox_cap = std::min<std::uint32_t>(32, 64 - widest); // existing + incoming fit one wave
+    // a list and what is filed against it share one wave (a candidate per lane) while they fit 64; wider lists go through LDS
+    const std::uint32_t inbox_cap = widest < 64 ? std::min<std::uint32_t>(32, 64 - widest) : build_wide_inbox_k;
     const std::uint32_t ef = std::max<std::uint32_t>(widest + 1, config_.expansion_add);
     UA_HIP(hipSetDevice(snapshot_.device()));
     hipStream_t stream = snapshot_.stream();
@@ -469,7 +470,7 @@ const char* builder_t::link_range(std::uint64_t begin, const std::uint64_t end_t
     args.touched_count = d_touched_count_;
     args.counters = d_counters_;
     args.deferred_cap = (std::uint32_t)std::min<std::uint64_t>(max_batch * m, 0xFFFFFFFFull); // every request of a pass fits
-    args.candidate_cap = std::max<std::uint32_t>(64, (ef + 63) / 64 * 64);
+    args.candidate_cap = std::max<std::uint32_t>(widest + inbox_cap > 64 ? build_selected_k : 64, (ef + 63) / 64 * 64);
 
     std::vector<std::uint32_t> nodes;
     std::vector<std::uint64_t> host_counters(max_batch);

@@ -21,7 +21,7 @@ namespace usearch_amd {
 /// Largest `expansion_add` (and base connectivity) the link kernels take: a node's candidates are ranked by one wave
 /// (build_kernels.hpp `build_max_candidates_k`; build.hip checks that the two agree).
 constexpr std::uint32_t builder_max_expansion_k = 1024;
-constexpr std::uint32_t builder_max_connectivity_base_k = 63;
+constexpr std::uint32_t builder_max_connectivity_base_k = 128;
 
 struct build_config_t {
     std::uint32_t connectivity = 16;      ///< M,  index.hpp `default_connectivity()`

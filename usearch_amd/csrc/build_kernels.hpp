@@ -17,6 +17,9 @@
  *  reference's concurrent `add` calls, which do not see each other's half-built nodes either. Lists stay prefix-compact
  *  with `none_slot_k` padding (the snapshot layout of common.hpp), so a finished build IS a searchable snapshot.
  *
+ *  Lists of up to 128 cells (base connectivity ≤ 128, connectivity ≤ 64): a list and what is filed against it fit one wave — a
+ *  candidate per lane — while capacity + inbox ≤ 64; wider lists go through LDS, up to three candidates per lane.
+ *
  *  `refine_` restated for a wave ("forward elimination"): candidates sorted ascending by distance to the centre; the
  *  first live candidate is accepted, then every later live candidate `c` with d(accepted, c) < d(c, centre) is struck
  *  out — the reference rejects exactly those when it reaches them (index.hpp:4297-4304). Same result, but each accepted
@@ -28,6 +31,9 @@
 namespace usearch_amd {
 
 constexpr std::uint32_t build_max_candidates_k = 1024; ///< insertion beam width the link kernels accept (ef_construction)
+constexpr std::uint32_t build_max_capacity_k = 128;    ///< widest list the link kernels take (base connectivity)
+constexpr std::uint32_t build_wide_inbox_k = 32;       ///< requests per target and round once a list no longer shares a wave with them
+constexpr std::uint32_t build_selected_k = 192;        ///< cells of the accepted / staging arrays: capacity + inbox, whole 64s
 
 /// One linking pass: the nodes of one batch that exist on `level`.
 struct build_args_t {
@@ -92,11 +98,13 @@ struct build_lds_t {
     float* cand_distances;       // [64]
     std::uint32_t* slots;        // [cap] candidates, ascending
     float* dists;                // [cap]
-    std::uint32_t* sel;          // [64] accepted
-    float* seld;                 // [64]
+    std::uint32_t* sel;          // [192] accepted (≤ the list capacity); the wide reverse path also stages existing ∪ incoming here
+    float* seld;                 // [192]
     std::uint64_t* alive;        // [cap / 64] one bit per candidate `refine_forward` has not struck yet
 };
-inline __host__ __device__ std::uint32_t build_lds_bytes(std::uint32_t cap) { return 64 * 4 * 2 + cap * 4 * 2 + 64 * 4 * 2 + cap / 64 * 8; }
+inline __host__ __device__ std::uint32_t build_lds_bytes(std::uint32_t cap) {
+    return 64 * 4 * 2 + cap * 4 * 2 + build_selected_k * 4 * 2 + cap / 64 * 8;
+}
 
 UA_DEVICE build_lds_t build_lds(std::uint8_t* base, std::uint32_t cap) {
     build_lds_t l;
@@ -105,13 +113,13 @@ UA_DEVICE build_lds_t build_lds(std::uint8_t* base, std::uint32_t cap) {
     l.slots = reinterpret_cast<std::uint32_t*>(base + 512);
     l.dists = reinterpret_cast<float*>(base + 512 + cap * 4);
     l.sel = reinterpret_cast<std::uint32_t*>(base + 512 + cap * 8);
-    l.seld = reinterpret_cast<float*>(base + 512 + cap * 8 + 256);
-    l.alive = reinterpret_cast<std::uint64_t*>(base + 512 + cap * 8 + 512);
+    l.seld = reinterpret_cast<float*>(base + 512 + cap * 8 + build_selected_k * 4);
+    l.alive = reinterpret_cast<std::uint64_t*>(base + 512 + cap * 8 + build_selected_k * 8);
     return l;
 }
 
 /**
- *  `refine_` (index.hpp:4276-4318) over `count` candidates (LDS, ascending), at most `needed` (≤ 64) accepted into
+ *  `refine_` (index.hpp:4276-4318) over `count` candidates (LDS, ascending), at most `needed` (≤ 128) accepted into
  *  `sel/seld`. Returns how many. The caller handles the reference's shortcut for `count < needed`.
  */
 template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak>
@@ -235,14 +243,106 @@ __global__ __launch_bounds__(64, build_waves(lanes_ak)) void build_reverse_kerne
     for (std::uint32_t t = blockIdx.x; t < touched; t += gridDim.x) {
         const std::uint32_t target = uniform_u32(b.touched[t]);
         std::uint32_t* list = build_list(b, ix, target);
-        const std::uint32_t capacity = b.capacity; // host guarantees capacity + inbox_cap <= 64
+        const std::uint32_t capacity = b.capacity;
+        if (capacity + b.inbox_cap > 64) { // the list and its requests do not share a wave: through LDS
+            std::uint32_t existing_count = 0;
+            for (std::uint32_t tile = 0; tile < capacity; tile += 64) { // lists are prefix-compact
+                const std::uint32_t cell = tile + lane;
+                const std::uint32_t value = cell < capacity ? list[cell] : none_slot_k;
+                if (value != none_slot_k)
+                    l.sel[cell] = value;
+                existing_count += popcount64(ballot(value != none_slot_k));
+            }
+            std::uint32_t incoming_count = uniform_u32(b.inbox_count[target]);
+            incoming_count = incoming_count < b.inbox_cap ? incoming_count : b.inbox_cap;
+            const cand_t incoming = lane < incoming_count ? b.inbox[(std::uint64_t)target * b.inbox_cap + lane] : 0;
+            if (lane == 0)
+                b.inbox_count[target] = 0; // ready for the next pass
+            wave_sync<false>();
+            // a requester the list already names (a member that is being re-linked in place keeps its inbound links) is not new
+            const std::uint32_t mine = cand_slot(incoming);
+            bool fresh = lane < incoming_count;
+            for (std::uint32_t j = 0; j < existing_count; ++j)
+                fresh = fresh && l.sel[j] != mine;
+            const std::uint64_t fresh_mask = ballot(fresh);
+            const std::uint32_t fresh_count = popcount64(fresh_mask);
+            if (existing_count + fresh_count <= capacity) {
+                // room left (index.hpp:3872-3875): append, in ascending requester order so that the build is reproducible
+                std::uint32_t rank = 0;
+                for (std::uint32_t j = 0; j < incoming_count; ++j)
+                    rank += ((fresh_mask >> j) & 1ull) && read_lane_u32(mine, j) < mine ? 1u : 0u;
+                if (fresh)
+                    list[existing_count + rank] = mine;
+            } else {
+                // index.hpp:3877-3891: existing ∪ incoming, measured from `target`, refined down to the capacity
+                const query_norm_t a2 = stage_row<metric_ak, scalar_ak, lanes_ak>(ix, target, query_lds);
+                for (std::uint32_t tile = 0; tile < existing_count; tile += 64) {
+                    const std::uint32_t batch = existing_count - tile < 64 ? existing_count - tile : 64;
+                    if (lane < batch)
+                        l.cand_slots[lane] = l.sel[tile + lane];
+                    wave_sync<false>();
+                    measure_rows<metric_ak, scalar_ak, lanes_ak, unroll_ak, false>(ix, query_lds, a2, l.cand_slots, l.cand_distances, batch);
+                    if (lane < batch)
+                        l.seld[tile + lane] = l.cand_distances[lane];
+                    wave_sync<false>();
+                }
+                evaluated += existing_count;
+                if (fresh) { // the requesters behind the old neighbours, with the distance they filed
+                    const std::uint32_t position = existing_count + rank_below(fresh_mask, lane);
+                    l.sel[position] = mine, l.seld[position] = cand_distance(incoming);
+                }
+                wave_sync<false>();
+                const std::uint32_t total = existing_count + fresh_count; // ≤ 160: up to three candidates per lane
+                for (std::uint32_t mine_index = lane; mine_index < total; mine_index += 64) { // ascending by (distance, slot)
+                    const float my_distance = l.seld[mine_index];
+                    const std::uint32_t my_slot = l.sel[mine_index];
+                    std::uint32_t rank = 0;
+                    for (std::uint32_t j = 0; j < total; ++j) {
+                        const float other_distance = l.seld[j];
+                        const std::uint32_t other_slot = l.sel[j];
+                        rank += (other_distance < my_distance || (other_distance == my_distance && other_slot < my_slot)) ? 1u : 0u;
+                    }
+                    l.slots[rank] = my_slot, l.dists[rank] = my_distance;
+                }
+                wave_sync<false>();
+                const std::uint32_t accepted =
+                    refine_forward<metric_ak, scalar_ak, lanes_ak, unroll_ak>(ix, query_lds, l, total, capacity, evaluated);
+                for (std::uint32_t cell = lane; cell < capacity; cell += 64)
+                    list[cell] = cell < accepted ? l.sel[cell] : none_slot_k;
+                ++repruned;
+            }
+            wave_sync<false>();
+            continue;
+        }
         const std::uint32_t existing = lane < capacity ? list[lane] : none_slot_k;
         const std::uint32_t existing_count = popcount64(ballot(existing != none_slot_k)); // lists are prefix-compact
         std::uint32_t incoming_count = uniform_u32(b.inbox_count[target]);
         incoming_count = incoming_count < b.inbox_cap ? incoming_count : b.inbox_cap;
-        const cand_t incoming = lane < incoming_count ? b.inbox[(std::uint64_t)target * b.inbox_cap + lane] : 0;
+        cand_t incoming = lane < incoming_count ? b.inbox[(std::uint64_t)target * b.inbox_cap + lane] : 0;
         if (lane == 0)
             b.inbox_count[target] = 0; // ready for the next pass
+        {   // a requester the list already names (a member that is being re-linked in place keeps its inbound links) is not new:
+            // the fresh ones move to the front lanes, in the order they were filed
+            const std::uint32_t mine = cand_slot(incoming);
+            bool fresh = lane < incoming_count;
+            for (std::uint32_t j = 0; j < existing_count; ++j)
+                fresh = fresh && read_lane_u32(existing, j) != mine;
+            const std::uint64_t fresh_mask = ballot(fresh);
+            if (popcount64(fresh_mask) != incoming_count) {
+                const std::uint32_t position = rank_below(fresh_mask, lane);
+                l.cand_slots[lane] = 0;
+                wave_sync<false>();
+                if (fresh)
+                    l.cand_slots[position] = lane;
+                wave_sync<false>();
+                incoming_count = popcount64(fresh_mask);
+                const int from = (int)l.cand_slots[lane];
+                const std::uint32_t moved_slot = (std::uint32_t)__shfl((int)cand_slot(incoming), from, 64);
+                const float moved_distance = __shfl(cand_distance(incoming), from, 64);
+                incoming = lane < incoming_count ? make_cand(moved_distance, moved_slot) : 0;
+                wave_sync<false>();
+            }
+        }
         if (existing_count + incoming_count <= capacity) {
             // room left (index.hpp:3872-3875): append, in ascending requester order so that the build is reproducible
             const std::uint32_t mine = cand_slot(incoming);

@@ -542,8 +542,8 @@ usearch_index_t usearch_init(usearch_init_options_t* options, usearch_error_t* e
     index->multi = options->multi;
     // the device builder's limits, said here instead of at the first search (build.hip: a node's existing and incoming links
     // are ranked by one wave)
-    if (2 * index->connectivity > 63 || index->connectivity < 2) {
-        fail(error, "Connectivity must be between 2 and 31 for the device builder (base connectivity 2·M ≤ 63)");
+    if (2 * index->connectivity > builder_max_connectivity_base_k || index->connectivity < 2) {
+        fail(error, "Connectivity must be between 2 and 64 for the device builder (base connectivity 2·M ≤ 128)");
         delete index;
         return nullptr;
     }
