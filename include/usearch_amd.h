@@ -116,7 +116,7 @@ USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_device_bytes(usearch_amd_snapshot
 /** How the matrix of stored rows was placed in HBM. Where a multi-gigabyte array lands decides how fast the walk runs over it
  *  (the headline batch: 45.4 … 51.9 ms for the same bytes), and no synthetic probe tells the placements apart, so the loader and
  *  the builder draw a few placements (device-to-device copies), let a short SELF-SEARCH of stored rows judge each and keep the
- *  fastest (csrc/placement.hpp, `snapshot_t::tune_placement`; USEARCH_AMD_PLACEMENT_DRAWS, default 8 — fewer once a fast placement has followed a slow one — 1 = off; arrays under
+ *  fastest (csrc/placement.hpp, `snapshot_t::tune_placement`; USEARCH_AMD_PLACEMENT_DRAWS, default 8, 1 = off; arrays under
  *  USEARCH_AMD_PLACEMENT_MIN_BYTES = 1 GiB take the first). `judge_ms` receives up to 8 times in MILLISECONDS (lower is better),
  *  `*kept` which draw won, `*probe_ms` what the draws cost in all. */
 USEARCH_AMD_EXPORT void usearch_amd_snapshot_placement(usearch_amd_snapshot_t snapshot, uint32_t* draws, uint32_t* kept,

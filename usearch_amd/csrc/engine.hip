@@ -320,7 +320,6 @@ const char* snapshot_t::tune_placement() {
         return nullptr; // cannot judge: the matrix stays where it is
     placement_.judge_ms[0] = best_ms;
     placement_.draws = 1, placement_.kept = 0;
-    float worst_ms = best_ms;
     std::vector<void*> losers; // held until the end, so that every further draw has to land somewhere else
     for (std::size_t d = 1; d < draws; ++d) {
         std::size_t free_bytes = 0, total_bytes = 0;
@@ -343,7 +342,6 @@ const char* snapshot_t::tune_placement() {
         const bool judged = judge(ms);
         placement_.judge_ms[d] = ms;
         placement_.draws = (std::uint32_t)d + 1;
-        worst_ms = judged && ms > worst_ms ? ms : worst_ms;
         if (judged && ms < best_ms) {
             best_ms = ms;
             placement_.kept = (std::uint32_t)d;
@@ -354,8 +352,6 @@ const char* snapshot_t::tune_placement() {
             losers.push_back(candidate);
         }
         if (!judged)
-            break;
-        if (best_ms < 0.94f * worst_ms) // both levels have shown (they lie ≈ 11 % apart) and the fast one is kept: no more copies
             break;
     }
     for (void* p : losers)

@@ -197,7 +197,7 @@ class snapshot_t {
     /// contiguous block. Costs size × M0 × 16 bytes of HBM; USEARCH_AMD_INLINE_ROWS=0 turns it off.
     const char* finalize_layout();
     /// Once the index is resident: draws a few placements of the matrix of stored rows (each a device-to-device copy), lets a short
-    /// self-search of stored rows time the walk on each, keeps the fastest (placement.hpp). USEARCH_AMD_PLACEMENT_DRAWS (default 8, fewer once a fast placement follows a slow one;
+    /// self-search of stored rows time the walk on each, keeps the fastest (placement.hpp). USEARCH_AMD_PLACEMENT_DRAWS (default 8;
     /// 1 = off); matrices under 1 GiB and indexes under 65 536 members are left where they are. Called by `finalize_layout`.
     const char* tune_placement();
     void suspend_layout() { view_.nbr0_rows = nullptr; } ///< while the lists are being rewritten (construction)
