@@ -827,7 +827,21 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
     // so small that every query gets a wave of its own even at the LDS residency (a `usearch_search` caller's single query above
     // all) also takes LDS: residency buys it nothing, and every probe round of the global hash is a two-microsecond trip to the
     // memory side — half of such a query's latency (profiles/r03_short_rows/README.md §1)
-    const std::uint64_t lds_mode_bytes = lds_bytes_for(scratch_lds_k, next_cap, hash_cap);
+    std::uint64_t lds_mode_bytes = lds_bytes_for(scratch_lds_k, next_cap, hash_cap);
+    // a set sized for half load that does not fit LDS where the one sized for 75 % would (expansion 608 over long rows: 256 KB
+    // against 128 KB): a small batch takes the smaller set in LDS rather than the larger one in global memory — a lone query walks
+    // 3.1 ms that way and 3.5 ms the other
+    if (!tuning.hash_cap && !env_size("USEARCH_AMD_HASH_CAP", 0) && mode_request == 0 && lds_mode_bytes > lds_budget) {
+        const std::uint32_t tighter = std::min<std::uint32_t>(
+            pow2_ceil(std::max<std::uint32_t>(1024, (ef * 30 + 1600) / 3 * 4)),
+            pow2_ceil((std::uint32_t)std::min<std::uint64_t>(view_.size * 2 + 128, 1u << 30)));
+        const std::uint64_t tighter_bytes = lds_bytes_for(scratch_lds_k, next_cap, tighter);
+        if (tighter < hash_cap && tighter_bytes <= lds_budget && count <= (std::uint64_t)waves_for(tighter_bytes) * compute_units_ &&
+            !env_size("USEARCH_AMD_NO_SMALL_BATCH_LDS", 0)) {
+            hash_cap = tighter;
+            lds_mode_bytes = tighter_bytes;
+        }
+    }
     const bool small_batch = lds_mode_bytes <= lds_budget && count <= (std::uint64_t)waves_for(lds_mode_bytes) * compute_units_ &&
                              !env_size("USEARCH_AMD_NO_SMALL_BATCH_LDS", 0);
     int mode = mode_request == 1 ? scratch_lds_k : mode_request == 2 ? scratch_hash_k : mode_request == 3 ? scratch_global_k
