@@ -15,7 +15,7 @@
  *                  build the first time, afterwards only the members added since (the graph is extended in place, the batch-
  *                  deferred form of index.hpp:2780-2879). `usearch_remove` writes the tombstone and `usearch_rename` the new key
  *                  in place in HBM; only `usearch_change_metric_kind` costs a rebuild. Limits of the device builder are said
- *                  at `usearch_init`: connectivity ≤ 28, expansion_add ≤ 256.
+ *                  at `usearch_init`: connectivity ≤ 64 (base layer ≤ 128), expansion_add ≤ 1024.
  *    concurrency   searches share the index (one engine workspace per call in flight, `usearch_change_threads_search` sizes
  *                  the pool); mutations and the deferred linking take it alone.
  *    persistence   `usearch_save*` writes and `usearch_load* / view*` read the reference's v2 format: files move freely

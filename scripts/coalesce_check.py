@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
 """scripts/coalesce_check.py — T host threads looping `usearch_search` (ONE query per call, the C ABI's hot signature) on the headline
-index through the drop-in library, with and without the call combiner (USEARCH_AMD_COALESCE, csrc/combiner.hpp: calls that arrive
-while a launch is in flight go out together in the next one). Calls per second and milliseconds per call at T = 1, 16, 64.
+index through the drop-in library (native threads: scripts/callers_loop.c), with and without the call combiner (USEARCH_AMD_COALESCE, csrc/combiner.hpp: calls that arrive
+while a launch is in flight go out together in the next one; with a window, the launcher waits that long at most for the callers of
+the launch that just finished to call again). Calls per second and milliseconds per call at T = 1, 16, 64.
 
     GPU_MAX_HW_QUEUES=16 python scripts/coalesce_check.py
 """
 import ctypes as C
 import os
+import subprocess
 import sys
-import threading
-import time
 
 import numpy as np
 
@@ -46,8 +46,16 @@ def main():
     L.usearch_search.restype = C.c_size_t
     L.usearch_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, err_p]
     L.usearch_free.argtypes = [C.c_void_p, err_p]
-    for coalesce in (0, 1):
-        os.environ["USEARCH_AMD_COALESCE"] = str(coalesce)  # read when the index is created
+    helper = "/tmp/usearch_amd_callers_loop.so"  # native caller threads: Python's would pass the interpreter lock around between calls
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-pthread", os.path.join(ROOT, "scripts", "callers_loop.c"), "-o", helper])
+    native = C.CDLL(helper)
+    native.callers_loop.restype = C.c_double
+    native.callers_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                    C.POINTER(C.c_int)]
+    search_pointer = C.cast(L.usearch_search, C.c_void_p)
+    for coalesce, window in ((0, 0), (1, 0), (1, 200), (1, 500)):
+        os.environ["USEARCH_AMD_COALESCE"] = str(coalesce)  # both read when the index is created
+        os.environ["USEARCH_AMD_COALESCE_WINDOW_US"] = str(window)
         err = C.c_char_p()
         options = Options(1, None, 3, dim, 16, 128, 64, False)  # cos, f16
         index = L.usearch_init(C.byref(options), C.byref(err))
@@ -57,29 +65,14 @@ def main():
         for ef in (608, 64):
             L.usearch_change_expansion_search(index, ef, C.byref(err))
             for threads in (1, 16, 64):
-                per_thread = 24 if ef == 608 else 96
-                failures = []
-
-                def work(t):
-                    keys, distances, e = np.zeros(10, dtype=np.uint64), np.zeros(10, dtype=np.float32), C.c_char_p()
-                    for i in range(per_thread):
-                        q = queries[(t * per_thread + i) % 4096]
-                        L.usearch_search(index, C.c_void_p(q.ctypes.data), 3, 10, C.c_void_p(keys.ctypes.data),
-                                         C.c_void_p(distances.ctypes.data), C.byref(e))
-                        if e.value:
-                            failures.append(e.value)
-                            return
-
-                work(0)
-                pool = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
-                t0 = time.perf_counter()
-                for thread in pool:
-                    thread.start()
-                for thread in pool:
-                    thread.join()
-                seconds = time.perf_counter() - t0
+                per_thread = 48 if ef == 608 else 192
+                failures = C.c_int(0)
+                native.callers_loop(search_pointer, index, C.c_void_p(queries.ctypes.data), dim * 2, 4096, 3, 10, 1, 1, C.byref(failures))
+                seconds = native.callers_loop(search_pointer, index, C.c_void_p(queries.ctypes.data), dim * 2, 4096, 3, 10, threads, per_thread,
+                                              C.byref(failures))
+                failures = [failures.value] if failures.value else []
                 assert not failures, failures[:1]
-                print(f"coalesce={coalesce} ef={ef} threads={threads}: {threads * per_thread / seconds:,.0f} calls per second "
+                print(f"coalesce={coalesce} window={window}us ef={ef} threads={threads}: {threads * per_thread / seconds:,.0f} calls per second "
                       f"({seconds / per_thread * 1e3:.2f} ms per call and thread)", flush=True)
         L.usearch_free(index, C.byref(err))
 

@@ -1,5 +1,7 @@
 // tests/cpp/combiner_test.cpp — the call combiner of the drop-in (usearch_amd/csrc/combiner.hpp) under 32 threads with a mock launch:
-// every call gets its own answer, calls that arrive during a launch go out together, groups never mix kinds or result counts.
+// every call gets its own answer, calls that arrive during a launch go out together, groups never mix kinds or result counts;
+// sixteen looping callers end up in ONE launch each time when the launcher gives the returning callers a moment (and in two
+// alternating groups of eight when it does not), and a lone caller is never made to wait.
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -55,6 +57,41 @@ int main() {
     failing.wanted = 1;
     combiner.submit(failing, [](std::vector<combined_call_t*>&) { throw 1; });
     const bool reported = failing.done && failing.error && !failing.found;
-    std::printf("%s\n", ok && reported ? "PASSED" : "FAILED");
-    return ok && reported ? 0 : 1;
+
+    // looping callers: launches needed for the same calls with and without the launcher's wait for the callers just served
+    std::uint64_t launches_for[2] = {0, 0}, expired_alone = 0;
+    for (int with_window = 0; with_window < 2; ++with_window)
+        for (int callers : {16, 1}) {
+            combiner_t looped;
+            looped.window_limit(std::chrono::microseconds(with_window ? 400 : 0));
+            std::vector<std::thread> loopers;
+            for (int t = 0; t < callers; ++t)
+                loopers.emplace_back([&] {
+                    for (int i = 0; i < 30; ++i) {
+                        float query[4] = {0};
+                        std::uint64_t keys[4];
+                        float distances[4];
+                        combined_call_t call;
+                        call.query = query, call.query_bytes = sizeof(query), call.kind = 1, call.wanted = 4, call.keys = keys,
+                        call.distances = distances;
+                        looped.submit(call, [](std::vector<combined_call_t*>& batch) {
+                            for (combined_call_t* other : batch)
+                                other->found = other->wanted;
+                            std::this_thread::sleep_for(std::chrono::microseconds(4000));
+                        });
+                    }
+                });
+            for (std::thread& thread : loopers)
+                thread.join();
+            std::uint64_t served = 0;
+            if (callers == 16)
+                looped.totals(launches_for[with_window], served);
+            else if (with_window)
+                expired_alone = looped.windows_expired();
+        }
+    std::printf("sixteen looping callers, thirty calls each: %llu launches without the wait, %llu with it; a lone caller waited %llu times\n",
+                (unsigned long long)launches_for[0], (unsigned long long)launches_for[1], (unsigned long long)expired_alone);
+    const bool gathered = launches_for[1] * 100 < launches_for[0] * 85 && !expired_alone;
+    std::printf("%s\n", ok && reported && gathered ? "PASSED" : "FAILED");
+    return ok && reported && gathered ? 0 : 1;
 }

@@ -9,9 +9,18 @@
  *  (same query kind, same result count) and runs them as one batch through `usearch_search_many`'s path; the others sleep
  *  until their results are there. Pure host logic, no HIP: `tests/cpp/combiner_test.cpp` drives it with a mock launch.
  *
- *  Opt-in for now (`USEARCH_AMD_COALESCE=1`, read at `usearch_init`): the device side of it has not been measured yet.
+ *  Left at that, T looping callers settle into TWO groups of T/2 that alternate (one in flight, one waiting: each call then
+ *  costs two launches of wall time, profiles/r04_single_query/coalesce.log: 7.25 ms per call for a 3.5 ms launch). The callers
+ *  of the launch that just finished are microseconds away from calling again, so the one who launches next gives them a
+ *  moment — at most an eighth of the last launch's duration and `window_limit` (200 us unless told otherwise) — and stops waiting the
+ *  instant as many calls have arrived as the finished launch had served. A lone caller never waits (its own return is the one
+ *  arrival expected), a caller that stops calling costs the others one window, once.
+ *
+ *  On by default in the drop-in (`USEARCH_AMD_COALESCE=0` turns it off, `USEARCH_AMD_COALESCE_WINDOW_US` sets the limit;
+ *  both read at `usearch_init`).
  */
 #pragma once
+#include <chrono>
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
@@ -41,29 +50,42 @@ class combiner_t {
      *  At most one `run` is in flight per combiner.
      */
     template <typename run_at> void submit(combined_call_t& call, run_at&& run) {
+        using clock_t = std::chrono::steady_clock;
         std::unique_lock<std::mutex> lock(mutex_);
         waiting_.push_back(&call);
+        if (expected_back_ && !--expected_back_)
+            gathered_.notify_one();
         while (!call.done && launching_)
             changed_.wait(lock);
         if (call.done)
             return;
         launching_ = true;
+        if (expected_back_ && window_limit_.count()) { // the callers the last launch served are on their way back
+            const auto window = last_duration_ / 8 < window_limit_ ? last_duration_ / 8 : window_limit_;
+            if (!gathered_.wait_for(lock, window, [this] { return expected_back_ == 0; }))
+                ++windows_expired_;
+        }
+        expected_back_ = 0;
         std::vector<combined_call_t*> batch, rest;
         for (combined_call_t* other : waiting_)
             (other->kind == call.kind && other->wanted == call.wanted && other->query_bytes == call.query_bytes ? batch : rest)
                 .push_back(other);
         waiting_.swap(rest);
         lock.unlock();
+        const clock_t::time_point started = clock_t::now();
         try {
             run(batch);
         } catch (...) {
             for (combined_call_t* other : batch)
                 other->found = 0, other->error = "Unexpected failure inside the index";
         }
+        const auto duration = std::chrono::duration_cast<std::chrono::nanoseconds>(clock_t::now() - started);
         lock.lock();
         for (combined_call_t* other : batch)
             other->done = true;
         launching_ = false;
+        last_duration_ = duration;
+        expected_back_ = batch.size();
         ++launches_;
         calls_ += batch.size();
         changed_.notify_all();
@@ -75,12 +97,27 @@ class combiner_t {
         launches = launches_, calls = calls_;
     }
 
+    /// How many times a launcher's wait for returning callers ran its full length (telemetry / tests).
+    std::uint64_t windows_expired() {
+        std::lock_guard<std::mutex> lock(mutex_);
+        return windows_expired_;
+    }
+
+    /// The longest a launcher waits for the callers of the launch before its own; zero: it never waits.
+    void window_limit(std::chrono::nanoseconds limit) {
+        std::lock_guard<std::mutex> lock(mutex_);
+        window_limit_ = limit;
+    }
+
   private:
     std::mutex mutex_;
-    std::condition_variable changed_;
+    std::condition_variable changed_;  ///< a launch finished: its calls are done, somebody else may launch
+    std::condition_variable gathered_; ///< everybody the launcher was waiting for has arrived
     std::vector<combined_call_t*> waiting_;
     bool launching_ = false;
-    std::uint64_t launches_ = 0, calls_ = 0;
+    std::size_t expected_back_ = 0; ///< calls the last launch served whose callers have not called again yet
+    std::chrono::nanoseconds last_duration_{0}, window_limit_{200000};
+    std::uint64_t launches_ = 0, calls_ = 0, windows_expired_ = 0;
 };
 
 } // namespace usearch_amd

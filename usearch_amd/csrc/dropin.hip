@@ -151,10 +151,12 @@ struct index_t {
     std::shared_mutex mutex;
     std::size_t threads_search = 0; ///< `usearch_change_threads_search`: batches in flight at once (0 = the engine's default)
     /// `usearch_search` calls in flight share a launch (combiner.hpp): whoever finds nobody launching takes every compatible call
-    /// that is waiting and runs them as one batch. A lone caller is untouched (3.5 ms / 0.34 ms per call at ef 608 / 64 on the
-    /// headline index either way); 16 callers at ef 608: 939 → 2 207 calls per second, 64 callers: 1 696 → 8 148 (latency 37.7 →
-    /// 7.9 ms), 64 callers at ef 64: 9.6 k → 47.7 k (profiles/r04_single_query/coalesce.log). `USEARCH_AMD_COALESCE=0` (read when the
-    /// index is created) turns it off.
+    /// that is waiting and runs them as one batch, after giving the callers of the launch before up to `USEARCH_AMD_COALESCE_WINDOW_US`
+    /// (200) microseconds — never more than an eighth of that launch, nothing for a lone caller — to call again: looping callers then go
+    /// out in one launch instead of two alternating halves. A lone caller is untouched (3.1 ms / 0.34 ms per call at ef 608 / 64 on the
+    /// headline index either way); 16 native callers at ef 608: 1 420 → 4 775 calls per second (11.3 → 3.35 ms per call), 64 callers:
+    /// 1 844 → 17 850 (34.7 → 3.6 ms), 64 callers at ef 64: 9.6 k → 84.4 k (profiles/r04_single_query/). `USEARCH_AMD_COALESCE=0`
+    /// (read when the index is created) turns it off.
     bool coalesce = env_size("USEARCH_AMD_COALESCE", 1) != 0;
     combiner_t combiner;
     // configuration — `usearch_init_options_t`, c/usearch.h:64-110
@@ -513,6 +515,7 @@ usearch_index_t usearch_init(usearch_init_options_t* options, usearch_error_t* e
         fail(error, "Out of memory!");
         return nullptr;
     }
+    index->combiner.window_limit(std::chrono::microseconds(env_size("USEARCH_AMD_COALESCE_WINDOW_US", 200)));
     if (!options) // an empty shell to `usearch_load` / `usearch_view` into, c/lib.cpp:142-147
         return index;
     if (options->metric) {
