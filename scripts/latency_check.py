@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """scripts/latency_check.py [--vectors N --dim D --dtype T --ef E …]: one query at a time through the host API (what a `usearch_search`
-loop sees) and small batches, with the team build (four waves per query) and without it (USEARCH_AMD_NO_TEAM=1) — same index, same
+loop sees) and small batches, with the team build (five waves per query) and without it (USEARCH_AMD_NO_TEAM=1) — same index, same
 process; results compared key for key, distance bits and counters included."""
 import argparse
 import os

@@ -276,9 +276,10 @@ def test_exact_float_ties_between_frontier_candidates(reference):
 @pytest.mark.parametrize("metric,dtype,ndim,expansion", [("cos", "f16", 768, 64), ("cos", "f32", 256, 300), ("l2sq", "i8", 1024, 128),
                                                          ("ip", "bf16", 512, 600), ("l2sq", "f32", 300, 1000)])
 def test_team_and_one_wave_agree(reference, monkeypatch, metric, dtype, ndim, expansion):
-    """Rows of at least 128 bytes, batches of at most two queries per CU: four waves share a query (team_search_kernel) — wave 0
-    walks, all four measure the hop's rows. Keys, distance bits and both counters equal the one-wave kernel's and the oracle's;
-    a single query, a handful, and the largest batch that still takes the team build."""
+    """Rows of at least 128 bytes, batches of at most two queries per CU: five waves share a query (team_search_kernel) — wave 0
+    walks and commits, the others measure the hop's rows (over the reference's heap all five measure). Keys, distance bits and both
+    counters equal the one-wave kernel's and the oracle's; a single query, a handful, and the largest batch that still takes the
+    team build."""
     from usearch_amd import Index
     image, vectors, _ = util.build_image(5000, ndim, metric, dtype, seed=57)
     index = Index.restore(image)
@@ -289,6 +290,29 @@ def test_team_and_one_wave_agree(reference, monkeypatch, metric, dtype, ndim, ex
         monkeypatch.setenv("USEARCH_AMD_NO_TEAM", "1")
         plain = index.search(queries[:count], 10, expansion=expansion, dtype=dtype)
         assert team.stats.variant == (5 if count <= 512 else plain.stats.variant) and plain.stats.variant != 5
+        assert np.array_equal(team.keys, plain.keys) and util.same_float_bits(team.distances, plain.distances)
+        assert np.array_equal(team.visited_per_query, plain.visited_per_query)
+        assert np.array_equal(team.computed_per_query, plain.computed_per_query)
+
+
+@pytest.mark.parametrize("metric,dtype,ndim,expansion", [("cos", "f16", 768, 96), ("l2sq", "f32", 256, 700)])
+def test_team_settles_ties_like_one_wave(reference, monkeypatch, metric, dtype, ndim, expansion):
+    """The team's leader names the next member to expand before it commits the hop just measured — exact unless distances tie, and
+    then it commits first and looks again. An index in which every vector occurs three times (and queries that ARE stored vectors)
+    ties at every hop: keys, distance bits and counters still equal the one-wave kernel's and the oracle's."""
+    from usearch_amd import Index
+    distinct = util.make_vectors(1700, ndim, dtype, seed=61, metric=metric)
+    order = np.random.default_rng(62).permutation(5100)
+    vectors = np.ascontiguousarray(np.concatenate([distinct, distinct, distinct])[order])
+    image, _, _ = util.build_image(5100, ndim, metric, dtype, vectors=vectors)
+    index = Index.restore(image)
+    queries = np.ascontiguousarray(np.concatenate([distinct[:40], util.make_vectors(40, ndim, dtype, seed=63, metric=metric)]))
+    for count in (1, 80):
+        monkeypatch.delenv("USEARCH_AMD_NO_TEAM", raising=False)
+        team = check_against_oracle(index, image, queries[:count], 10, dtype, expansion)
+        monkeypatch.setenv("USEARCH_AMD_NO_TEAM", "1")
+        plain = index.search(queries[:count], 10, expansion=expansion, dtype=dtype)
+        assert team.stats.variant == 5 and plain.stats.variant != 5
         assert np.array_equal(team.keys, plain.keys) and util.same_float_bits(team.distances, plain.distances)
         assert np.array_equal(team.visited_per_query, plain.visited_per_query)
         assert np.array_equal(team.computed_per_query, plain.computed_per_query)

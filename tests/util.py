@@ -47,10 +47,11 @@ def make_vectors(n: int, ndim: int, dtype: str, seed: int, clustered: bool = Tru
 
 
 def build_image(n: int, ndim: int, metric: str, dtype: str, seed: int = 1, connectivity: int = 16,
-                expansion_add: int = 128, threads: int = 1, clustered: bool = True, keys=None, remove=()):
+                expansion_add: int = 128, threads: int = 1, clustered: bool = True, keys=None, remove=(), vectors=None):
     """Builds an index with the REAL reference (single-threaded ⇒ deterministic graph) and serializes it.
     → (image bytes as np.uint8, vectors, RefIndex)."""
-    vectors = make_vectors(n, ndim, dtype, seed, clustered, metric=metric)
+    if vectors is None:
+        vectors = make_vectors(n, ndim, dtype, seed, clustered, metric=metric)
     index = refbind.RefIndex(ndim, metric, dtype, connectivity=connectivity, expansion_add=expansion_add)
     if keys is None:
         keys = np.arange(n, dtype=np.uint64) + 1000

@@ -785,7 +785,7 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
         variant = requested;
     }
     // A batch that cannot give every CU two queries to walk (a `usearch_search` caller's single query above all) over long rows: four
-    // waves per query — the hop's rows split four ways, everything else as ever (kernels.hpp team_search_kernel)
+    // helper waves per query take the rows of every hop, the leader walks and commits (kernels.hpp team_search_kernel)
     const bool team = every_build && chunks_per_lane >= 8 && !variant_request && mode_request != 3 &&
                       count <= 2ull * compute_units_ && !(extras && extras->descent_only) && !env_size("USEARCH_AMD_NO_TEAM", 0) &&
                       !tuning.waves_per_cu;
@@ -946,8 +946,9 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
     const std::uint32_t pending = call.have_todo ? (std::uint32_t)call.todo.size() : (std::uint32_t)call.count;
     // a team's workgroup adds its shared control block (16-byte alignment + 64 bytes) to the leader's areas: a size that only just
     // fits the budget alone must not become a launch failure — such a batch walks with one wave per query
+    const std::uint32_t team_bytes = 64;
     if (params.team && call.mode != scratch_global_k &&
-        (lds_bytes_for(call.mode, call.next_cap, call.hash_cap) + 15) / 16 * 16 + 64 > lds_budget) {
+        (lds_bytes_for(call.mode, call.next_cap, call.hash_cap) + 15) / 16 * 16 + team_bytes > lds_budget) {
         params.team = 0;
         call.stats.variant = (std::uint32_t)params.variant + 1;
     }
@@ -962,9 +963,9 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         }
     }
     if (call.mode != scratch_global_k) {
-        // a team's workgroup carries the leader's LDS areas plus the shared control block; one workgroup per query of the small batch
+        // a team's workgroup carries the leader's LDS areas plus the shared block; one workgroup per query of the small batch
         const std::uint64_t wave_lds_bytes = lds_bytes_for(call.mode, call.next_cap, call.hash_cap);
-        const std::uint64_t lds_bytes = params.team ? (wave_lds_bytes + 15) / 16 * 16 + 64 : wave_lds_bytes;
+        const std::uint64_t lds_bytes = params.team ? (wave_lds_bytes + 15) / 16 * 16 + team_bytes : wave_lds_bytes;
         args.team_offset = params.team ? (std::uint32_t)((wave_lds_bytes + 15) / 16 * 16) : 0u;
         const std::uint32_t grid = params.team ? pending
                                                : (std::uint32_t)std::min<std::uint64_t>(pending, (std::uint64_t)waves_for(lds_bytes) * compute_units_);
@@ -1215,6 +1216,10 @@ const char* snapshot_t::search_finish(search_call_t& call, search_stats_t* stats
                      call.ef, first_grid, 100 * ticks[0] / total, 100 * ticks[1] / total, 100 * ticks[2] / total,
                      100 * ticks[3] / total, 100 * ticks[4] / total, 100 * ticks[8] / total, 100 * ticks[9] / total, ticks[10],
                      100 * ticks[5] / total, total, ticks[6], ticks[7]);
+        if (ticks[15])
+            std::fprintf(stderr, "[usearch_amd] a team's helpers: %llu hops, ticks measuring per hop %.0f %.0f %.0f %.0f\n", ticks[15],
+                         (double)ticks[11] / (double)ticks[15], (double)ticks[12] / (double)ticks[15],
+                         (double)ticks[13] / (double)ticks[15], (double)ticks[14] / (double)ticks[15]);
     }
     if (call.want_clock && ws.d_wave_clock && first_grid) {
         // batch tail: between the first wave's start and the last wave's exit, how much wave-time was spent gone?

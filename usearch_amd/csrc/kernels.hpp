@@ -88,6 +88,26 @@ UA_DEVICE double xor_lane(double v, int offset) {
     return __builtin_bit_cast(double, low | (high << 32));
 }
 
+/// The smallest value held by any lane, in every lane: quad exchanges and the two row mirrors on the vector ALU (DPP), then the
+/// four rows through scalar registers — no trip through the LDS crossbar. All 64 lanes must be active.
+UA_DEVICE float wave_min_f32(float v) {
+    auto dpp = [](float x, int control) {
+        const int bits = __builtin_bit_cast(int, x);
+        if (control == 0)
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(bits, bits, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false));
+        if (control == 1)
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(bits, bits, 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false));
+        if (control == 2)
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(bits, bits, 0x141 /* row_half_mirror */, 0xf, 0xf, false));
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(bits, bits, 0x140 /* row_mirror */, 0xf, 0xf, false));
+    };
+    v = fminf(v, dpp(v, 0));
+    v = fminf(v, dpp(v, 1));
+    v = fminf(v, dpp(v, 2));
+    v = fminf(v, dpp(v, 3));
+    return fminf(fminf(read_lane_f32(v, 0), read_lane_f32(v, 16)), fminf(read_lane_f32(v, 32), read_lane_f32(v, 48)));
+}
+
 /// {float distance; u32 slot} of index.hpp:2097-2101, packed so that one 8-byte LDS access moves it.
 using cand_t = std::uint64_t;
 UA_DEVICE cand_t make_cand(float d, std::uint32_t slot) {
@@ -1106,22 +1126,33 @@ template <int scalar_ak> inline __host__ __device__ std::uint32_t query_lds_byte
 }
 
 /// What the waves of a TEAM share besides the leader's LDS areas (team_search_kernel): how many rows the hop in progress has
-/// gathered, and the query's norms.
+/// gathered, whether the leader measures a share of them itself, and the query's norms.
 struct team_t {
     std::uint32_t count;
-    std::uint32_t reserved[3];
+    std::uint32_t leader_in;
+    std::uint32_t reserved[2];
     query_norm_t a2;
 };
+static_assert(sizeof(team_t) <= 64, "the engine reserves 64 bytes for the control block");
 constexpr std::uint32_t team_exit_k = 0xFFFFFFFFu;
+/// The leader and four helpers: 4 × 8 lane groups take the ≤ 32 rows of a hop in ONE round. (Two helpers per SIMD with four rows
+/// each were measured: 7 % slower — a helper's round is instruction issue, which a second wave on the SIMD doubles.)
+constexpr int team_waves_k = 5;
 
-/// Wave `wave` of `team_ak` measures its share of the `count` rows gathered in `slots` — whole rows, each by a lane group in the
-/// very layout `measure_rows` uses everywhere, so every distance has the bits the one-wave kernel computes.
-template <int metric_ak, int scalar_ak, int lanes_ak, int loads_ak, int team_ak>
+/// The workgroup barrier of a team: LDS traffic settled, every wave arrived — and NOT the wait for this wave's global loads that
+/// `__syncthreads()` brings along: the leader keeps a neighbour list in flight across the barrier (requested a hop ahead), and
+/// waiting for it there would put a memory round trip back on every hop.
+UA_DEVICE void team_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+/// Part `part` of `parts` measures its share of the `count` rows gathered in `slots` — whole rows, each by a lane group in the
+/// very layout `measure_rows` uses everywhere, so every distance has the bits the one-wave kernel computes. `in_turn`: the parts
+/// take one round of a wave (64 / lanes rows) each in turn and the last one whatever is left, instead of equal shares.
+template <int metric_ak, int scalar_ak, int lanes_ak, int loads_ak>
 UA_DEVICE void team_share(const snapshot_view_t& ix, const std::uint8_t* query_lds, query_norm_t a2, const std::uint32_t* slots,
-                          float* out, std::uint32_t count, std::uint32_t wave) {
-    const std::uint32_t per_wave = (count + team_ak - 1) / team_ak;
-    const std::uint32_t begin = wave * per_wave;
-    const std::uint32_t end = begin + per_wave < count ? begin + per_wave : count;
+                          float* out, std::uint32_t count, std::uint32_t part, std::uint32_t parts, bool in_turn = false) {
+    const std::uint32_t per_part = in_turn ? 64u / lanes_ak : (count + parts - 1) / parts;
+    const std::uint32_t begin = part * per_part;
+    const std::uint32_t end = (in_turn && part + 1 == parts) || begin + per_part > count ? count : begin + per_part;
     if (begin < end)
         measure_rows<metric_ak, scalar_ak, lanes_ak, loads_ak, false, 1>(ix, query_lds, a2, slots + begin, out + begin, end - begin);
 }
@@ -1192,10 +1223,10 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
         if constexpr (team_ak > 1) {
             // the leader of a team: publish the gather list, take the first share, meet the helpers again when all of it is measured
             if (lane == 0)
-                team->count = count, team->a2 = a2;
-            __syncthreads();
-            team_share<metric_ak, scalar_ak, lanes_ak, loads_ak, team_ak>(ix, query_lds, a2, cand_slots, cand_distances, count, 0);
-            __syncthreads();
+                team->count = count, team->leader_in = 1u, team->a2 = a2;
+            team_barrier();
+            team_share<metric_ak, scalar_ak, lanes_ak, loads_ak>(ix, query_lds, a2, cand_slots, cand_distances, count, 0, 4);
+            team_barrier();
         } else {
             measure_rows<metric_ak, scalar_ak, lanes_ak, loads_ak, global_ak, rows_ak>(ix, query_lds, a2, cand_slots,
                                                                                        cand_distances, count);
@@ -1300,7 +1331,158 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     const bool inline_rows = inline_ak && ix.nbr0_rows != nullptr && !beam_level && cells <= 64 && ix.chunks == 1;
     uint4 ahead_row = {0u, 0u, 0u, 0u};
     tick(0);
-    for (;;) {
+    // ---- a team over the in-`top` frontier with a wide `top` (≥ 8 cells per lane: expansions above 256, where a commit costs about
+    // what measuring the hop's rows does) walks the beam as a PIPELINE (lists of ≤ 64 cells): the leader names the next member to
+    // expand BEFORE it commits the hop just measured, probes its list, hands the gather to the helpers and commits while they
+    // measure. What makes the early naming exact: the next member is the first open cell of the array the commit WOULD leave — the
+    // closest open member of `top` as it stands, or the closest newcomer if that one is strictly closer (it is then certain to
+    // land: ahead of a kept member). Every tie — two newcomers at the smallest distance, a newcomer level with the open member, a
+    // buffer that fills up mid-commit — is settled the long way: commit first, look again. Same commits in the same order, same
+    // counters, same bits (tests/test_gpu_search_parity.py: test_team_and_one_wave_agree, test_team_settles_ties_like_one_wave).
+    bool pipelined = false;
+    if constexpr (team_ak > 1 && in_top_ak && epl_ak >= 8)
+        pipelined = cells <= 64 && !inline_rows;
+    if constexpr (team_ak > 1 && in_top_ak && epl_ak >= 8) {
+        if (pipelined) {
+            bool pending = false;        // the hop measured last has not been committed yet
+            bool candidate = false;      // this lane holds one of its newcomers (lanes in list order)
+            float mine = 0.f;
+            std::uint32_t mine_slot = 0u;
+            // commit in list order with the reference's tests (index.hpp:4233-4240); the newcomer that is being expanded lands closed
+            auto commit = [&](std::uint32_t closed_lane) {
+                std::uint64_t todo = ballot(candidate && (top.size < ef || mine < radius)); // radius only shrinks
+                while (todo) {
+                    const std::uint32_t i = (std::uint32_t)__ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const float d = read_lane_f32(mine, i);
+                    if (!(top.size < ef || d < radius))
+                        continue;
+                    const std::uint32_t successor = read_lane_u32(mine_slot, i);
+                    top.insert(d, i == closed_lane ? successor | top.closed_bit_k : successor, ef, radius);
+                }
+                pending = false;
+            };
+            for (;;) {
+                float open_distance = 0.f;
+                std::uint32_t open_slot = 0u, owner_lane = 0u, owner_cell = 0u;
+                const bool has_open = top.first_open(open_distance, open_slot, owner_lane, owner_cell);
+                std::uint32_t from_lane = 64u; // the newcomer expanded next, if it is one
+                if (pending) {
+                    const std::uint64_t newcomers = ballot(candidate);
+                    const std::uint32_t room = ef - top.size;
+                    bool exact = room == 0u || room >= popcount64(newcomers); // else the buffer fills up mid-commit
+                    const bool lands = candidate && (room != 0u || mine < radius);
+                    if (exact && ballot(lands)) {
+                        const float best = wave_min_f32(lands ? mine : __builtin_inff());
+                        const std::uint64_t at_best = ballot(lands && mine == best);
+                        if (!has_open || best < open_distance) {
+                            if (at_best & (at_best - 1))
+                                exact = false; // two newcomers at the smallest distance: their order in the array decides
+                            else
+                                from_lane = (std::uint32_t)__ffsll((long long)at_best) - 1;
+                        } else if (best == open_distance)
+                            exact = false; // a newcomer lands in front of its equal
+                    }
+                    if (!exact) {
+                        commit(64u);
+                        continue;
+                    }
+                }
+                if (from_lane == 64u && !has_open) {
+                    if (pending)
+                        commit(64u); // nothing of it lands (or it would have been named): kept for the shape of the loop
+                    break;
+                }
+                std::uint32_t expanded;
+                std::uint32_t neighbor = none_slot_k;
+                std::uint32_t likely = none_slot_k; // where the walk goes after this hop unless it finds something closer
+                if (from_lane != 64u) {
+                    expanded = read_lane_u32(mine_slot, from_lane);
+                    if (lane < cells) // nobody could ask for a newcomer's list ahead: a round trip of ≈ 0.4 µs, on a third of the hops
+                        neighbor = list_of(expanded)[lane];
+                    likely = has_open ? open_slot : none_slot_k; // the open member stays first in line
+                } else {
+                    expanded = open_slot;
+                    top.close(owner_lane, owner_cell);
+                    if (expanded == ahead_slot)
+                        neighbor = ahead_cell;
+                    else if (lane < cells)
+                        neighbor = list_of(expanded)[lane];
+#ifdef USEARCH_AMD_PHASES
+                    diagnostic_ready += expanded == ahead_slot ? 1u : 0u;
+#endif
+                    float likely_distance;
+                    std::uint32_t likely_lane, likely_cell;
+                    if (!top.first_open(likely_distance, likely, likely_lane, likely_cell))
+                        likely = none_slot_k;
+                }
+                ++cycles;
+                const bool present = neighbor != none_slot_k;
+                const std::uint32_t present_count = popcount64(ballot(present));
+                std::uint32_t count = 0;
+                tick(1);
+                if (present_count) {
+                    if (visits_count + present_count > visits_limit) {
+                        overflow = true;
+                        break;
+                    }
+                    std::uint32_t h = hash_slot(neighbor) & visits_mask;
+                    std::uint32_t old = neighbor; // an absent lane probes nothing
+                    if (present)
+                        old = atomicCAS(visits + h, none_slot_k, neighbor);
+                    while (old != none_slot_k && old != neighbor) { // linear probing, index.hpp:1085-1211
+                        h = (h + 1) & visits_mask;
+                        old = atomicCAS(visits + h, none_slot_k, neighbor);
+                    }
+                    const bool fresh = present && old == none_slot_k;
+                    const std::uint64_t fresh_mask = ballot(fresh);
+                    count = popcount64(fresh_mask);
+                    visits_count += count;
+                    if (fresh)
+                        cand_slots[rank_below(fresh_mask, lane)] = neighbor; // keeps list order
+                }
+                // its list is requested now, a hop ahead (the commit below may still put a newcomer of the hop before in front of it) —
+                // and only now that this hop's own list has been consumed: loads return in order, and a wait for that list placed
+                // after this request would wait for both
+                if (likely != ahead_slot) {
+                    ahead_slot = likely;
+                    if (likely != none_slot_k)
+                        ahead_cell = lane < cells ? list_of(likely)[lane] : none_slot_k;
+                }
+                tick(2);
+                if (count) {
+                    if (lane == 0)
+                        team->count = count, team->leader_in = 0u, team->a2 = a2;
+                    team_barrier(); // the helpers fetch and measure the rows …
+                }
+                if (pending)
+                    commit(from_lane); // … while the hop before lands in `top`
+                // … and if that put a newcomer in front of the member whose list was just asked for, its list is asked for too
+                {
+                    float ahead_distance;
+                    std::uint32_t first = none_slot_k, ahead_lane, ahead_index;
+                    if (!top.first_open(ahead_distance, first, ahead_lane, ahead_index))
+                        first = none_slot_k;
+                    if (first != ahead_slot) {
+                        ahead_slot = first;
+                        if (first != none_slot_k)
+                            ahead_cell = lane < cells ? list_of(first)[lane] : none_slot_k;
+                    }
+                }
+                tick(4);
+                if (count) {
+                    team_barrier(); // every share is in LDS
+                    candidate = lane < count;
+                    mine = candidate ? cand_distances[lane] : 0.f;
+                    mine_slot = candidate ? cand_slots[lane] : 0u;
+                    computed += count;
+                    pending = true;
+                }
+                tick(3);
+            }
+        }
+    }
+    for (; !pipelined;) {
         std::uint32_t expanded;
         if constexpr (in_top_ak) {
             // the closest member not expanded yet; every kept member is within the radius, so index.hpp:4210 never fires
@@ -1587,16 +1769,18 @@ __global__ __launch_bounds__(64, kernel_waves(variant_ak, epl_ak, frontier_ak, l
 }
 
 /**
- *  FOUR waves per query, for batches too small to fill the chip with one wave each (a `usearch_search` caller's single query
- *  above all) over long rows: wave 0 walks exactly as `search_kernel` does — pop, list, visited set, ordered commit, `top` in its
- *  registers — and the three others help with the one step that is bandwidth a lone wave cannot pull: the hop's ≤ M0 rows are
- *  split four ways (`team_share`), two workgroup barriers per hop. Same distances bit for bit (whole rows per lane group), same
- *  order of commits, same counters. The helpers share the leader's LDS image of the query and its gather list.
+ *  FIVE waves per query, for batches too small to fill the chip with one wave each (a `usearch_search` caller's single query
+ *  above all) over long rows: wave 0 walks — pop, list, visited set, ordered commit, `top` in its registers — and the others take
+ *  the one step a lone wave is slow at: the hop's ≤ M0 rows, whole rows per lane group (`team_share`), two workgroup barriers per
+ *  hop. With a wide `top` over the in-`top` frontier the leader does not measure at all: it commits the hop before while the four
+ *  helpers measure this one (`search_one`, the pipelined beam); otherwise waves 0 … 3 measure a quarter each and the fifth only
+ *  keeps the barriers company. Same distances bit for bit, same order of commits, same counters. The helpers share the leader's
+ *  LDS image of the query and its gather list.
  */
 template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak, int frontier_ak>
-__global__ __launch_bounds__(256) void team_search_kernel(const snapshot_view_t ix, const search_args_t args) {
+__global__ __launch_bounds__(64 * team_waves_k) void team_search_kernel(const snapshot_view_t ix, const search_args_t args) {
     static_assert(mode_ak != scratch_global_k, "the team walks with its heaps in LDS");
-    constexpr int team_ak = 4;
+    constexpr int team_ak = team_waves_k;
     constexpr int loads_ak = variant_unroll(variant_ak);
     extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
     std::uint8_t* query_lds = lds;
@@ -1623,19 +1807,50 @@ __global__ __launch_bounds__(256) void team_search_kernel(const snapshot_view_t 
         }
         if (lane_id() == 0)
             team->count = team_exit_k;
-        __syncthreads();
+        team_barrier();
     } else {
         const std::uint32_t* cand_slots = reinterpret_cast<const std::uint32_t*>(heaps + layout.cand_slots);
         float* cand_distances = reinterpret_cast<float*>(heaps + layout.cand_distances);
+        // whose turn a helper has when the leader stays out: the waves of the other SIMDs first, the leader's SIMD-mate (waves go
+        // to the four SIMDs round-robin) last — it gets rows only when a hop gathers more than the others take in one round each,
+        // and that matters: the leader's commit is all vector ALU work
+        const std::uint32_t turn = wave - 1;
+#ifdef USEARCH_AMD_PHASES // every helper's clock: what it spent between the two barriers of a hop
+        std::uint64_t helper_mark = args.phases ? __builtin_amdgcn_s_memtime() : 0, helper_busy = 0, helper_idle = 0, helper_hops = 0;
+#endif
         for (;;) {
-            __syncthreads(); // the leader has published a hop (or the end)
+            team_barrier(); // the leader has published a hop (or the end)
+#ifdef USEARCH_AMD_PHASES
+            if (args.phases) {
+                const std::uint64_t now = __builtin_amdgcn_s_memtime();
+                helper_idle += now - helper_mark, helper_mark = now;
+            }
+#endif
             const std::uint32_t count = uniform_u32(team->count);
             if (count == team_exit_k)
                 break;
             const query_norm_t a2 = team->a2;
-            team_share<metric_ak, scalar_ak, lanes_ak, loads_ak, team_ak>(ix, query_lds, a2, cand_slots, cand_distances, count, wave);
-            __syncthreads(); // every share is in LDS: the leader commits
+            if (uniform_u32(team->leader_in)) {
+                if (wave < 4)
+                    team_share<metric_ak, scalar_ak, lanes_ak, loads_ak>(ix, query_lds, a2, cand_slots, cand_distances, count, wave, 4);
+            } else
+                team_share<metric_ak, scalar_ak, lanes_ak, loads_ak>(ix, query_lds, a2, cand_slots, cand_distances, count, turn,
+                                                                     team_ak - 1, true);
+#ifdef USEARCH_AMD_PHASES
+            if (args.phases) {
+                const std::uint64_t now = __builtin_amdgcn_s_memtime();
+                helper_busy += now - helper_mark, helper_mark = now, ++helper_hops;
+            }
+#endif
+            team_barrier(); // every share is in LDS: the leader commits
         }
+#ifdef USEARCH_AMD_PHASES
+        if (args.phases && lane_id() == 0) { // [11 … 14] what each helper spent measuring, [15] the first one's hops
+            atomicAdd(args.phases + 10 + wave, (unsigned long long)helper_busy);
+            if (wave == 1)
+                atomicAdd(args.phases + 15, (unsigned long long)helper_hops);
+        }
+#endif
     }
 }
 

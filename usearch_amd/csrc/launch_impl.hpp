@@ -10,7 +10,7 @@ namespace usearch_amd {
 
 template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak, int frontier_ak = frontier_heap_k>
 hipError_t launch_search_one(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
-    if (p.team) { // four waves per query: rows of ≥ 128 bytes, the 12-deep build of the common pairs, heaps in LDS
+    if (p.team) { // five waves per query: rows of ≥ 128 bytes, the 12-deep build of the common pairs, heaps in LDS
         if constexpr (lanes_ak == 8 && variant_ak == variant_u12_w2_k && mode_ak != scratch_global_k) {
             auto team_kernel = team_search_kernel<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, epl_ak, frontier_ak>;
             if (p.lds_bytes > 64 * 1024) {
@@ -19,7 +19,7 @@ hipError_t launch_search_one(const launch_params_t& p, const snapshot_view_t& vi
                 if (e != hipSuccess)
                     return e;
             }
-            hipLaunchKernelGGL(team_kernel, dim3(p.grid), dim3(256), p.lds_bytes, p.stream, view, args);
+            hipLaunchKernelGGL(team_kernel, dim3(p.grid), dim3(64 * team_waves_k), p.lds_bytes, p.stream, view, args);
             return hipGetLastError();
         } else {
             return hipErrorInvalidValue;
