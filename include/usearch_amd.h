@@ -73,7 +73,7 @@ typedef struct usearch_amd_stats_t {
     uint32_t grid;           /**< persistent waves of the first launch */
     uint32_t lds_bytes;      /**< LDS bytes per wave of the first launch */
     uint32_t frontier;       /**< frontier of the first launch (values of usearch_amd_tuning_t::frontier) */
-    uint32_t variant;        /**< kernel build of the first launch (values of usearch_amd_tuning_t::variant; 5 = four waves per query,
+    uint32_t variant;        /**< kernel build of the first launch (values of usearch_amd_tuning_t::variant; 5 = five waves per query,
                                   the build small batches over rows of ≥ 128 bytes get on their own) */
     float tail_idle;         /**< with wave_clock: share of (waves × span) during which waves were not there — batch tail */
     float span_ms;           /**< with wave_clock: first wave start → last wave exit, device wall clock */

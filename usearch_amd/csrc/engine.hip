@@ -886,7 +886,7 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
     params.stream = stream;
     call.stats = search_stats_t{};
     call.stats.frontier = frontier == frontier_top_k ? 2u : 1u;
-    call.stats.variant = team ? 5u : (std::uint32_t)variant + 1; // 5 = the team build (four waves per query)
+    call.stats.variant = team ? 5u : (std::uint32_t)variant + 1; // 5 = the team build (five waves per query)
     call.stats.top_cells = entries_per_lane;
 
     // diagnostic: per-phase shader-clock ticks of the search kernel, printed to stderr (USEARCH_AMD_PHASES=1)

@@ -72,7 +72,7 @@ struct launch_params_t {
     std::uint32_t grid;
     std::uint32_t lds_bytes;
     hipStream_t stream;
-    std::uint32_t team = 0;       ///< 1 = four waves per query (team_search_kernel): small batches over long rows
+    std::uint32_t team = 0;       ///< 1 = five waves per query (team_search_kernel): small batches over long rows
 };
 
 /**

@@ -33,7 +33,7 @@ namespace usearch_amd {
 //  Wave-level helpers (wave = 64 lanes = the whole workgroup)
 // ---------------------------------------------------------------------------------------------------------------------
 
-/// Lane of the wave. Workgroups are one wave wide except the team kernel's (four waves share a query): the mask costs nothing
+/// Lane of the wave. Workgroups are one wave wide except the team kernel's (five waves share a query): the mask costs nothing
 /// where the compiler knows the workgroup is 64 wide.
 UA_DEVICE std::uint32_t lane_id() { return threadIdx.x & 63u; }
 
