@@ -10,7 +10,7 @@
  *  until their results are there. Pure host logic, no HIP: `tests/cpp/combiner_test.cpp` drives it with a mock launch.
  *
  *  Left at that, T looping callers settle into TWO groups of T/2 that alternate (one in flight, one waiting: each call then
- *  costs two launches of wall time, profiles/r04_single_query/coalesce.log: 7.25 ms per call for a 3.5 ms launch). The callers
+ *  costs two launches of wall time, profiles/r04_single_query/: 5.5 ms per call for a 2.7 ms launch). The callers
  *  of the launch that just finished are microseconds away from calling again, so the one who launches next gives them a
  *  moment — at most an eighth of the last launch's duration and `window_limit` (200 us unless told otherwise) — and stops waiting the
  *  instant as many calls have arrived as the finished launch had served. A lone caller never waits (its own return is the one

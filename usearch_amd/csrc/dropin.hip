@@ -153,9 +153,9 @@ struct index_t {
     /// `usearch_search` calls in flight share a launch (combiner.hpp): whoever finds nobody launching takes every compatible call
     /// that is waiting and runs them as one batch, after giving the callers of the launch before up to `USEARCH_AMD_COALESCE_WINDOW_US`
     /// (200) microseconds — never more than an eighth of that launch, nothing for a lone caller — to call again: looping callers then go
-    /// out in one launch instead of two alternating halves. A lone caller is untouched (3.1 ms / 0.34 ms per call at ef 608 / 64 on the
-    /// headline index either way); 16 native callers at ef 608: 1 420 → 4 775 calls per second (11.3 → 3.35 ms per call), 64 callers:
-    /// 1 844 → 17 850 (34.7 → 3.6 ms), 64 callers at ef 64: 9.6 k → 84.4 k (profiles/r04_single_query/). `USEARCH_AMD_COALESCE=0`
+    /// out in one launch instead of two alternating halves. A lone caller is untouched (2.7 ms / 0.35 ms per call at ef 608 / 64 on the
+    /// headline index either way); 16 native callers at ef 608: 1 640 → 5 530 calls per second (9.8 → 2.9 ms per call), 64 callers:
+    /// 2 068 → 20 546 (30.9 → 3.1 ms), 64 callers at ef 64: 9.1 k → 80.3 k (profiles/r04_single_query/). `USEARCH_AMD_COALESCE=0`
     /// (read when the index is created) turns it off.
     bool coalesce = env_size("USEARCH_AMD_COALESCE", 1) != 0;
     combiner_t combiner;
