@@ -247,3 +247,22 @@ def test_calls_in_flight_share_a_launch():
                            os.path.join(root, "tests", "cpp", "combiner_test.cpp"), "-o", binary])
     out = subprocess.run([binary], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "PASSED" in out.stdout, out.stdout + out.stderr
+
+
+
+def test_calls_in_flight_share_a_launch_under_the_thread_sanitizer():
+    """The same program under ThreadSanitizer (clang's runtime: it knows `pthread_cond_clockwait`, which the launcher's timed wait
+    for returning callers uses): no data race, no lock-order report in the combiner."""
+    import subprocess
+    compiler = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(compiler):
+        pytest.skip("no clang++ with a ThreadSanitizer runtime here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    binary = "/tmp/usearch_amd_combiner_test_tsan"
+    built = subprocess.run([compiler, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread",
+                            os.path.join(root, "tests", "cpp", "combiner_test.cpp"), "-o", binary], capture_output=True, text=True)
+    if built.returncode != 0:
+        pytest.skip("the ThreadSanitizer runtime does not link here: " + built.stderr[-300:])
+    out = subprocess.run([binary], capture_output=True, text=True, timeout=300, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0"))
+    assert "ThreadSanitizer" not in out.stderr, out.stderr[-3000:]
+    assert out.returncode == 0 and "PASSED" in out.stdout, out.stdout + out.stderr[-1000:]
