@@ -689,10 +689,12 @@ def main() -> None:
     expansion = expansion or 64
 
     # ---- placement: where the workspace's scratch block and the matrix land in HBM decides which of four speeds the walk runs at
-    #      (profiles/r03_placement/README.md). The ENGINE draws both and lets the walk judge them (csrc/placement.hpp): nothing to do
-    #      here but to report what it drew.
-    placement = {"matrix": index.placement, "policy": "engine: scratch block drawn by run_ladder (<= 8 candidates timed by the launch's "
-                 "first queries), matrix by snapshot_t::tune_placement (<= 4 copies judged by a self-search)"}
+    #      (csrc/placement.hpp). The ENGINE tries placements inside the launches that fill the chip — the sweep above was made of such
+    #      launches — and lets the walk itself judge them on the caller's queries: nothing to do here but to report what it did
+    #      (read again after the timed steps: trials may still be under way during the warm-up).
+    placement_policy = ("engine: scratch block drawn by run_ladder when a chip-filling launch needs a new one (<= 8 candidates timed by the "
+                        "launch's first queries); matrix: one fresh device-to-device copy per chip-filling launch judged against the incumbent "
+                        "on that launch's first queries at the caller's expansion (<= 8 trials, ended by three wins of the incumbent in a row)")
 
     # ---- warmup, then EXACTLY `steps` timed steps between barriers
     flush_native_stdio()
@@ -723,6 +725,8 @@ def main() -> None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    placement = {"matrix": index.placement, "policy": placement_policy}
 
     # ---- algorithmic bytes of one step from the per-query counters:
     #      B_q = computed·bpv + visited·(4·M0) + k·8 + bpv        (upper-level lists counted at the level-0 size)
@@ -867,10 +871,18 @@ def main() -> None:
                 if step:
                     times.append(stats_first.kernel_ms)
             first_placement = {"kernel_ms": float(np.mean(times)), "frac": step_bytes / (float(np.mean(times)) / 1e3) / 1e9 / HBM_PEAK_GBPS}
-            log(f"[bench] with the placement draws off (a fresh copy, first placement of everything): kernel {first_placement['kernel_ms']:.2f} ms "
-                f"against {kernel_s * 1e3:.2f} ms drawn")
             undrawn.close()
             del undrawn
+            # ... and the engine's own placement once more AFTER it, so that the order of the two measurements cannot make the sign
+            again = []
+            for step in range(6):
+                stats_again = search_step(expansion, True)
+                if step:
+                    again.append(stats_again.kernel_ms)
+            first_placement["kernel_ms_placed_before"] = kernel_s * 1e3
+            first_placement["kernel_ms_placed_after"] = float(np.mean(again))
+            log(f"[bench] with the placement trials off (a fresh copy, first placement of everything): kernel {first_placement['kernel_ms']:.2f} ms; "
+                f"the engine's placement before / after that measurement: {kernel_s * 1e3:.2f} / {first_placement['kernel_ms_placed_after']:.2f} ms")
         except (RuntimeError, MemoryError) as error:
             log(f"[bench] no first-placement check: {error}")
         finally:
@@ -960,6 +972,7 @@ def main() -> None:
                          "frac": achieved / HBM_PEAK_GBPS,
                          "frac_first_placement": first_placement["frac"] if first_placement else None,
                          "kernel_ms_first_placement": first_placement["kernel_ms"] if first_placement else None,
+                         "kernel_ms_after_first_placement_check": first_placement["kernel_ms_placed_after"] if first_placement else None,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "search_kernel", "kernel_ms": kernel_s * 1e3,
                          # template arguments of the timed instantiation as rocprofv3 prints them: metric and scalar codes, lanes

@@ -114,13 +114,17 @@ USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_row_stride(usearch_amd_snapshot_t
 /** Bytes of HBM the snapshot occupies (cf. `usearch_memory_usage`, c/usearch.h:139). */
 USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_device_bytes(usearch_amd_snapshot_t snapshot);
 /** How the matrix of stored rows was placed in HBM. Where a multi-gigabyte array lands decides how fast the walk runs over it
- *  (the headline batch: 45.4 … 51.9 ms for the same bytes), and no synthetic probe tells the placements apart, so the loader and
- *  the builder draw a few placements (device-to-device copies), let a short SELF-SEARCH of stored rows judge each and keep the
- *  fastest (csrc/placement.hpp, `snapshot_t::tune_placement`; USEARCH_AMD_PLACEMENT_DRAWS, default 8, 1 = off; arrays under
- *  USEARCH_AMD_PLACEMENT_MIN_BYTES = 1 GiB take the first). `judge_ms` receives up to 8 times in MILLISECONDS (lower is better),
- *  `*kept` which draw won, `*probe_ms` what the draws cost in all. */
+ *  (the headline batch: 44.8 … 51.9 ms for the same bytes; the state belongs to the physical frames, which the driver releases late
+ *  and hands out by rules of its own), and no synthetic probe tells the placements apart. So the first launches that fill the chip
+ *  each try ONE fresh device-to-device copy of the matrix against the incumbent — both timed on that launch's own first queries at
+ *  the caller's expansion — and keep the faster (csrc/placement.hpp, `snapshot_t::try_matrix_placement`; at most
+ *  USEARCH_AMD_PLACEMENT_DRAWS = 8 trials, 1 = off, ended early by three wins of the incumbent in a row; arrays under
+ *  USEARCH_AMD_PLACEMENT_MIN_BYTES = 1 GiB stay where they are). `*draws` = trials made so far, `*kept` = how many moved the
+ *  matrix, `judge_ms[i]` / `incumbent_ms[i]` = the candidate's / the incumbent's milliseconds in trial i (up to 8 each),
+ *  `*probe_ms` = what the trials have cost in all. */
 USEARCH_AMD_EXPORT void usearch_amd_snapshot_placement(usearch_amd_snapshot_t snapshot, uint32_t* draws, uint32_t* kept,
                                                        float* judge_ms, float* probe_ms);
+USEARCH_AMD_EXPORT void usearch_amd_snapshot_placement_incumbents(usearch_amd_snapshot_t snapshot, float* incumbent_ms);
 /** The placement probe alone, on the resident matrix or a part of it: GB/s of a dependency-free gather of random stored rows
  *  among rows [first_row, first_row + rows) (`rows` = 0: to the end). Diagnostics (scripts/placement_study.py). */
 USEARCH_AMD_EXPORT float usearch_amd_snapshot_gather_probe(usearch_amd_snapshot_t snapshot, uint64_t first_row, uint64_t rows,

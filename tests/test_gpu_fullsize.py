@@ -1,6 +1,7 @@
 """Parity at the BASELINE configurations' own scale, under the driver: config 2 at full size (1M x 768 f32 cosine) and 2M-vector
 slices of configs 4 and 5 (96-d i8 L2, 128-bit Hamming) — index built on the device, saved, and handed to the REAL reference
-(`oracle/_ref`, `usearch_view_buffer`); the same >= 256 queries searched by both. Integer-valued pairs: keys, distance bits,
+(`oracle/_ref`, `usearch_view_buffer`); the same >= 512 queries searched by both (more than two per compute unit: the one-wave
+kernel the bench lines time, not the team build of small batches). Integer-valued pairs: keys, distance bits,
 counts and both traversal counters identical, ties included. Float pair: the oracle in the kernels' summation layout bit for
 bit, the reference within the stated tolerance with IDENTICAL labels at every position whose neighbouring reference distances
 are farther apart than twice that tolerance (tests/util.py `assert_float_parity`). (The 10M / 100M / 125M configurations themselves
@@ -21,7 +22,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CONFIGS = [  # (vectors, dimensions, dtype, metric, queries, k, expansion)
-    (1_000_000, 768, "f32", "cos", 256, 10, 64),
+    (1_000_000, 768, "f32", "cos", 640, 10, 64),   # > 2 queries per CU: the one-wave kernel every BASELINE line times
     (2_000_000, 96, "i8", "l2sq", 512, 10, 64),
     (2_000_000, 128, "b1", "hamming", 512, 10, 64),
 ]
@@ -46,6 +47,7 @@ def test_baseline_shapes_at_scale_match_the_reference(reference, n, dim, dtype, 
     reference_index.expansion_search = expansion
     got = index.search(batch, k, expansion=expansion, dtype=dtype)
     assert got.stats.passes == 1, "the default scratch must hold these traversals"
+    assert got.stats.variant != 5, "a batch of this size must walk with one wave per query (the benchmarked kernel), not the team build"
     rkeys, rdists, rcounts, rvisited, rcomputed = reference_index.search(batch, k, dtype=dtype, threads=0)
     assert np.array_equal(got.counts, rcounts)
     if util.exact_pair(metric, dtype):

@@ -318,6 +318,53 @@ def test_team_settles_ties_like_one_wave(reference, monkeypatch, metric, dtype, 
         assert np.array_equal(team.computed_per_query, plain.computed_per_query)
 
 
+def test_the_benchmarked_instantiation_matches_the_oracle(reference):
+    """The kernel every BASELINE line of `bench.py` times, held against the oracle ITSELF (not piece by piece): rows of 768 f16
+    (8 lanes per row, 12 chunks per lane), expansion 608 (16 `top` cells per lane, frontier in `top`), a batch that fills the chip
+    and then some (more queries than the 2 048 persistent waves, so tickets are drawn more than once) ⇒ one wave per query,
+    `search_kernel<cos, f16, 8, u12x2, global-hash, 16, in-top>`, the visited sets in per-wave slabs of global memory at 65 536
+    cells. Keys, distance bits, counts and BOTH traversal counters of every query equal the oracle's in the kernels' summation
+    layout; the reference-shaped heap over the same batch equals its oracle too. (cpp/test.cpp:499-503)"""
+    import torch
+
+    import bench
+    import usearch_amd
+    from usearch_amd import Tuning
+    import os
+    n, dim, dtype, count, expansion = 20_000, 768, "f16", 2_560, 608
+    host_threads = max(1, min(16, os.cpu_count() or 1))
+    device = torch.device("cuda", 0)
+    data = bench.synthetic_vectors_device(n, dim, dtype, 42, device)
+    built = usearch_amd.build(None, "cos", dtype, device_pointer=data.data_ptr(), count=n, stride=data.stride(0), ndim=dim)
+    queries = bench.synthetic_vectors_device(count, dim, dtype, 43, device).cpu().numpy().view(np.float16)
+    del data
+    image = built.save_buffer()
+    index = usearch_amd.Index.restore(image)
+    got = index.search(queries, 10, expansion=expansion, dtype=dtype)
+    assert got.stats.passes == 1
+    assert (got.stats.mode, got.stats.variant, got.stats.frontier, got.stats.top_cells) == (2, 4, 2, 16), \
+        "not the instantiation the bench times"
+    assert got.stats.grid >= 2048 and count > got.stats.grid
+    keys, dists, counts, visited, computed = util.oracle_search(image, queries, 10, dtype, expansion, lanes=index.lanes_per_row,
+                                                                frontier_in_top=True, threads=host_threads)
+    assert np.array_equal(got.keys, keys) and np.array_equal(got.counts, counts)
+    assert util.same_float_bits(got.distances, dists)
+    assert np.array_equal(got.visited_per_query, visited) and np.array_equal(got.computed_per_query, computed)
+    # the 16-waves-per-CU build that batches of >= 40 000 queries take, on the same batch: nothing but the schedule differs
+    wide = index.search(queries, 10, expansion=expansion, dtype=dtype, tuning=Tuning(variant=1))
+    assert (wide.stats.mode, wide.stats.variant, wide.stats.frontier) == (2, 1, 2)
+    assert np.array_equal(wide.keys, keys) and util.same_float_bits(wide.distances, dists)
+    assert np.array_equal(wide.visited_per_query, visited) and np.array_equal(wide.computed_per_query, computed)
+    # the reference's heap, same batch, against the reference-shaped oracle; on this index the two frontiers name the same members
+    heap = index.search(queries, 10, expansion=expansion, dtype=dtype, tuning=Tuning(frontier=1))
+    assert heap.stats.frontier == 1 and heap.stats.mode == 2
+    hkeys, hdists, hcounts, hvisited, hcomputed = util.oracle_search(image, queries, 10, dtype, expansion, lanes=index.lanes_per_row,
+                                                                     threads=host_threads)
+    assert np.array_equal(heap.keys, hkeys) and util.same_float_bits(heap.distances, hdists)
+    assert np.array_equal(heap.visited_per_query, hvisited) and np.array_equal(heap.computed_per_query, hcomputed)
+    assert util.same_float_bits(heap.distances, got.distances)
+
+
 def test_large_expansion(reference):
     from usearch_amd import Index
     image, _, _ = util.build_image(4000, 48, "l2sq", "f32", seed=51)

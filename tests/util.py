@@ -125,11 +125,19 @@ def same_float_bits(a: np.ndarray, b: np.ndarray) -> bool:
 
 
 def oracle_search(image: np.ndarray, queries: np.ndarray, k: int, dtype: str, expansion: int = 64, lanes: int = 0,
-                  exact: bool = False, frontier_in_top: bool = False):
+                  exact: bool = False, frontier_in_top: bool = False, threads: int = 1):
     """`frontier_in_top`: restate the engine's heap-less frontier (kernels.hpp frontier_top_k) instead of the reference's heap;
-    GPU tests pass what the engine reports it ran (`stats.frontier == 2`)."""
-    return oraclebind.OracleIndex(image).search(queries, k, dtype=dtype, expansion=expansion, lanes=lanes, exact=exact,
-                                                frontier_in_top=frontier_in_top)
+    GPU tests pass what the engine reports it ran (`stats.frontier == 2`). `threads` > 1 splits the batch over that many host
+    threads (queries are independent; the oracle's mode switch is thread-local, its index read-only)."""
+    oracle = oraclebind.OracleIndex(image)
+    if threads <= 1 or len(queries) < 2 * threads:
+        return oracle.search(queries, k, dtype=dtype, expansion=expansion, lanes=lanes, exact=exact, frontier_in_top=frontier_in_top)
+    from concurrent.futures import ThreadPoolExecutor
+    bounds = np.linspace(0, len(queries), threads + 1).astype(int)
+    with ThreadPoolExecutor(threads) as pool:
+        parts = list(pool.map(lambda i: oracle.search(queries[bounds[i]:bounds[i + 1]], k, dtype=dtype, expansion=expansion, lanes=lanes,
+                                                      exact=exact, frontier_in_top=frontier_in_top), range(threads)))
+    return tuple(np.concatenate([part[field] for part in parts]) for field in range(5))
 
 
 def with_64_bit_dimensions(image: np.ndarray) -> np.ndarray:

@@ -267,6 +267,11 @@ void usearch_amd_snapshot_placement(usearch_amd_snapshot_t s, uint32_t* draws, u
     if (probe_ms)
         *probe_ms = placement.probe_ms;
 }
+void usearch_amd_snapshot_placement_incumbents(usearch_amd_snapshot_t s, float* incumbent_ms) {
+    const placement_t& placement = as_snapshot(s)->placement();
+    for (int i = 0; i < placement_max_draws_k; ++i)
+        incumbent_ms[i] = placement.incumbent_ms[i];
+}
 int usearch_amd_snapshot_scalar_kind(usearch_amd_snapshot_t s) { return scalar_to_c(as_snapshot(s)->scalar()); }
 int usearch_amd_snapshot_metric_kind(usearch_amd_snapshot_t s) { return metric_to_c(as_snapshot(s)->metric()); }
 size_t usearch_amd_snapshot_lanes_per_row(usearch_amd_snapshot_t s) { return as_snapshot(s)->lanes_per_row(); }

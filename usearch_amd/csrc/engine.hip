@@ -119,7 +119,7 @@ const char* workspace_t::reserve(std::size_t queries_wanted, std::size_t scratch
             parked.push_back(d_scratch);
         if (parked.size() > 12) {
             for (void* p : parked)
-                (void)hipFree(p);
+                placed_free(p);
             parked.clear();
         }
         d_scratch = nullptr;
@@ -127,7 +127,7 @@ const char* workspace_t::reserve(std::size_t queries_wanted, std::size_t scratch
     }
     if (scratch_wanted > scratch_bytes) {
         if (d_scratch)
-            (void)hipFree(d_scratch);
+            placed_free(d_scratch);
         d_scratch = nullptr;
         scratch_bytes = 0;
         UA_HIP(block_malloc((void**)&d_scratch, scratch_wanted)); // big blocks for chip-filling launches are drawn by run_ladder
@@ -171,10 +171,10 @@ const char* workspace_t::reserve_wave_clock(std::size_t waves) {
 }
 
 void workspace_t::destroy() {
-    for (void* p : {(void*)d_status, (void*)d_todo, (void*)d_queue, (void*)d_peaks, (void*)d_scratch, (void*)d_stage,
-                    (void*)d_wave_clock})
+    for (void* p : {(void*)d_status, (void*)d_todo, (void*)d_queue, (void*)d_peaks, (void*)d_stage, (void*)d_wave_clock})
         if (p)
             (void)hipFree(p);
+    placed_free(d_scratch); // a block of `block_malloc` (possibly a mapped range)
     if (h_status)
         (void)hipHostFree(h_status);
     if (h_stage)
@@ -191,6 +191,10 @@ void workspace_t::destroy() {
 const char* snapshot_t::take(workspace_t*& out) {
     std::unique_lock<std::mutex> lock(pool_mutex_);
     for (;;) {
+        if (placing_) { // a launch is trying another placement of the matrix (`try_matrix_placement`): nobody else reads it meanwhile
+            pool_ready_.wait(lock);
+            continue;
+        }
         if (!idle_.empty()) {
             out = idle_.back();
             idle_.pop_back();
@@ -263,107 +267,89 @@ __global__ void inline_rows_kernel(const std::uint8_t* vectors, const std::uint3
     }
 }
 
-const char* snapshot_t::tune_placement() {
-    const std::size_t draws = std::min<std::size_t>(placement_max_draws_k, env_size("USEARCH_AMD_PLACEMENT_DRAWS", 8));
-    if (draws <= 1 || !d_vectors_ || tuned_vectors_ == d_vectors_ || view_.size < 65536 ||
-        vectors_bytes_ < env_size("USEARCH_AMD_PLACEMENT_MIN_BYTES", (std::size_t)1 << 30))
-        return nullptr;
-    const auto started = std::chrono::steady_clock::now();
-    if (hipSetDevice(device_) != hipSuccess)
-        return nullptr;
-    // the judge: 4 096 stored rows searched for their 10 nearest at expansion 128 — a few milliseconds of the real walk
-    const std::size_t queries = 4096, wanted = 10, expansion = 128;
-    struct buffers_t {
-        std::vector<void*> pointers;
-        ~buffers_t() {
-            for (void* p : pointers)
-                (void)hipFree(p);
-        }
-        void* take(std::size_t bytes) {
-            void* p = nullptr;
-            if (hipMalloc(&p, bytes) != hipSuccess)
-                return nullptr;
-            pointers.push_back(p);
-            return p;
-        }
-    } buffers;
-    auto* d_ids = static_cast<std::uint32_t*>(buffers.take(queries * 4));
-    auto* d_keys = static_cast<std::uint64_t*>(buffers.take(queries * wanted * 8));
-    auto* d_distances = static_cast<float*>(buffers.take(queries * wanted * 4));
-    auto* d_counts = static_cast<std::uint64_t*>(buffers.take(queries * 8 * 3));
-    if (!d_ids || !d_keys || !d_distances || !d_counts)
-        return (void)hipGetLastError(), nullptr;
-    std::vector<std::uint32_t> ids(queries);
-    std::uint64_t state = 0x9E3779B97F4A7C15ull;
-    for (std::uint32_t& id : ids) {
-        state = state * 6364136223846793005ull + 1442695040888963407ull;
-        id = (std::uint32_t)(((state >> 33) * view_.size) >> 31);
-        id = id < view_.size ? id : (std::uint32_t)(view_.size - 1);
+/// One trial (placement.hpp). `launch(view, ms)` runs the launch's first queries over `view` once and reports the milliseconds.
+const char* snapshot_t::try_matrix_placement(const std::function<const char*(const snapshot_view_t&, float&)>& launch, hipStream_t stream) {
+    {   // the matrix must be this launch's alone: no other batch in flight, none admitted until the trial is over
+        std::lock_guard<std::mutex> lock(pool_mutex_);
+        if (placing_ || workspaces_.size() - idle_.size() != 1)
+            return nullptr;
+        placing_ = true;
     }
-    if (hipMemcpy(d_ids, ids.data(), queries * 4, hipMemcpyHostToDevice) != hipSuccess)
-        return (void)hipGetLastError(), nullptr;
-    search_extras_t extras;
-    extras.query_ids = d_ids;
-    auto judge = [&](float& ms) -> bool {
-        for (int repeat = 0; repeat < 2; ++repeat) { // the first run also draws the scratch block and warms the code
-            search_stats_t stats;
-            if (search_device(view_.vectors, queries, view_.row_stride, wanted, expansion, d_keys, d_distances, d_counts,
-                              d_counts + queries, d_counts + 2 * queries, nullptr, search_tuning_t{}, &stats, true, &extras))
-                return false;
-            ms = stats.kernel_ms;
+    struct release_t {
+        snapshot_t& owner;
+        ~release_t() {
+            {
+                std::lock_guard<std::mutex> lock(owner.pool_mutex_);
+                owner.placing_ = false;
+            }
+            owner.pool_ready_.notify_all();
         }
-        return true;
-    };
-    placement_ = placement_t{};
-    float best_ms = 0.f;
-    if (!judge(best_ms))
-        return nullptr; // cannot judge: the matrix stays where it is
-    placement_.judge_ms[0] = best_ms;
-    placement_.draws = 1, placement_.kept = 0;
-    std::vector<void*> losers; // held until the end, so that every further draw has to land somewhere else
-    for (std::size_t d = 1; d < draws; ++d) {
-        std::size_t free_bytes = 0, total_bytes = 0;
-        if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess || free_bytes < vectors_bytes_ + ((std::size_t)4 << 30))
-            break;
-        void* candidate = nullptr;
-        if (placed_malloc(&candidate, vectors_bytes_, view_.row_stride, nullptr) != hipSuccess) {
-            (void)hipGetLastError();
-            break;
-        }
-        if (hipMemcpy(candidate, d_vectors_, vectors_bytes_, hipMemcpyDeviceToDevice) != hipSuccess) {
-            (void)hipGetLastError();
-            placed_free(candidate);
-            break;
-        }
+    } release{*this};
+    const auto started = std::chrono::steady_clock::now();
+    std::size_t free_bytes = 0, total_bytes = 0;
+    if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess || free_bytes < vectors_bytes_ + ((std::size_t)4 << 30)) {
+        (void)hipGetLastError();
+        placement_trials_left_ = 0; // no room for a second copy of the matrix: it stays where it is
+        return nullptr;
+    }
+    void* candidate = nullptr;
+    if (placed_malloc(&candidate, vectors_bytes_, view_.row_stride, nullptr) != hipSuccess) {
+        (void)hipGetLastError();
+        placement_trials_left_ = 0;
+        return nullptr;
+    }
+    if (hipMemcpyAsync(candidate, d_vectors_, vectors_bytes_, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) {
+        (void)hipGetLastError();
+        placed_free(candidate);
+        placement_trials_left_ = 0;
+        return nullptr;
+    }
+    snapshot_view_t other = view_;
+    other.vectors = static_cast<const std::uint8_t*>(candidate);
+    // incumbent, candidate, incumbent, candidate: the first run of each also pays first touches and the clocks' ramp, the later
+    // ones count (the smaller of two each)
+    // (short launches — a small expansion — are judged over more rounds: their differences are tenths of a millisecond)
+    float incumbent_ms = 0.f, candidate_ms = 0.f;
+    const char* failure = nullptr;
+    for (int round = 0; round < 6 && !failure && !(round >= 3 && incumbent_ms >= 3.f); ++round) {
+        float ms = 0.f;
+        failure = launch(view_, ms);
+        if (!failure && round)
+            incumbent_ms = incumbent_ms == 0.f ? ms : std::min(incumbent_ms, ms);
+        if (!failure)
+            failure = launch(other, ms);
+        if (!failure && round)
+            candidate_ms = candidate_ms == 0.f ? ms : std::min(candidate_ms, ms);
+    }
+    if (failure) {
+        placed_free(candidate);
+        return failure;
+    }
+    const std::uint32_t trial = placement_.draws;
+    if (trial < (std::uint32_t)placement_max_draws_k)
+        placement_.judge_ms[trial] = candidate_ms, placement_.incumbent_ms[trial] = incumbent_ms;
+    ++placement_.draws;
+    --placement_trials_left_;
+    // a candidate has to win by more than the judge's noise (two hundredths); three trials in a row that the incumbent wins end the
+    // search — it sits on frames as good as this device hands out
+    const bool swap = candidate_ms < incumbent_ms * 0.98f;
+    if (swap) {
         void* previous = d_vectors_;
         d_vectors_ = candidate;
-        view_.vectors = static_cast<const std::uint8_t*>(candidate);
-        float ms = 0.f;
-        const bool judged = judge(ms);
-        placement_.judge_ms[d] = ms;
-        placement_.draws = (std::uint32_t)d + 1;
-        if (judged && ms < best_ms) {
-            best_ms = ms;
-            placement_.kept = (std::uint32_t)d;
-            losers.push_back(previous);
-        } else {
-            d_vectors_ = previous;
-            view_.vectors = static_cast<const std::uint8_t*>(previous);
-            losers.push_back(candidate);
-        }
-        if (!judged)
-            break;
+        view_.vectors = other.vectors;
+        placed_free(previous);
+        ++placement_.kept;
+        placement_losses_ = 0;
+    } else {
+        placed_free(candidate);
+        if (++placement_losses_ >= 3)
+            placement_trials_left_ = 0;
     }
-    for (void* p : losers)
-        placed_free(p);
-    tuned_vectors_ = d_vectors_;
-    placement_.probe_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - started).count();
-    if (env_size("USEARCH_AMD_PLACEMENT_LOG", 0)) {
-        std::fprintf(stderr, "[usearch_amd] matrix placement of %.2f GB, judged by a self-search of %zu stored rows: ", vectors_bytes_ / 1e9, queries);
-        for (std::uint32_t i = 0; i < placement_.draws; ++i)
-            std::fprintf(stderr, "%s%.3f%s", i ? " " : "", placement_.judge_ms[i], i == placement_.kept ? "*" : "");
-        std::fprintf(stderr, " ms, %.0f ms in all\n", placement_.probe_ms);
-    }
+    placement_.probe_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - started).count();
+    if (env_size("USEARCH_AMD_PLACEMENT_LOG", 0))
+        std::fprintf(stderr, "[usearch_amd] matrix placement trial %u (%.2f GB): incumbent %.3f ms, fresh copy %.3f ms over the launch's first queries: %s; %u trials left\n",
+                     trial, vectors_bytes_ / 1e9, incumbent_ms, candidate_ms, swap ? "moved" : "stays", placement_trials_left_);
     return nullptr;
 }
 
@@ -375,7 +361,7 @@ const char* snapshot_t::finalize_layout() {
         view_.nbr0_rows = nullptr;
     }
     if (lanes_ != 1 || view_.chunks != 1 || view_.m0 > 64 || !view_.size || !env_size("USEARCH_AMD_INLINE_ROWS", 1))
-        return tune_placement();
+        return nullptr;
     UA_HIP(hipSetDevice(device_));
     const std::uint64_t cells = view_.size * view_.m0;
     UA_HIP(placed_malloc(&d_nbr0_rows_, cells * 16, (std::size_t)view_.m0 * 16, nullptr)); // what a hop gathers: one block
@@ -386,7 +372,7 @@ const char* snapshot_t::finalize_layout() {
     UA_HIP(hipGetLastError());
     UA_HIP(hipStreamSynchronize(stream_));
     view_.nbr0_rows = static_cast<const std::uint8_t*>(d_nbr0_rows_);
-    return tune_placement();
+    return nullptr;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1053,13 +1039,12 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
                     kept = i;
             for (std::size_t i = 0; i < drawn; ++i)
                 if (i != kept || failure || !drawn)
-                    (void)hipFree(candidates[i]);
+                    placed_free(candidates[i]);
             if (failure)
                 return failure;
             if (!drawn)
                 return hip_message(hipErrorOutOfMemory);
-            if (ws.d_scratch)
-                (void)hipFree(ws.d_scratch);
+            placed_free(ws.d_scratch);
             ws.d_scratch = static_cast<std::uint8_t*>(candidates[kept]);
             ws.scratch_bytes = slab * grid;
             args.scratch = ws.d_scratch;
@@ -1070,6 +1055,46 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
                     std::fprintf(stderr, "%s%.3f%s@%p", i ? " " : "", trial_ms[i], i == kept ? "*" : "", candidates[i]);
                 std::fprintf(stderr, " ms\n");
             }
+        }
+        // ---- the matrix of stored rows: up to `placement_max_draws_k` trials over the first launches that fill the chip, judged like
+        //      the scratch block — by this launch's own first queries at the caller's expansion (placement.hpp)
+        const std::uint32_t matrix_draws = (std::uint32_t)std::min<std::size_t>(placement_max_draws_k, env_size("USEARCH_AMD_PLACEMENT_DRAWS", placement_max_draws_k));
+        if (placement_trials_left_ && matrix_draws > 1 && placement_.draws < matrix_draws && call.passes == 0 && !call.have_todo &&
+            !params.team && pending >= 2ull * grid && grid >= 2u * (std::uint32_t)compute_units_ && !view_.nbr0_rows && d_vectors_ &&
+            vectors_bytes_ >= env_size("USEARCH_AMD_PLACEMENT_MIN_BYTES", (std::size_t)1 << 30) && !args.query_ids && !args.allow_bits &&
+            !args.descent_only && !args.beam_level && !env_size("USEARCH_AMD_SCRATCH_REDRAW", 0)) {
+            params.mode = call.mode;
+            params.entries_per_lane = call.entries_per_lane;
+            params.grid = grid;
+            params.lds_bytes = (std::uint32_t)lds_bytes;
+            hipEvent_t begin = nullptr, end = nullptr;
+            UA_HIP(hipEventCreate(&begin));
+            if (hipError_t created = hipEventCreate(&end); created != hipSuccess) {
+                (void)hipEventDestroy(begin);
+                return hip_message(created);
+            }
+            args.count = grid; // one query per wave: the launch's steady state; their results are computed again by the launch proper
+            const char* failure = try_matrix_placement(
+                [&](const snapshot_view_t& view, float& ms) -> const char* {
+                    hipError_t e = hipMemsetAsync(ws.d_queue, 0, 8, stream);
+                    if (e == hipSuccess)
+                        e = hipEventRecord(begin, stream);
+                    if (e == hipSuccess)
+                        e = launch_search(metric_, scalar_, params, view, args);
+                    if (e == hipSuccess)
+                        e = hipEventRecord(end, stream);
+                    if (e == hipSuccess)
+                        e = hipEventSynchronize(end);
+                    if (e == hipSuccess)
+                        e = hipEventElapsedTime(&ms, begin, end);
+                    return e == hipSuccess ? nullptr : hip_message(e);
+                },
+                stream);
+            args.count = pending;
+            (void)hipEventDestroy(begin);
+            (void)hipEventDestroy(end);
+            if (failure)
+                return failure;
         }
         if (call.want_clock && call.passes == 0) {
             if (const char* e = ws.reserve_wave_clock(grid))

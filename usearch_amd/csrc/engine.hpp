@@ -11,6 +11,7 @@
 
 #include <condition_variable>
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -196,10 +197,6 @@ class snapshot_t {
     /// (`snapshot_view_t::nbr0_rows`) when rows are a single 16-byte chunk — b1 × 128, haversine … — so that a hop reads one
     /// contiguous block. Costs size × M0 × 16 bytes of HBM; USEARCH_AMD_INLINE_ROWS=0 turns it off.
     const char* finalize_layout();
-    /// Once the index is resident: draws a few placements of the matrix of stored rows (each a device-to-device copy), lets a short
-    /// self-search of stored rows time the walk on each, keeps the fastest (placement.hpp). USEARCH_AMD_PLACEMENT_DRAWS (default 8;
-    /// 1 = off); matrices under 1 GiB and indexes under 65 536 members are left where they are. Called by `finalize_layout`.
-    const char* tune_placement();
     void suspend_layout() { view_.nbr0_rows = nullptr; } ///< while the lists are being rewritten (construction)
     std::uint32_t* mutable_nbr0() { return static_cast<std::uint32_t*>(d_nbr0_); }
     std::uint32_t* mutable_upper() { return static_cast<std::uint32_t*>(d_upper_); }
@@ -258,6 +255,10 @@ class snapshot_t {
 
   private:
     const char* run_ladder(search_call_t& call);
+    /// One placement trial of the matrix of stored rows inside a launch that fills the chip (placement.hpp): a fresh device-to-device
+    /// copy, incumbent and candidate timed alternately over the launch's first `grid` queries (`launch(view, ms)` runs them once and
+    /// times them), the faster one stays. Needs the matrix to itself (no other batch in flight); does nothing otherwise.
+    const char* try_matrix_placement(const std::function<const char*(const snapshot_view_t&, float&)>& launch, hipStream_t stream);
     void release();
 
     snapshot_view_t view_{};
@@ -277,7 +278,9 @@ class snapshot_t {
     std::uint64_t build_capacity_ = 0, build_lists_capacity_ = 0; ///< room in the arrays above while an index is under construction
 
     placement_t placement_{};
-    void* tuned_vectors_ = nullptr;   ///< the matrix `tune_placement` has already judged
+    std::uint32_t placement_trials_left_ = placement_max_draws_k; ///< trials `try_matrix_placement` may still make
+    std::uint32_t placement_losses_ = 0;                          ///< trials in a row the incumbent has won
+    bool placing_ = false;            ///< a trial owns the matrix: `take` waits (guarded by pool_mutex_)
     std::size_t vectors_bytes_ = 0;   ///< bytes allocated behind d_vectors_
     int compute_units_ = 256;
     float last_distances_ms_ = 0.f;

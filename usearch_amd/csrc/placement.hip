@@ -104,7 +104,10 @@ hipError_t mapped_malloc(void** out, std::size_t bytes, std::size_t chunk) {
     chunk = (std::max(chunk, granularity) + granularity - 1) / granularity * granularity;
     const std::size_t padded = (bytes + chunk - 1) / chunk * chunk;
     void* base = nullptr;
-    if (hipError_t e = hipMemAddressReserve(&base, padded, std::min<std::size_t>(chunk, (std::size_t)1 << 30), nullptr, 0); e != hipSuccess)
+    std::size_t alignment = granularity; // the largest power of two within the chunk, at most 1 GB
+    while (alignment * 2 <= std::min<std::size_t>(chunk, (std::size_t)1 << 30))
+        alignment *= 2;
+    if (hipError_t e = hipMemAddressReserve(&base, padded, alignment, nullptr, 0); e != hipSuccess)
         return e;
     mapped_t record{base, padded, {}};
     hipError_t result = hipSuccess;
@@ -153,6 +156,13 @@ hipError_t draw(void** out, std::size_t bytes) {
 } // namespace
 
 hipError_t block_malloc(void** out, std::size_t bytes) {
+    // experiment switch: ONE physical allocation mapped at a virtual range aligned to its own size (at most 1 GB), so that the page
+    // tables may describe it with fragments as large as the physical frames allow whatever address the runtime's allocator hands out
+    if (env_size("USEARCH_AMD_ALIGNED_MAP", 0) && bytes >= ((std::size_t)2 << 20)) {
+        if (mapped_malloc(out, bytes, bytes) == hipSuccess)
+            return hipSuccess;
+        (void)hipGetLastError();
+    }
     if (env_size("USEARCH_AMD_CONTIGUOUS", 0) && bytes >= ((std::size_t)2 << 20)) {
         if (hipExtMallocWithFlags(out, bytes, hipDeviceMallocContiguous) == hipSuccess) {
             if (env_size("USEARCH_AMD_PLACEMENT_LOG", 0))
@@ -163,7 +173,11 @@ hipError_t block_malloc(void** out, std::size_t bytes) {
         if (env_size("USEARCH_AMD_PLACEMENT_LOG", 0))
             std::fprintf(stderr, "[usearch_amd] no contiguous range of %.0f MB: plain allocation\n", bytes / 1e6);
     }
-    return hipMalloc(out, bytes);
+    const hipError_t result = hipMalloc(out, bytes);
+    if (result == hipSuccess && bytes >= ((std::size_t)64 << 20) && env_size("USEARCH_AMD_PLACEMENT_LOG", 0))
+        std::fprintf(stderr, "[usearch_amd] %.0f MB @%p (virtual range aligned to %zu MB)\n", bytes / 1e6, *out,
+                     (std::size_t)((reinterpret_cast<std::uintptr_t>(*out) & (~reinterpret_cast<std::uintptr_t>(*out) + 1)) >> 20));
+    return result;
 }
 
 const char* remap_trial(std::size_t bytes, std::size_t views, const std::function<const char*(void*, float&)>& judge,

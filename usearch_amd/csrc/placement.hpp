@@ -1,24 +1,29 @@
 /**
  *  usearch_amd/csrc/placement.hpp — where arrays land in HBM decides how fast the walk runs over them.
  *
- *  The headline batch (10M x 768 f16, 10 000 queries, ef 608) takes 45.4, ≈ 47.5, ≈ 49.5 or 51.8 ms on the same bytes, stable for
- *  the life of the allocations (profiles/r02_placement.log). Round 3 took the effect apart (profiles/r03_placement/README.md):
+ *  The headline batch (10M x 768 f16, 10 000 queries, ef 608) takes 44.8, ≈ 47, ≈ 49.5 or ≈ 51.5 ms on the same bytes, stable for
+ *  the life of the allocations. What three rounds of measurements say (profiles/r03_placement/, r04_placement/, r05_placement/):
  *
- *    * TWO allocations decide, independently, about 6 % each: the block of per-wave visited-set slabs of the workspace (268 MB;
- *      with the index untouched, re-allocating it alone flips the batch between 45.5 and 51.6 ms) and the matrix of stored rows.
- *      Fast + fast = 45.4 ms, one slow = 47.5 … 49.5, both slow = 51.8: the four levels.
- *    * No synthetic probe tells a slow placement from a fast one — not a dependency-free gather of rows (± 3 %, uncorrelated), not
- *      random page touches, not chains of dependent reads, not the slabs' own pattern of scattered compare-and-swaps (2.43 … 2.45
- *      µs per round everywhere). The counters see the same UTCL1 misses but translation requests that stay in flight 36 % longer
- *      (TCP_CLIENT_UTCL1_INFLIGHT ÷ TCP_UTCL1_TRANSLATION_MISS) — only the walk itself, gathers and atomics interleaved, feels it.
- *    * How an array is allocated (`hipMalloc`, `hipMemCreate` in chunks of 2 MB … the whole array) does not decide its speed.
+ *    * TWO allocations decide, independently: the block of per-wave visited-set slabs of the workspace and the matrix of stored
+ *      rows. The state belongs to the PHYSICAL frames a block received: the virtual address, its alignment (2 MB … 1 GB, by
+ *      `HSA_MAX_VA_ALIGN` or a range reserved by hand) and the allocation flavour (`hipMalloc`, `hipMemCreate`, contiguous) do not
+ *      decide it; no synthetic probe (gathers, page touches, dependent chains, scattered atomics) sees it; the counters see the
+ *      same UTCL1 misses but translations that stay in flight 36 % longer.
+ *    * Round 5 found the lever (profiles/r05_placement/README.md): an index restored over and over at the SAME virtual addresses
+ *      alternates strictly fast / slow / fast / slow — the driver releases freed frames late (wipe on release: between 0.3 and 1 s
+ *      for 17 GB although `hipMemGetInfo` reports them free at once), so every second copy lands on other frames; with one second
+ *      of idle time between free and allocation EVERY copy gets the driver's preferred frames and runs at the best level. Copies
+ *      allocated while earlier ones are held land anywhere (44.9 / 51.1 / 51.1 / 47.0 ms in one process).
  *
- *  So the engine draws placements and lets THE WALK judge them: the scratch block is drawn when a chip-filling launch needs a new
- *  one, each candidate timed by that very launch over its first queries (engine.hip `run_ladder`); the matrix is drawn once the
- *  index is resident, each candidate — a device-to-device copy — timed by a short self-search of stored rows
- *  (`snapshot_t::tune_placement`). Every path that creates a snapshot (loader, builder, drop-in, sharded step) gets both.
- *  This file keeps the allocation flavours and the probes used to rule the suspects out (diagnostics:
- *  scripts/placement_study.py).
+ *  So the engine lets THE WALK judge placements, with the caller's own queries at the caller's expansion, when a launch that fills
+ *  the chip comes along (engine.hip `run_ladder`): the scratch block when a new one is needed (≤ 8 candidates side by side, each
+ *  timed by the launch's first queries), the matrix in up to `placement_max_draws_k` trials over the first such launches (one fresh
+ *  device-to-device copy per launch, incumbent and candidate timed alternately on the launch's first queries, the loser freed —
+ *  late-released frames are why consecutive trials see different frames; `snapshot_t::try_matrix_placement`). Round 3/4's judge at
+ *  load time — a self-search of stored rows at expansion 128 — did not predict the batch that followed (the driver's run of round
+ *  4 kept the incumbent at 5.05 ms against 6.2 … 7.1 and then ran the batch at the slowest level) and is gone.
+ *  This file keeps the allocation flavours and the probes used to rule the suspects out (diagnostics: scripts/placement_study.py,
+ *  scripts/fragment_study.py).
  */
 #pragma once
 #include <hip/hip_runtime.h>
@@ -33,10 +38,11 @@ namespace usearch_amd {
 constexpr int placement_max_draws_k = 8;
 
 struct placement_t {
-    std::uint32_t draws = 0;                        ///< placements of the matrix tried (0 = too small to bother, or not tuned)
-    std::uint32_t kept = 0;                         ///< which one was kept
-    float judge_ms[placement_max_draws_k] = {0};    ///< milliseconds the judging self-search took on each draw (lower is better)
-    float probe_ms = 0.f;                           ///< wall time the draws cost, allocation and copies included
+    std::uint32_t draws = 0;                         ///< trials made so far: fresh copies of the matrix judged against the incumbent
+    std::uint32_t kept = 0;                          ///< how many of them replaced the incumbent
+    float judge_ms[placement_max_draws_k] = {0};     ///< trial i: the candidate's milliseconds over the launch's first queries
+    float incumbent_ms[placement_max_draws_k] = {0}; ///< trial i: the incumbent's milliseconds over the same queries
+    float probe_ms = 0.f;                            ///< wall time the trials have cost, allocation and copies included
 };
 
 /**

@@ -80,7 +80,7 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_snapshot_from_parts",
     "usearch_amd_snapshot_free", "usearch_amd_snapshot_size", "usearch_amd_snapshot_dimensions",
     "usearch_amd_snapshot_connectivity", "usearch_amd_snapshot_max_level", "usearch_amd_snapshot_bytes_per_vector",
-    "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_placement", "usearch_amd_snapshot_gather_probe", "usearch_amd_snapshot_translation_probe", "usearch_amd_snapshot_latency_probe",
+    "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_placement", "usearch_amd_snapshot_placement_incumbents", "usearch_amd_snapshot_gather_probe", "usearch_amd_snapshot_translation_probe", "usearch_amd_snapshot_latency_probe",
     "usearch_amd_snapshot_scalar_kind",
     "usearch_amd_snapshot_metric_kind", "usearch_amd_snapshot_lanes_per_row", "usearch_amd_snapshot_inline_rows",
     "usearch_amd_search_many",
@@ -150,6 +150,8 @@ def library() -> C.CDLL:
         f = getattr(L, f"usearch_amd_snapshot_{name}")
         f.restype = C.c_size_t
         f.argtypes = [C.c_void_p]
+    L.usearch_amd_snapshot_placement_incumbents.restype = None
+    L.usearch_amd_snapshot_placement_incumbents.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.usearch_amd_snapshot_placement.restype = None
     L.usearch_amd_snapshot_placement.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                                  C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -407,13 +409,17 @@ class Index:
 
     @property
     def placement(self) -> dict:
-        """How the engine placed the matrix of stored rows in HBM (csrc/placement.hpp): the gather rate of every draw and which
-        one was kept; `draws == 0` for arrays too small to bother."""
+        """How the engine placed the matrix of stored rows in HBM (csrc/placement.hpp): the trials made so far — each a fresh copy
+        judged against the incumbent on a chip-filling launch's own first queries — how many of them moved the matrix, and both
+        times of every trial; `draws == 0` before the first such launch and for arrays too small to bother."""
         draws, kept, probe_ms = C.c_uint32(), C.c_uint32(), C.c_float()
-        rates = (C.c_float * 8)()
+        rates, incumbents = (C.c_float * 8)(), (C.c_float * 8)()
         library().usearch_amd_snapshot_placement(self._handle, C.byref(draws), C.byref(kept), rates, C.byref(probe_ms))
+        library().usearch_amd_snapshot_placement_incumbents(self._handle, incumbents)
+        shown = min(int(draws.value), 8)
         return {"draws": int(draws.value), "kept": int(kept.value), "probe_ms": round(float(probe_ms.value), 2),
-                "judge_ms": [round(float(rates[i]), 3) for i in range(draws.value)]}
+                "judge_ms": [round(float(rates[i]), 3) for i in range(shown)],
+                "incumbent_ms": [round(float(incumbents[i]), 3) for i in range(shown)]}
 
     def latency_probe(self, lists: bool = False) -> float:
         """Nanoseconds per DEPENDENT read of a random stored row (or, `lists`, of a random level-0 neighbour list)."""
