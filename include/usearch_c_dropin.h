@@ -192,6 +192,14 @@ USEARCH_EXPORT void usearch_search_exact_many(usearch_index_t index, void const*
  *  filter instead: a bitmap built once (by a kernel over the keys in HBM for ranges and key sets) that any number of batches
  *  reuse. A filter describes the index as it was when the filter was made: after `usearch_add / remove / rename / load / view /
  *  clear / usearch_gpu_release` searches under it fail with "The index changed since the filter was made".
+ *
+ *  What the callback must be, either way: a PURE function of the key for the duration of the call (it is asked about members in
+ *  slot order, before the walk starts, including members the reference's walk would never have shown it; it must not call back
+ *  into the index). For binaries that cannot be changed, `USEARCH_AMD_FILTER_MEMO=1` in the environment (read at `usearch_init`)
+ *  keeps the bitmap of the last eight (callback, filter_state pointer) pairs per index version: a repeated
+ *  `usearch_filtered_search` under the same pair then makes no callback at all. That asks for MORE than purity per call — the
+ *  predicate must not change while its state pointer stays the same (a threshold edited in place behind the same pointer would
+ *  not be seen) — hence opt-in. Every mutation of the index forgets the remembered bitmaps.
  * ---------------------------------------------------------------------------------------------------------------------------- */
 typedef void* usearch_filter_t;
 

@@ -58,6 +58,42 @@ int main() {
     combiner.submit(failing, [](std::vector<combined_call_t*>&) { throw 1; });
     const bool reported = failing.done && failing.error && !failing.found;
 
+    // one caller's trouble stays that caller's: a shared launch that reports an error goes out again call by call, and only the
+    // call that is at fault comes back with it
+    combiner_t shared;
+    std::atomic<int> innocent_failures{0}, guilty_failures{0};
+    {
+        std::vector<std::thread> callers;
+        for (int t = 0; t < 12; ++t)
+            callers.emplace_back([&, t] {
+                for (int i = 0; i < 10; ++i) {
+                    float query[4] = {(float)t, 0.f, 0.f, 0.f};
+                    std::uint64_t keys[4];
+                    float distances[4];
+                    combined_call_t call;
+                    call.query = query, call.query_bytes = sizeof(query), call.kind = 1, call.wanted = 4, call.keys = keys,
+                    call.distances = distances;
+                    shared.submit(call, [](std::vector<combined_call_t*>& batch) {
+                        bool poisoned = false;
+                        for (combined_call_t* other : batch)
+                            poisoned = poisoned || static_cast<const float*>(other->query)[0] == 5.f; // caller 5 breaks a launch
+                        for (combined_call_t* other : batch)
+                            other->found = poisoned ? 0 : other->wanted, other->error = poisoned ? "This launch failed" : nullptr;
+                        std::this_thread::sleep_for(std::chrono::microseconds(500));
+                    });
+                    if (t == 5)
+                        guilty_failures += call.error != nullptr;
+                    else
+                        innocent_failures += call.error != nullptr || call.found != call.wanted;
+                }
+            });
+        for (std::thread& thread : callers)
+            thread.join();
+    }
+    std::printf("a caller whose calls fail among eleven whose calls do not: %d of its 10 calls failed, %d of the others', %llu shared "
+                "launches repeated call by call\n", guilty_failures.load(), innocent_failures.load(), (unsigned long long)shared.relaunched());
+    const bool contained = guilty_failures.load() == 10 && innocent_failures.load() == 0;
+
     // looping callers: launches needed for the same calls with and without the launcher's wait for the callers just served
     std::uint64_t launches_for[2] = {0, 0}, expired_alone = 0;
     for (int with_window = 0; with_window < 2; ++with_window)
@@ -92,6 +128,6 @@ int main() {
     std::printf("sixteen looping callers, thirty calls each: %llu launches without the wait, %llu with it; a lone caller waited %llu times\n",
                 (unsigned long long)launches_for[0], (unsigned long long)launches_for[1], (unsigned long long)expired_alone);
     const bool gathered = launches_for[1] * 100 < launches_for[0] * 85 && !expired_alone;
-    std::printf("%s\n", ok && reported && gathered ? "PASSED" : "FAILED");
-    return ok && reported && gathered ? 0 : 1;
+    std::printf("%s\n", ok && reported && gathered && contained ? "PASSED" : "FAILED");
+    return ok && reported && gathered && contained ? 0 : 1;
 }

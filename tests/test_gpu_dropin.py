@@ -389,6 +389,42 @@ def test_removed_slots_are_recycled(lib, reference):
     lib.usearch_free(index, C.byref(err))
 
 
+def test_a_loaded_index_at_capacity_takes_additions_into_its_tombstones(lib):
+    """After a load the reference lists the image's freed slots (`reindex_keys_`, index_dense.hpp:2162-2200), so an `add` into a
+    full index with tombstones needs no `reserve` (the capacity test used to run before the slots were listed)."""
+    err = C.c_char_p()
+    n, dims, k = 400, 16, 5
+    data = util.make_vectors(n + 3, dims, "f32", seed=17)
+    index, _ = filled_index(lib, n, dims, options=Options(METRIC["cos"], None, SCALAR["f32"], dims, 16, 128, 64, False), data=data[:n])
+    for key in (7, 8, 9):
+        assert lib.usearch_remove(index, key, C.byref(err)) == 1
+        ok(err)
+    length = lib.usearch_serialized_length(index, C.byref(err))
+    buffer = np.zeros(length, dtype=np.uint8)
+    lib.usearch_save_buffer(index, ptr(buffer), length, C.byref(err))
+    ok(err)
+    loaded = lib.usearch_init(None, C.byref(err))
+    lib.usearch_load_buffer(loaded, ptr(buffer), length, C.byref(err))
+    ok(err)
+    assert lib.usearch_size(loaded, C.byref(err)) == n - 3
+    assert lib.usearch_capacity(loaded, C.byref(err)) == n, "the test wants an index with no spare capacity"
+    keys = np.zeros(k, dtype=np.uint64)
+    distances = np.zeros(k, dtype=np.float32)
+    for i in range(3):  # exactly as many as there are tombstones …
+        lib.usearch_add(loaded, n + i, ptr(data[n + i]), SCALAR["f32"], C.byref(err))
+        ok(err)
+    assert lib.usearch_size(loaded, C.byref(err)) == n
+    lib.usearch_add(loaded, n + 3, ptr(data[0]), SCALAR["f32"], C.byref(err))
+    assert err.value and b"Reserve capacity" in err.value  # … and not one more
+    err = C.c_char_p()
+    for i in range(3):
+        assert lib.usearch_search(loaded, ptr(data[n + i]), SCALAR["f32"], k, ptr(keys), ptr(distances), C.byref(err)) == k
+        ok(err)
+        assert keys[0] == n + i and not (set(keys.tolist()) & {7, 8, 9})
+    lib.usearch_free(index, C.byref(err))
+    lib.usearch_free(loaded, C.byref(err))
+
+
 def test_filtered_search_and_rename(lib):
     """cpp/test.cpp:1105-1145: predicate key != 0 → 10 results none 0; `false` → 0; key == 10 → exactly [10]."""
     err = C.c_char_p()
@@ -416,6 +452,59 @@ def test_filtered_search_and_rename(lib):
     found = lib.usearch_search(index, ptr(data[10]), SCALAR["f32"], 1, ptr(keys), ptr(distances), C.byref(err))
     assert found == 1 and keys[0] == 777777
     lib.usearch_free(index, C.byref(err))
+
+
+def test_filtered_search_remembers_a_pure_predicate_when_told_to(lib, monkeypatch):
+    """`usearch_filtered_search` has to run the caller's callback over every member per call (the reference runs it on the few
+    thousand members a walk meets: c/lib.cpp:413-429). With USEARCH_AMD_FILTER_MEMO=1 — read at `usearch_init`, for callers whose
+    predicate is a pure function of the key while its state pointer stays the same — the bitmap is kept per (callback, state,
+    index version): the second call makes no callback at all, answers the same, and any mutation of the index forgets it."""
+    err = C.c_char_p()
+    n, dims, k = 3000, 32, 10
+    data = util.make_vectors(n, dims, "f32", seed=23)
+    options = Options(METRIC["cos"], None, SCALAR["f32"], dims, 16, 128, 64, False)
+    calls = [0]
+
+    def even(key, state):
+        calls[0] += 1
+        return int(key % 2 == 0)
+
+    def third(key, state):
+        calls[0] += 1
+        return int(key % 3 == 0)
+
+    even_c, third_c = FILTER(even), FILTER(third)
+    keys, distances = np.zeros(k, dtype=np.uint64), np.zeros(k, dtype=np.float32)
+    answers = {}
+    for memo in ("0", "1"):
+        monkeypatch.setenv("USEARCH_AMD_FILTER_MEMO", memo)
+        index, _ = filled_index(lib, n, dims, options=options, data=data)
+        per_call = []
+        for callback in (even_c, even_c, third_c, even_c):
+            calls[0] = 0
+            found = lib.usearch_filtered_search(index, ptr(data[1]), SCALAR["f32"], k, callback, None, ptr(keys), ptr(distances),
+                                                C.byref(err))
+            ok(err)
+            assert found == k
+            per_call.append((calls[0], keys.copy(), distances.copy()))
+        answers[memo] = per_call
+        if memo == "1":
+            assert [c for c, _, _ in per_call] == [n, 0, n, 0], "a remembered predicate is not evaluated again"
+            # a mutation forgets: the new member must be asked about
+            lib.usearch_reserve(index, n + 1, C.byref(err))
+            lib.usearch_add(index, n, ptr(data[1]), SCALAR["f32"], C.byref(err))  # key 3000: even, a twin of the query
+            ok(err)
+            calls[0] = 0
+            found = lib.usearch_filtered_search(index, ptr(data[1]), SCALAR["f32"], k, even_c, None, ptr(keys), ptr(distances),
+                                                C.byref(err))
+            ok(err)
+            assert calls[0] == n + 1 and found == k and n in keys.tolist()
+        else:
+            assert [c for c, _, _ in per_call] == [n, n, n, n]
+        lib.usearch_free(index, C.byref(err))
+    for (_, keys_off, distances_off), (_, keys_on, distances_on) in zip(answers["0"], answers["1"]):
+        assert np.array_equal(keys_off, keys_on) and np.array_equal(distances_off, distances_on)
+    assert all(key % 2 == 0 for key in answers["1"][1][1]) and all(key % 3 == 0 for key in answers["1"][2][1])
 
 
 def test_batch_and_buffers_match_the_reference(lib, reference):

@@ -318,6 +318,29 @@ def test_team_settles_ties_like_one_wave(reference, monkeypatch, metric, dtype, 
         assert np.array_equal(team.computed_per_query, plain.computed_per_query)
 
 
+def test_team_and_one_wave_agree_when_every_distance_is_a_nan(reference, monkeypatch):
+    """A query with a NaN component measures NaN against every member: no newcomer equals the smallest landing distance (the
+    minimum of NaNs is +inf), so the pipelined team has nobody to name early — it must commit first and look again, as for a tie
+    (it used to read a lane that does not exist). Same keys, bits and counters as the one-wave kernel."""
+    from usearch_amd import Index
+    ndim, dtype, metric, expansion = 768, "f32", "cos", 400
+    vectors = util.make_vectors(3000, ndim, dtype, seed=71, metric=metric)
+    image, _, _ = util.build_image(3000, ndim, metric, dtype, vectors=vectors)
+    index = Index.restore(image)
+    queries = util.make_vectors(6, ndim, dtype, seed=72, metric=metric).copy()
+    queries[0, :] = np.nan
+    queries[3, 5] = np.nan
+    monkeypatch.delenv("USEARCH_AMD_NO_TEAM", raising=False)
+    team = index.search(queries, 10, expansion=expansion, dtype=dtype)
+    monkeypatch.setenv("USEARCH_AMD_NO_TEAM", "1")
+    plain = index.search(queries, 10, expansion=expansion, dtype=dtype)
+    assert team.stats.variant == 5 and plain.stats.variant != 5
+    assert np.array_equal(team.keys, plain.keys) and np.array_equal(team.counts, plain.counts)
+    assert np.array_equal(team.distances.view(np.uint32), plain.distances.view(np.uint32))
+    assert np.array_equal(team.visited_per_query, plain.visited_per_query)
+    assert np.array_equal(team.computed_per_query, plain.computed_per_query)
+
+
 def test_the_benchmarked_instantiation_matches_the_oracle(reference):
     """The kernel every BASELINE line of `bench.py` times, held against the oracle ITSELF (not piece by piece): rows of 768 f16
     (8 lanes per row, 12 chunks per lane), expansion 608 (16 `top` cells per lane, frontier in `top`), a batch that fills the chip

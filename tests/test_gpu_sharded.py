@@ -18,18 +18,23 @@ WORLD = 2
 CASES = [("hamming", "b1", 128, 30000, 400, 10, 64), ("cos", "f16", 96, 20000, 300, 10, 96)]
 
 
-def worker(rank: int, port: int, results):
+def worker(rank: int, port: int, results, world: int = WORLD, transport: str = "host"):
+    """`transport` "host": every rank on cuda:0, the collectives gloo's over host memory. "rccl": rank r on cuda:r, the native
+    `ncclBroadcast` / `ncclAllGather` of csrc/sharded.hip (gloo only carries the unique id and the expectation)."""
+    WORLD = world  # noqa: N806 — the body below reads the world size under this name
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # both ranks are here: never the interface the hostname resolves to
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC, or RCCL cannot share buffers between the processes
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     try:
         import bench
         import usearch_amd
         from oracle import oraclebind
         from usearch_amd.sharded import Communicator, ShardedSearcher
-        device = torch.device("cuda", 0)
-        torch.cuda.set_device(0)
+        ordinal = rank if transport == "rccl" else 0
+        device = torch.device("cuda", ordinal)
+        torch.cuda.set_device(ordinal)
 
         def all_gather(send: np.ndarray, receive: np.ndarray):
             dist.all_gather_into_tensor(torch.from_numpy(receive), torch.from_numpy(send))
@@ -37,11 +42,20 @@ def worker(rank: int, port: int, results):
         def broadcast(buffer: np.ndarray, root: int):
             dist.broadcast(torch.from_numpy(buffer), src=root)
 
-        communicator = Communicator.over_host_collectives(rank, WORLD, 0, all_gather, broadcast)
+        def share_id(unique):
+            box = [unique]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        if transport == "rccl":
+            communicator = Communicator.rccl(rank, WORLD, ordinal, share_id)
+            assert communicator.kind == "rccl-native" and communicator.world == WORLD and communicator.rank == rank
+        else:
+            communicator = Communicator.over_host_collectives(rank, WORLD, 0, all_gather, broadcast)
         for metric, dtype, dim, n, q, k, expansion in CASES:
             data = bench.synthetic_vectors_device(n, dim, dtype, 100 + rank, device)
             keys = np.arange(n, dtype=np.uint64) + rank * n
-            built = usearch_amd.build(None, metric, dtype, keys=keys, device=0, device_pointer=data.data_ptr(), count=n,
+            built = usearch_amd.build(None, metric, dtype, keys=keys, device=ordinal, device_pointer=data.data_ptr(), count=n,
                                       stride=data.stride(0), ndim=dim)
             index = built.index
             queries = bench.synthetic_vectors_device(q, dim, dtype, 7 if rank == 0 else 8, device)  # rank 0's batch wins
@@ -94,6 +108,26 @@ def test_two_ranks_one_shard_each_through_the_native_step():
                 raise
             print(f"two-rank rendezvous failed, trying once more: {str(error)[-2000:]}", flush=True)
     assert dict(results) == {0: True, 1: True}
+
+
+def test_rccl_transport_across_every_visible_device():
+    """The production transport with more than one rank — `ncclCommInitRank`, `ncclBroadcast` of the batch, ONE `ncclAllGather` of
+    the packed blocks, the merge kernel — one process per device over however many devices this box shows (up to 8), held to the
+    same expectation as the two-rank host-collective test (every rank's plain search folded by the oracle's `merge_into`) and to
+    the repeated exchange after a scratch overflow. Skipped on the one-GPU boxes of the test pool; wherever a node with more is
+    leased, the first multi-rank `ncclAllGather` of this code is a test and not a benchmark (python/lib.cpp:321-402)."""
+    devices = torch.cuda.device_count()
+    if devices < 2:
+        pytest.skip(f"{devices} device visible: RCCL refuses two ranks on one device (the two-rank test above runs the same step "
+                    "over host collectives)")
+    world = min(devices, 8)
+    manager = mp.Manager()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    results = manager.dict()
+    mp.spawn(worker, args=(port, results, world, "rccl"), nprocs=world, join=True)
+    assert dict(results) == {rank: True for rank in range(world)}
 
 
 def test_single_rank_rccl_communicator():

@@ -194,6 +194,7 @@ const char* snapshot_t::append_for_build(std::uint64_t first, std::uint64_t coun
         UA_HIP(hipMemcpy(static_cast<std::uint64_t*>(d_keys_) + first, identity.data(), count * 8, hipMemcpyHostToDevice));
     }
     count_present_ = first + count;
+    ++mutations_;
     return nullptr;
 }
 
@@ -206,6 +207,7 @@ const char* snapshot_t::overwrite_member(std::uint64_t slot, const void* vector,
                                     view_.bytes_per_vector, 1))
         return e;
     UA_HIP(hipMemcpy(static_cast<std::uint64_t*>(d_keys_) + slot, &key, 8, hipMemcpyHostToDevice));
+    ++mutations_;
     return nullptr;
 }
 
@@ -216,6 +218,7 @@ const char* snapshot_t::set_key(std::uint64_t slot, std::uint64_t key) {
     UA_HIP(hipMemcpy(static_cast<std::uint64_t*>(d_keys_) + slot, &key, 8, hipMemcpyHostToDevice));
     if (key == free_key_k)
         view_.has_tombstones = 1;
+    ++mutations_;
     return nullptr;
 }
 

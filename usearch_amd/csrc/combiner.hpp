@@ -67,17 +67,49 @@ class combiner_t {
         }
         expected_back_ = 0;
         std::vector<combined_call_t*> batch, rest;
+        try { // allocation is the one thing that can fail between taking the launcher's seat and the launch
+            batch.reserve(waiting_.size()), rest.reserve(waiting_.size());
+        } catch (...) {
+            // give the seat back, or every later caller sleeps for good: this call leaves the queue and reports the failure,
+            // the others find nobody launching and one of them launches
+            for (std::size_t i = 0; i < waiting_.size(); ++i)
+                if (waiting_[i] == &call) {
+                    waiting_.erase(waiting_.begin() + (std::ptrdiff_t)i);
+                    break;
+                }
+            call.found = 0, call.error = "Out of memory", call.done = true;
+            launching_ = false;
+            changed_.notify_all();
+            return;
+        }
         for (combined_call_t* other : waiting_)
             (other->kind == call.kind && other->wanted == call.wanted && other->query_bytes == call.query_bytes ? batch : rest)
                 .push_back(other);
         waiting_.swap(rest);
         lock.unlock();
         const clock_t::time_point started = clock_t::now();
-        try {
-            run(batch);
-        } catch (...) {
-            for (combined_call_t* other : batch)
-                other->found = 0, other->error = "Unexpected failure inside the index";
+        auto guarded_run = [&](std::vector<combined_call_t*>& calls) {
+            try {
+                run(calls);
+            } catch (...) {
+                for (combined_call_t* other : calls)
+                    other->found = 0, other->error = "Unexpected failure inside the index";
+            }
+        };
+        guarded_run(batch);
+        // a launch that failed reports its error to every call it carried; so that one caller's trouble stays that caller's, the
+        // calls of a failed shared launch go out again one by one (rare, and no slower than the uncombined path)
+        bool failed = false;
+        for (combined_call_t* other : batch)
+            failed = failed || other->error != nullptr;
+        if (failed && batch.size() > 1) {
+            std::vector<combined_call_t*> single(1);
+            for (combined_call_t* other : batch) {
+                other->found = 0, other->error = nullptr;
+                single[0] = other;
+                guarded_run(single);
+            }
+            ++relaunched_;
         }
         const auto duration = std::chrono::duration_cast<std::chrono::nanoseconds>(clock_t::now() - started);
         lock.lock();
@@ -103,6 +135,12 @@ class combiner_t {
         return windows_expired_;
     }
 
+    /// How many shared launches reported an error and were repeated call by call (telemetry / tests).
+    std::uint64_t relaunched() {
+        std::lock_guard<std::mutex> lock(mutex_);
+        return relaunched_;
+    }
+
     /// The longest a launcher waits for the callers of the launch before its own; zero: it never waits.
     void window_limit(std::chrono::nanoseconds limit) {
         std::lock_guard<std::mutex> lock(mutex_);
@@ -117,7 +155,7 @@ class combiner_t {
     bool launching_ = false;
     std::size_t expected_back_ = 0; ///< calls the last launch served whose callers have not called again yet
     std::chrono::nanoseconds last_duration_{0}, window_limit_{200000};
-    std::uint64_t launches_ = 0, calls_ = 0, windows_expired_ = 0;
+    std::uint64_t launches_ = 0, calls_ = 0, windows_expired_ = 0, relaunched_ = 0;
 };
 
 } // namespace usearch_amd

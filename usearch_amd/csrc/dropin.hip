@@ -159,6 +159,20 @@ struct index_t {
     /// (read when the index is created) turns it off.
     bool coalesce = env_size("USEARCH_AMD_COALESCE", 1) != 0;
     combiner_t combiner;
+    /// `usearch_filtered_search` under USEARCH_AMD_FILTER_MEMO=1 (read at `usearch_init`): the bitmap a callback produced is kept per
+    /// (callback, state pointer, index version) and the next call with the same three makes NO callbacks and uploads nothing. Opt-in,
+    /// because it needs more than the ABI promises: the predicate must be a pure function of the key for as long as the state
+    /// POINTER stays the same (the reference calls it afresh, a few thousand times per query: c/lib.cpp:413-429, index.hpp:4200-4205).
+    bool filter_memo = env_size("USEARCH_AMD_FILTER_MEMO", 0) != 0;
+    struct filter_memo_t {
+        int (*filter)(usearch_key_t, void*) = nullptr;
+        void* state = nullptr;
+        std::uint64_t version = 0;
+        std::shared_ptr<filter_t> bitmap;
+    };
+    std::mutex memo_mutex;
+    std::vector<filter_memo_t> memos; ///< most recent first, at most `memo_limit_k`
+    static constexpr std::size_t memo_limit_k = 8;
     // configuration — `usearch_init_options_t`, c/usearch.h:64-110
     metric_kind_t metric = metric_cos_k;
     scalar_kind_t scalar = scalar_f32_k;
@@ -199,6 +213,7 @@ struct index_t {
 
     void drop_device() {
         ++version;
+        memos.clear(); // the callers hold the index alone: no search is reading one
         delete builder, builder = nullptr;
         delete snapshot, snapshot = nullptr;
     }
@@ -791,6 +806,10 @@ void usearch_add(usearch_index_t handle, usearch_key_t key, void const* vector, 
             return fail(error, "Free key is reserved");
         if (!index.dimensions || !index.bpv())
             return fail(error, "Index is not initialized");
+        // a loaded / viewed image at capacity: the slots its tombstones hold are room too — the reference fills `free_keys_` right
+        // after a load (`reindex_keys_`, index_dense.hpp:2162-2200) — and here they are only listed once the image is staged
+        if (index.size() >= index.capacity && !index.staged && index.has_image && index.key_lookup().size() < index.size())
+            index.materialize();
         if (index.size() >= index.capacity && !(index.staged && index.free_head < index.free_slots.size()))
             return fail(error, "Reserve capacity ahead of insertions!"); // index.hpp:2812-2818: no growth on its own; a freed slot is room
         if (!index.multi && index.key_lookup().count(key))
@@ -871,6 +890,7 @@ static size_t search_shared(index_t& index, void const* queries, scalar_kind_t k
                         spare_distances.resize(queries_count * count), out_distances = spare_distances.data();
                     std::vector<std::uint32_t> bits;
                     search_extras_t extras;
+                    std::shared_ptr<filter_t> remembered; // keeps a memoised bitmap alive while this call reads it
                     if (made) {
                         // the predicate is already a bitmap in HBM (usearch_filter_from_*): nothing per member happens here
                         if (made->index != &index || made->version != index.version)
@@ -882,15 +902,38 @@ static size_t search_shared(index_t& index, void const* queries, scalar_kind_t k
                         // traversal then applies it where the reference does (index.hpp:4200-4205, 4236-4240), so results are
                         // the reference's as long as the predicate is a pure function of the key. O(members) callbacks PER
                         // CALL — the reference makes a few thousand; callers that search more than once under one predicate
-                        // make a `usearch_filter_t` instead.
-                        callback_bits(index, filter, filter_state, bits);
+                        // make a `usearch_filter_t` instead — or, if the predicate is pure for as long as its state pointer
+                        // stays the same, switch the memo on (USEARCH_AMD_FILTER_MEMO=1): the binary stays as it is.
+                        if (index.filter_memo && device_index) {
+                            std::lock_guard<std::mutex> memo_lock(index.memo_mutex); // one maker at a time; searches overlap
+                            for (const index_t::filter_memo_t& memo : index.memos)
+                                if (memo.filter == filter && memo.state == filter_state && memo.version == index.version)
+                                    remembered = memo.bitmap;
+                            if (!remembered) {
+                                callback_bits(index, filter, filter_state, bits);
+                                std::unique_ptr<filter_t> fresh;
+                                if (const char* e = filter_t::from_bits(*device_index, bits.data(), bits.size(), fresh))
+                                    return fail(error, e);
+                                remembered = std::move(fresh);
+                                std::vector<index_t::filter_memo_t> kept;
+                                kept.push_back({filter, filter_state, index.version, remembered});
+                                for (index_t::filter_memo_t& memo : index.memos) // bitmaps of older versions describe nothing now
+                                    if (memo.version == index.version && kept.size() < index_t::memo_limit_k)
+                                        kept.push_back(std::move(memo));
+                                index.memos.swap(kept);
+                            }
+                            extras.allow_bits = remembered->bits();
+                        } else {
+                            callback_bits(index, filter, filter_state, bits);
+                        }
                     }
                     if (!device_index) { // nothing indexed yet: index.hpp:3034-3037
                         pad_results(reinterpret_cast<usearch_key_t*>(out_keys), out_distances, queries_count * count);
                     } else if (const char* e = device_index->search_host(
                                    queries, kind, queries_count, queries_stride, count, index.expansion_search, out_keys,
                                    out_distances, found.data(), visited.data(), computed.data(), search_tuning_t{}, nullptr,
-                                   filter && !made ? bits.data() : nullptr, made ? &extras : nullptr)) {
+                                   filter && !made && !remembered ? bits.data() : nullptr,
+                                   made || remembered ? &extras : nullptr)) {
                         return fail(error, e);
                     }
                     std::size_t total_visited = 0, total_computed = 0;

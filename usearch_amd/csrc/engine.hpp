@@ -186,6 +186,9 @@ class snapshot_t {
     const char* overwrite_member(std::uint64_t slot, const void* vector, std::uint64_t key);
     /// Overwrites one member's key in HBM (rename; `free_key_k` = tombstone).
     const char* set_key(std::uint64_t slot, std::uint64_t key);
+    /// Counts what changes WHO the members are without necessarily changing how many there are (`append_for_build`,
+    /// `overwrite_member`, `set_key`): a `filter_t` made before is a bitmap of the keys as they were (filter.hpp: `check`).
+    std::uint64_t mutations() const { return mutations_; }
     std::uint64_t build_capacity() const { return build_capacity_; }
     std::uint64_t build_lists_capacity() const { return build_lists_capacity_; }
     void set_upper_lists(std::uint64_t lists) { upper_lists_ = lists; }
@@ -267,7 +270,7 @@ class snapshot_t {
     std::uint32_t lanes_ = 1;
     int device_ = 0;
     std::size_t device_bytes_ = 0;
-    std::uint64_t count_present_ = 0, upper_lists_ = 0;
+    std::uint64_t count_present_ = 0, upper_lists_ = 0, mutations_ = 0;
 
     void* d_vectors_ = nullptr;
     void* d_nbr0_ = nullptr;

@@ -411,7 +411,10 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                                                                     const std::uint32_t* row_norms, const std::uint32_t* query_norms,
                                                                     std::uint32_t map_keys, const std::uint32_t* allow_bits,
                                                                     std::uint32_t* shared_bounds, float* out_distances,
-                                                                    std::uint64_t* out_keys, std::uint64_t* out_counts) {
+                                                                    std::uint64_t* out_keys, std::uint64_t* out_counts,
+                                                                    std::uint32_t knock) {
+    // `knock` (USEARCH_AMD_EXACT_KNOCKOUT, timing experiments only — results are wrong with any bit set): 1 = no fold, 2 = no fills
+    // after the prologue's, 4 = no wait for the fills and no barrier
     using accumulator_t = typename accumulator_gt<scalar_ak>::type;
     constexpr bool integers = scalar_ak == scalar_i8_k;
     using sum_t = typename std::conditional<integers, int, float>::type;
@@ -429,7 +432,9 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
     float* lists_d = reinterpret_cast<float*>(others + 2 * 512);                        // with `lds_lists_ak`: [256][wanted] distances
     std::uint32_t* lists_s = reinterpret_cast<std::uint32_t*>(lists_d + wide_queries_k * wanted); // … and slots
 
-    const std::uint32_t thread = threadIdx.x, wave = thread / 64, lane = thread % 64;
+    // the wave's number as a SCALAR: everything that only depends on it — the LDS targets of the fills (they travel in M0), the
+    // wave's slices of the per-query arrays — is then scalar arithmetic instead of vector registers held (and spilled) across the loop
+    const std::uint32_t thread = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(thread / 64), lane = thread % 64;
     // ---- which (query tile, partition) this workgroup is (wide_plan): workgroups go to the XCDs round-robin by their linear
     //      index; an XCD's `tiles_per_xcd` consecutive workgroups work on ONE partition for different query tiles (the row tile
     //      they stream is shared through the XCD's L2). A batch of ≥ 8 query tiles is dealt over the XCDs (tile = 8·g + xcd, every
@@ -824,19 +829,23 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
     std::uint64_t phase_ticks[4] = {0, 0, 0, 0}, phase_mark = __builtin_amdgcn_s_memtime();
 #endif
     for (std::uint32_t c = 0; c < total; ++c) {
+        const bool filling = c + 1 < total && !(knock & 2u);
         if (work_chunk == 0)
-            multiply_chunk(std::true_type{}, c & 1u, c + 1 < total, (c + 1) & 1u);
+            multiply_chunk(std::true_type{}, c & 1u, filling, (c + 1) & 1u);
         else
-            multiply_chunk(std::false_type{}, c & 1u, c + 1 < total, (c + 1) & 1u);
+            multiply_chunk(std::false_type{}, c & 1u, filling, (c + 1) & 1u);
         UA_PHASE_TICK(0)
         if (++work_chunk == chunks) {
-            fold_tile();
+            if (!(knock & 1u))
+                fold_tile();
             work_chunk = 0, ++work_tile;
         }
         UA_PHASE_TICK(1)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        UA_PHASE_TICK(2)
-        __builtin_amdgcn_s_barrier();
+        if (!(knock & 4u)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            UA_PHASE_TICK(2)
+            __builtin_amdgcn_s_barrier();
+        }
         UA_PHASE_TICK(3)
     }
 #ifdef USEARCH_AMD_EXACT_PHASES
@@ -903,7 +912,8 @@ hipError_t launch_wide(const snapshot_view_t& view, const std::uint8_t* queries,
                        padded_stride, padded_rows);
     hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(wide_threads_k), lds_bytes, stream, view,
                        (const std::uint8_t*)padded, padded_stride, query_count, wanted, rows_per_partition, query_tiles, tiles_per_xcd, row_norms,
-                       query_norms, map_keys ? 1u : 0u, allow_bits, shared_bounds, out_distances, out_keys, out_counts);
+                       query_norms, map_keys ? 1u : 0u, allow_bits, shared_bounds, out_distances, out_keys, out_counts,
+                       (std::uint32_t)env_size("USEARCH_AMD_EXACT_KNOCKOUT", 0));
     return hipGetLastError();
 }
 

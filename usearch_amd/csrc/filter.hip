@@ -90,6 +90,7 @@ const char* filter_t::allocate(snapshot_t& snapshot) {
     owner_ = &snapshot;
     device_ = snapshot.device();
     members_ = snapshot.view().size;
+    mutations_ = snapshot.mutations();
     if (members_ >= none_slot_k)
         return "Index is too large for 32-bit slots";
     UA_HIP(hipSetDevice(device_));
@@ -113,7 +114,8 @@ const char* filter_t::finish(hipStream_t stream) {
 const char* filter_t::check(const snapshot_t& snapshot) const {
     if (owner_ != &snapshot)
         return "The filter was made for another index";
-    if (members_ != snapshot.view().size)
+    // the count alone would miss a rename, a tombstone or a recycled slot (builder_t::update, set_key): same size, other keys
+    if (members_ != snapshot.view().size || mutations_ != snapshot.mutations())
         return "The index changed since the filter was made";
     return nullptr;
 }

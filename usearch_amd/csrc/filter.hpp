@@ -48,7 +48,7 @@ class filter_t {
     const snapshot_t* owner_ = nullptr;
     std::uint32_t* d_bits_ = nullptr;
     unsigned long long* d_allowed_ = nullptr;
-    std::uint64_t members_ = 0, allowed_ = 0;
+    std::uint64_t members_ = 0, allowed_ = 0, mutations_ = 0; ///< … and the snapshot's mutation count when it was made
     int device_ = 0;
 };
 

@@ -1372,12 +1372,15 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                     const std::uint32_t room = ef - top.size;
                     bool exact = room == 0u || room >= popcount64(newcomers); // else the buffer fills up mid-commit
                     const bool lands = candidate && (room != 0u || mine < radius);
+                    if (ballot(lands && mine != mine))
+                        exact = false; // a NaN among the landing newcomers orders against nothing: the long way
                     if (exact && ballot(lands)) {
                         const float best = wave_min_f32(lands ? mine : __builtin_inff());
                         const std::uint64_t at_best = ballot(lands && mine == best);
                         if (!has_open || best < open_distance) {
-                            if (at_best & (at_best - 1))
-                                exact = false; // two newcomers at the smallest distance: their order in the array decides
+                            if (at_best == 0 || (at_best & (at_best - 1)))
+                                exact = false; // two newcomers at the smallest distance: their order in the array decides — or none
+                                               // at it at all (every landing newcomer a NaN, which equals nothing): commit, look again
                             else
                                 from_lane = (std::uint32_t)__ffsll((long long)at_best) - 1;
                         } else if (best == open_distance)
