@@ -604,6 +604,52 @@ def test_add_after_a_search_links_only_the_new_members(lib):
     lib.usearch_free(index, C.byref(err))
 
 
+@pytest.mark.parametrize("immediate", ["0", "1"])
+def test_readers_racing_a_writer_find_what_was_added(lib, monkeypatch, immediate):
+    """index.hpp:2780-2879: a member is findable the moment `add` returns. The drop-in links staged members at the next search
+    (the default) or inside `usearch_add` itself (USEARCH_AMD_IMMEDIATE_ADD=1, read at `usearch_init`): either way four reader
+    threads racing one writer find every member whose `add` has returned, first and at distance zero."""
+    import threading
+    monkeypatch.setenv("USEARCH_AMD_IMMEDIATE_ADD", immediate)
+    err = C.c_char_p()
+    dimensions, first, more = 24, 1500, 120
+    options = create_options(dimensions, metric_kind=METRIC["l2sq"], connectivity=16, expansion_add=128, expansion_search=64)
+    data = create_vectors(first + more, dimensions, seed=29)
+    index = lib.usearch_init(C.byref(options), C.byref(err))
+    ok(err)
+    lib.usearch_reserve(index, first + more, C.byref(err))
+    for i in range(first):
+        lib.usearch_add(index, i, ptr(data[i]), SCALAR["f32"], C.byref(err))
+        ok(err)
+    added = [first]  # members 0 … added[0] - 1 are in: their `add` has returned
+    failures = []
+
+    def reader(seed):
+        rng = np.random.default_rng(seed)
+        failure = C.c_char_p()
+        keys = np.zeros(1, dtype=np.uint64)
+        distances = np.zeros(1, dtype=np.float32)
+        while added[0] < first + more and not failures:
+            upto = added[0]
+            member = int(rng.integers(max(0, upto - 8), upto))  # mostly the newest ones
+            found = lib.usearch_search(index, ptr(data[member]), SCALAR["f32"], 1, ptr(keys), ptr(distances), C.byref(failure))
+            if failure.value or found != 1 or keys[0] != member or distances[0] != 0.0:
+                failures.append((member, upto, failure.value, int(keys[0]), float(distances[0])))
+
+    readers = [threading.Thread(target=reader, args=(s,)) for s in range(4)]
+    for thread in readers:
+        thread.start()
+    for i in range(first, first + more):
+        lib.usearch_add(index, i, ptr(data[i]), SCALAR["f32"], C.byref(err))
+        ok(err)
+        added[0] = i + 1
+    for thread in readers:
+        thread.join()
+    assert not failures, failures[:3]
+    assert lib.usearch_size(index, C.byref(err)) == first + more
+    lib.usearch_free(index, C.byref(err))
+
+
 def test_remove_and_rename_do_not_relink(lib):
     """index_dense_gt::remove (index_dense.hpp:1479-1511) leaves the member in the graph as a tombstone; rename rewrites the
     key. Neither touches a list: the serialized graph before and after differs in the keys only."""

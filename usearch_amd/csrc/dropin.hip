@@ -164,6 +164,11 @@ struct index_t {
     /// because it needs more than the ABI promises: the predicate must be a pure function of the key for as long as the state
     /// POINTER stays the same (the reference calls it afresh, a few thousand times per query: c/lib.cpp:413-429, index.hpp:4200-4205).
     bool filter_memo = env_size("USEARCH_AMD_FILTER_MEMO", 0) != 0;
+    /// `usearch_add` under USEARCH_AMD_IMMEDIATE_ADD=1 (read at `usearch_init`): the member is linked on the device before the call
+    /// returns, as the reference's `add` links it before it returns (index.hpp:2780-2879) — a reader racing a writer then sees what
+    /// it would see there. Off by default: a launch sequence per added vector where the batch-deferred form links thousands per
+    /// launch (bulk-load-then-search is what the device is for).
+    bool immediate_add = env_size("USEARCH_AMD_IMMEDIATE_ADD", 0) != 0;
     struct filter_memo_t {
         int (*filter)(usearch_key_t, void*) = nullptr;
         void* state = nullptr;
@@ -838,7 +843,13 @@ void usearch_add(usearch_index_t handle, usearch_key_t key, void const* vector, 
         ++index.version;
         if (index.lookup_valid)
             index.lookup.emplace(key, (std::uint32_t)slot);
-        // the device index, if there is one, stays: the next search links the members added since (builder_t::extend)
+        // the device index, if there is one, stays: the next search links the members added since (builder_t::extend) — or this
+        // call does, for hosts that want the reference's visibility (a member is findable the moment `add` returns)
+        if (index.immediate_add) {
+            snapshot_t* device_index = nullptr;
+            if (const char* e = index.ready(&device_index))
+                return fail(error, e);
+        }
     });
 }
 
