@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """scripts/exact_knockout.py — where the wide exact tile's time goes, by taking parts of it out (timing only: with any part out the
 results are wrong). `USEARCH_AMD_EXACT_KNOCKOUT` is read per launch (csrc/exact_tiled.hip: 1 = no fold, 2 = no fills after the
-prologue's, 4 = no wait for the fills and no barrier). Prints kernel ms and T(FL)OP/s per combination, same process, same data.
+prologue's, 4 = no wait for the fills and no barrier, 8 = thresholds refreshed once, 16 = no per-block tests). Prints kernel ms and T(FL)OP/s per combination, same process, same data.
 
     python scripts/exact_knockout.py [--n 10000000] [--dim 768] [--queries 10000] [--dtype f16] [--combos 0,1,4,5,3,7]
 """
@@ -49,12 +49,12 @@ def main() -> None:
     operations = 2.0 * args.queries * args.n * args.dim
     for _ in range(3):
         step()
-    names = {1: "no fold", 2: "no fills", 4: "no barrier"}
+    names = {1: "no fold", 2: "no fills", 4: "no barrier", 8: "thresholds once", 16: "no block tests"}
     for combo in [int(c) for c in args.combos.split(",")]:
         os.environ["USEARCH_AMD_EXACT_KNOCKOUT"] = str(combo)
         step()
         ms = [step() for _ in range(args.repeats)]
-        what = " + ".join(names[b] for b in (1, 2, 4) if combo & b) or "the kernel as it is"
+        what = " + ".join(names[b] for b in (1, 2, 4, 8, 16) if combo & b) or "the kernel as it is"
         print(f"knockout {combo} ({what}): kernel {np.mean(ms):.1f} ms (min {np.min(ms):.1f}) = "
               f"{operations / (np.mean(ms) / 1e3) / 1e12:.0f} T(FL)OP/s", flush=True)
     os.environ["USEARCH_AMD_EXACT_KNOCKOUT"] = "0"

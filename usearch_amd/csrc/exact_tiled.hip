@@ -414,7 +414,8 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                                                                     std::uint64_t* out_keys, std::uint64_t* out_counts,
                                                                     std::uint32_t knock) {
     // `knock` (USEARCH_AMD_EXACT_KNOCKOUT, timing experiments only — results are wrong with any bit set): 1 = no fold, 2 = no fills
-    // after the prologue's, 4 = no wait for the fills and no barrier
+    // after the prologue's, 4 = no wait for the fills and no barrier, 8 = the fold's thresholds refreshed for the first tile only, 16 = the
+    // fold without its per-block tests
     using accumulator_t = typename accumulator_gt<scalar_ak>::type;
     constexpr bool integers = scalar_ak == scalar_i8_k;
     using sum_t = typename std::conditional<integers, int, float>::type;
@@ -491,38 +492,59 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
 
     // ---- LDS-DMA fills. A fill instruction of a wave writes 1 024 consecutive bytes = 8 staged rows; wave w fills rows
     //      64·pass + 8w … + 8 (4 passes of queries, 4 of dataset rows); lane i brings the piece that belongs in slot i of "its" row
-    //      (wide_swizzle; the same piece in every pass: row bases are multiples of 64). No branch on the data path: addresses are
-    //      clamped into the arrays — a row past the partition's end re-reads the last row (the epilogue drops it: `live`), bytes
-    //      past a row's last 16-byte chunk re-read that chunk and meet the zeros the padded queries hold there. Sources are
-    //      running pointers: a chunk is 128 bytes further on, a tile starts its rows anew.
+    //      (wide_swizzle; the same piece in every pass: row bases are multiples of 64). The BUFFER form of the instruction
+    //      (`buffer_load_dwordx4 … offen lds`): the 256 padded queries of the workgroup are one resource for the whole launch, the
+    //      256 rows of a tile one resource per tile (scalar arithmetic); a lane's share of an address is ONE 32-bit offset that
+    //      never changes — its row inside the block and its piece — and pass and chunk travel in the instruction's scalar offset.
+    //      A fill is then two scalar instructions (M0, the offset) and the load: no 64-bit vector address per fill and chunk (the
+    //      global form moved eight of them per wave and chunk through the vector ALU and twice the address registers to the
+    //      texture unit). No branch on the data path: a row past the partition's end lies outside its tile's resource (whatever
+    //      the staging cell then holds, the epilogue drops that column: `live`), bytes past a row's last 16-byte chunk re-read that
+    //      chunk (ragged rows only: one subtraction on the last chunk) and meet the zeros the padded queries hold there.
+    constexpr int resource_flags = 0x00020000; // raw buffer, 32-bit data format: what the range check needs on gfx94x / gfx950
     const std::uint32_t fill_row = wave * 8 + lane / 8; // + 64·pass
     const std::uint32_t fill_piece = wide_swizzle(fill_row, lane & 7u);
-    const std::uint64_t query_pass_bytes = 64 * padded_stride;
-    const std::uint8_t* query_source = padded_queries + (std::uint64_t)(first_query + fill_row) * padded_stride + fill_piece * 16; // pass 0, this chunk
-    const std::uint8_t* row_source[4] = {ix.vectors, ix.vectors, ix.vectors, ix.vectors}; // start of "my" four rows of the tile being fetched
-    std::uint32_t fetch_tile = 0, fetch_chunk = 0, fetch_byte = fill_piece * 16;
+    const std::uint32_t row_stride = (std::uint32_t)ix.row_stride, query_stride = (std::uint32_t)padded_stride; // × 256 fits 31 bits (launch_wide)
+    const __amdgpu_buffer_rsrc_t query_resource = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<std::uint8_t*>(padded_queries + (std::uint64_t)first_query * padded_stride), 0, (int)(wide_queries_k * query_stride),
+        resource_flags);
+    const std::uint32_t query_offset = fill_row * query_stride + fill_piece * 16; // + (64·pass rows + the chunk) in the scalar offset
+    const std::uint32_t row_offset = fill_row * row_stride + fill_piece * 16;
+    const bool ragged = row_bytes % chunk_bytes_k != 0; // the last chunk of a row ends before 128 bytes
+    // the tile's resource as three scalars (the compiler must SEE that they are: a resource it takes for lane-dependent is
+    // applied lane by lane, in a loop around every fill)
+    std::uint32_t row_base_low = 0, row_base_high = 0, row_records = 0;
+    std::uint32_t fetch_tile = 0, fetch_chunk = 0;
     auto begin_tile = [&]() {
         const std::uint64_t tile_row = first_row + (std::uint64_t)fetch_tile * wide_rows_k;
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const std::uint64_t wanted_row = tile_row + pass * 64 + fill_row;
-            row_source[pass] = ix.vectors + (wanted_row < last_row ? wanted_row : last_row - 1) * ix.row_stride;
-        }
+        const std::uint64_t rows_here = tile_row < last_row ? (last_row - tile_row < wide_rows_k ? last_row - tile_row : wide_rows_k) : 0;
+        const std::uint64_t base = (std::uint64_t)(ix.vectors + (tile_row < last_row ? tile_row : 0) * ix.row_stride);
+        row_base_low = __builtin_amdgcn_readfirstlane((std::uint32_t)base);
+        row_base_high = __builtin_amdgcn_readfirstlane((std::uint32_t)(base >> 32));
+        row_records = __builtin_amdgcn_readfirstlane((std::uint32_t)rows_here * row_stride);
     };
     auto fill_queries = [&](std::uint32_t buffer, int first_pass) { // two of the four query passes
         std::uint8_t* stage = lds + buffer * wide_stage_bytes_k;
 #pragma unroll
         for (int pass = first_pass; pass < first_pass + 2; ++pass)
-            __builtin_amdgcn_global_load_lds((global_bytes_t)(query_source + pass * query_pass_bytes),
-                                             (lds_bytes_t)(stage + (pass * 64 + wave * 8) * chunk_bytes_k), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(query_resource, (lds_bytes_t)(stage + (pass * 64 + wave * 8) * chunk_bytes_k), 16,
+                                                     (int)query_offset,
+                                                     (int)__builtin_amdgcn_readfirstlane(pass * 64 * query_stride + fetch_chunk * chunk_bytes_k), 0, 0);
     };
     auto fill_rows = [&](std::uint32_t buffer, int first_pass) { // two of the four row passes
         std::uint8_t* stage = lds + buffer * wide_stage_bytes_k;
-        const std::uint32_t byte_inside = fetch_byte < row_bytes ? fetch_byte : row_bytes - 16; // stored rows: 16-byte aligned, zero padded to 16
+        const __amdgpu_buffer_rsrc_t row_resource = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((std::uint64_t)row_base_high << 32) | row_base_low), 0, (int)row_records, resource_flags);
+        std::uint32_t offset = row_offset;
+        if (ragged && fetch_chunk + 1 == chunks) { // bytes past the row's last 16-byte chunk: that chunk again
+            const std::uint32_t byte = fetch_chunk * chunk_bytes_k + fill_piece * 16;
+            offset -= byte < row_bytes ? 0u : byte - (row_bytes - 16);
+        }
 #pragma unroll
         for (int pass = first_pass; pass < first_pass + 2; ++pass)
-            __builtin_amdgcn_global_load_lds((global_bytes_t)(row_source[pass] + byte_inside),
-                                             (lds_bytes_t)(stage + (wide_queries_k + pass * 64 + wave * 8) * chunk_bytes_k), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(row_resource, (lds_bytes_t)(stage + (wide_queries_k + pass * 64 + wave * 8) * chunk_bytes_k),
+                                                     16, (int)offset,
+                                                     (int)__builtin_amdgcn_readfirstlane(pass * 64 * row_stride + fetch_chunk * chunk_bytes_k), 0, 0);
     };
     auto fill_tile_head_and_advance = [&]() {
         if (fetch_chunk == 0) { // this wave's 32 queries' shared bounds as they stand now (lanes 32 … 63 repeat them), same DMA
@@ -535,10 +557,8 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                                                  (lds_bytes_t)(norms_r + (fetch_tile & 1u) * wide_rows_k + wave * 64), 4, 0, 0);
             }
         }
-        query_source += chunk_bytes_k, fetch_byte += chunk_bytes_k;
         if (++fetch_chunk == chunks) {
             fetch_chunk = 0, ++fetch_tile;
-            query_source -= (std::uint64_t)chunks * chunk_bytes_k, fetch_byte = fill_piece * 16;
             begin_tile();
         }
     };
@@ -680,7 +700,8 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                 for (int r = 0; r < 16; ++r)
                     roots[r] = __builtin_bit_cast(float, bits[r]);
             }
-            refresh_thresholds(shared, own, roots);
+            if (!(knock & 8u) || work_tile == 0)
+                refresh_thresholds(shared, own, roots);
         }
         const std::uint32_t tile_norms = lds_base + (std::uint32_t)((std::uint8_t*)(norms_r + (work_tile & 1u) * wide_rows_k + (lane & 31)) - lds);
         std::uint32_t tile_b2[wide_blocks_k];
@@ -699,6 +720,8 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
         const bool check_members = ix.has_tombstones || allow_bits != nullptr;
 #pragma unroll
         for (int u = 0; u < wide_blocks_k; ++u) {
+            if (knock & 16u)
+                continue;
             const std::uint64_t my_row = tile_row + u * 32 + (lane & 31);
             bool live = my_row < last_row;
             if (check_members) {
@@ -984,8 +1007,10 @@ const char* exact_search_tiled_device(metric_kind_t metric, scalar_kind_t scalar
     // The wide tile (256 queries per workgroup: a quarter of the dataset passes) takes batches that fill the chip with it; the
     // 64-query tile keeps the small batches and the long result lists. USEARCH_AMD_EXACT_TILE=64 / 256 forces either.
     const std::size_t forced_tile = env_size("USEARCH_AMD_EXACT_TILE", 0);
+    // (a tile of 256 rows, stored or padded, must lie inside one buffer resource with 32-bit offsets: rows of < 8 MB)
     const bool wide = forced_tile != 64 && wanted <= (std::size_t)wide_wanted_k && view.size >= 8u * 4u * wide_rows_k &&
-                      (forced_tile == 256 || count > 512);
+                      (forced_tile == 256 || count > 512) && (std::uint64_t)view.row_stride * wide_rows_k < (1ull << 31) &&
+                      wide_padded_stride(view.bytes_per_vector) * wide_queries_k < (1ull << 31);
     std::uint64_t partitions, rows_per_partition, tiles_per_xcd = 0, workgroups = 0;
     if (wide) {
         // ONE round of the chip (32 compute units per XCD) with as few partitions as that takes (exact_wide_kernel)

@@ -410,8 +410,10 @@ template <int epl_ak, bool global_ak, bool flags_ak = false> struct top_gt {
             const std::uint32_t below_s = lane_below_u32(s[epl_ak - 1]);
             below_d = lane == 0 ? -__builtin_inff() : below_d;
             // lower_bound placement: the landing cell is the first one that is not smaller than `nd` (new before equal)
+            // (for lane 0 that holds whatever `nd` is: a NaN compares smaller than nothing, lands in the very first cell — where
+            // the reference's lower_bound puts it, index.hpp:928-939 — and must not pull the cell "below" into the array)
             bool smaller[regs_k + 1];
-            smaller[0] = below_d < nd;
+            smaller[0] = lane == 0 || below_d < nd;
 #pragma unroll
             for (int i = 0; i < epl_ak; ++i)
                 smaller[i + 1] = d[i] < nd;
