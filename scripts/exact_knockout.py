@@ -49,12 +49,12 @@ def main() -> None:
     operations = 2.0 * args.queries * args.n * args.dim
     for _ in range(3):
         step()
-    names = {1: "no fold", 2: "no fills", 4: "no barrier", 8: "thresholds once", 16: "no block tests"}
+    names = {1: "no fold", 2: "no fills", 4: "no barrier", 8: "thresholds once", 16: "no block tests", 32: "general fold forced", 64: "fused fold without its rare path", 128: "fold at priority 3"}
     for combo in [int(c) for c in args.combos.split(",")]:
         os.environ["USEARCH_AMD_EXACT_KNOCKOUT"] = str(combo)
         step()
         ms = [step() for _ in range(args.repeats)]
-        what = " + ".join(names[b] for b in (1, 2, 4, 8, 16) if combo & b) or "the kernel as it is"
+        what = " + ".join(names[b] for b in (1, 2, 4, 8, 16, 32, 64, 128) if combo & b) or "the kernel as it is"
         print(f"knockout {combo} ({what}): kernel {np.mean(ms):.1f} ms (min {np.min(ms):.1f}) = "
               f"{operations / (np.mean(ms) / 1e3) / 1e12:.0f} T(FL)OP/s", flush=True)
     os.environ["USEARCH_AMD_EXACT_KNOCKOUT"] = "0"

@@ -91,7 +91,7 @@ def test_tiled_exact_search_is_bit_identical_for_i8(reference, monkeypatch, metr
 
 
 @pytest.mark.parametrize("tile", [64, 256])
-@pytest.mark.parametrize("metric,dtype,ndim,n,k", [("cos", "f16", 768, 12001, 10), ("ip", "f16", 100, 9000, 32),
+@pytest.mark.parametrize("metric,dtype,ndim,n,k", [("cos", "f16", 768, 12001, 10), ("ip", "f16", 100, 9000, 32), ("ip", "f16", 256, 9000, 10),
                                                    ("cos", "bf16", 96, 7000, 10), ("ip", "bf16", 768, 5000, 5),
                                                    ("l2sq", "f16", 96, 6000, 10), ("l2sq", "bf16", 200, 5000, 8)])
 def test_tiled_exact_search_of_float_pairs_is_within_tolerance(reference, monkeypatch, metric, dtype, ndim, n, k, tile):
@@ -113,6 +113,43 @@ def test_tiled_exact_search_of_float_pairs_is_within_tolerance(reference, monkey
     with pytest.raises(RuntimeError):  # no matrix-unit kernel for this pair: said so, not silently rerouted
         image32, _, _ = util.build_image(500, 16, "l2sq", "f32", seed=1)
         Index.restore(image32).search(np.zeros((2, 16), dtype=np.float32), 3, exact="tiled")
+
+
+@pytest.mark.parametrize("metric", ["cos", "ip"])
+def test_wide_tile_thresholds_inside_the_sums_at_their_corners(reference, monkeypatch, metric):
+    """The wide tile's fold for f16 cos / ip keeps Σab − threshold·√Σb² in the accumulators (exact_tiled.hip: `fold_tile_fused`):
+    thresholds of either sign (queries that point AWAY from every row: the k-th best similarity is negative), rows whose norm f16
+    cannot carry (zero rows, rows of 1e-6), a query of zero norm (no finite threshold: the general fold takes its wave's tiles),
+    many equal rows (ties at the threshold). Same neighbours and distances as the bit-exact kernel within the float tolerance —
+    and, with the general fold forced (knock-out 32), the very same bits from the same kernel."""
+    from usearch_amd import Index
+    monkeypatch.setenv("USEARCH_AMD_EXACT_TILE", "256")
+    rng = np.random.default_rng(123)
+    n, ndim, k = 9000, 128, 10
+    direction = rng.standard_normal(ndim).astype(np.float32)
+    vectors = (direction[None, :] + 0.3 * rng.standard_normal((n, ndim))).astype(np.float16)
+    vectors[100:110] = 0                       # zero rows
+    vectors[200:220] = (vectors[200:220].astype(np.float32) * 1e-6).astype(np.float16)  # norms below what f16 carries
+    vectors[300:340] = vectors[300]            # forty equal rows
+    image, _, _ = util.build_image(n, ndim, metric, "f16", vectors=vectors, expansion_add=16, connectivity=4)
+    queries = np.concatenate([(-direction[None, :] + 0.3 * rng.standard_normal((150, ndim))),   # every similarity negative
+                              (direction[None, :] + 0.3 * rng.standard_normal((149, ndim))),
+                              np.zeros((1, ndim))]).astype(np.float16)                          # a query of zero norm
+    queries[7] = vectors[300]
+    index = Index.restore(image)
+    exact = index.search(queries, k, exact=True, dtype="f16")
+    tiled = index.search(queries, k, exact="tiled", dtype="f16")
+    assert np.array_equal(exact.counts, tiled.counts)
+    scale = np.maximum(1.0, np.abs(exact.distances))
+    assert np.all(np.abs(exact.distances - tiled.distances) <= util.tolerance("f16") * scale)
+    assert (exact.keys == tiled.keys).mean() > 0.9  # ties (forty equal rows, zero rows at distance 1) may be named in another order
+    assert np.all(np.diff(tiled.distances, axis=1) >= 0)
+    monkeypatch.setenv("USEARCH_AMD_EXACT_KNOCKOUT", "32")
+    general = index.search(queries, k, exact="tiled", dtype="f16")
+    monkeypatch.delenv("USEARCH_AMD_EXACT_KNOCKOUT")
+    assert np.array_equal(general.counts, tiled.counts)
+    assert np.all(np.abs(general.distances - tiled.distances) <= 2e-6 * scale), "the two folds close the same sums"
+    assert (general.keys == tiled.keys).mean() > 0.97
 
 
 def test_exact_search_of_a_raw_i8_dataset_takes_the_matrix_units(monkeypatch):

@@ -340,7 +340,7 @@ inline std::uint64_t wide_padded_stride(std::uint64_t bytes_per_vector) {
 /// hundred cycles instead of a global round trip and a fence: the epilogue and, through it, the barrier shrink).
 constexpr int wide_lds_lists_k = 10;
 constexpr std::uint32_t wide_lds_bytes(bool lds_lists, std::uint32_t wanted) {
-    return wide_buffers_k * wide_stage_bytes_k + wide_queries_k * 4 * 4 + 2 * wide_rows_k * 4 + 2 * 512 * 4 +
+    return wide_buffers_k * wide_stage_bytes_k + wide_queries_k * 4 * 5 + 2 * wide_rows_k * 4 + 2 * 512 * 4 +
            (lds_lists ? wide_queries_k * wanted * 8 : 0);
 }
 
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                                                                     std::uint32_t knock) {
     // `knock` (USEARCH_AMD_EXACT_KNOCKOUT, timing experiments only — results are wrong with any bit set): 1 = no fold, 2 = no fills
     // after the prologue's, 4 = no wait for the fills and no barrier, 8 = the fold's thresholds refreshed for the first tile only, 16 = the
-    // fold without its per-block tests
+    // fold without its per-block tests, 32 = the general fold where the fused one would run (results stay right), 64 = the fused fold without what follows a block's test
     using accumulator_t = typename accumulator_gt<scalar_ak>::type;
     constexpr bool integers = scalar_ak == scalar_i8_k;
     using sum_t = typename std::conditional<integers, int, float>::type;
@@ -430,7 +430,8 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                                                        // (fills run one chunk ahead: the next tile at most): slot = tile mod 2
     std::uint32_t* others = norms_r + 2 * wide_rows_k; // [2][8][64] the queries' shared bounds as fetched with the tile (same
                                                        // slots): a fill writes 64 cells, a wave's 32 queries twice
-    float* lists_d = reinterpret_cast<float*>(others + 2 * 512);                        // with `lds_lists_ak`: [256][wanted] distances
+    float* folded = reinterpret_cast<float*>(others + 2 * 512); // [256] what the fused fold put into the sums per query (f16 cos / ip)
+    float* lists_d = folded + wide_queries_k;                                           // with `lds_lists_ak`: [256][wanted] distances
     std::uint32_t* lists_s = reinterpret_cast<std::uint32_t*>(lists_d + wide_queries_k * wanted); // … and slots
 
     // the wave's number as a SCALAR: everything that only depends on it — the LDS targets of the fills (they travel in M0), the
@@ -548,11 +549,13 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
     };
     auto fill_tile_head_and_advance = [&]() {
         if (fetch_chunk == 0) { // this wave's 32 queries' shared bounds as they stand now (lanes 32 … 63 repeat them), same DMA
-            const std::uint32_t q = first_query + wave * 32 + (lane & 31);
+            std::uint32_t lane_here = lane; // opaque: once per tile, two addresses computed on the spot instead of four registers
+            asm volatile("" : "+v"(lane_here)); // held across the loop (and spilled: a reload waits for every fill in flight)
+            const std::uint32_t q = first_query + wave * 32 + (lane_here & 31);
             __builtin_amdgcn_global_load_lds((global_bytes_t)(shared_bounds + (q < query_count ? q : query_count - 1)),
                                              (lds_bytes_t)(others + (fetch_tile & 1u) * 512 + wave * 64), 4, 0, 0);
             if (wave < wide_rows_k / 64) { // the tile's Σb², 64 per wave
-                const std::uint64_t wanted_row = first_row + (std::uint64_t)fetch_tile * wide_rows_k + wave * 64 + lane;
+                const std::uint64_t wanted_row = first_row + (std::uint64_t)fetch_tile * wide_rows_k + wave * 64 + lane_here;
                 __builtin_amdgcn_global_load_lds((global_bytes_t)(row_norms + (wanted_row < last_row ? wanted_row : last_row - 1)),
                                                  (lds_bytes_t)(norms_r + (fetch_tile & 1u) * wide_rows_k + wave * 64), 4, 0, 0);
             }
@@ -649,13 +652,97 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
 #undef UA_REQUEST_ROWS
 #undef UA_AWAIT
 
+    // ---- LDS words behind the compiler's back. A read or write it can see makes it wait for every LDS-DMA fill in flight first
+    //      (`s_waitcnt vmcnt(0)`: for all it knows the fill writes the very cell) — a wave that finds a candidate for a list would
+    //      sit out the landing of the next tile's first chunk, and the seven others meet it at the barrier. The cells these touch
+    //      (limits, list sizes, lists, what the fused fold put in) are never a fill's target.
+    auto lds_address = [&](const void* cell) -> std::uint32_t { return lds_base + (std::uint32_t)((const std::uint8_t*)cell - lds); };
+    auto lds_read = [&](const void* cell) -> std::uint32_t {
+        std::uint32_t value;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(value) : "v"(lds_address(cell)) : "memory");
+        return value;
+    };
+    auto lds_write = [&](void* cell, std::uint32_t value) { asm volatile("ds_write_b32 %0, %1" : : "v"(lds_address(cell)), "v"(value) : "memory"); };
+
+    /// Offers (distance `d`, slot `s`) to query i's list — the whole wave calls it together, uniformly: the ordered insert that the
+    /// rare path of either fold ends in.
+    auto offer = [&](std::uint32_t i, std::uint32_t s, float d) {
+        if (d > __builtin_bit_cast(float, lds_read(limit + i))) // farther than this partition's k-th best (the test in the registers is a tile old): no list access
+            return;
+        const std::uint32_t size = lds_read(top_n + i);
+        const bool mine = lane < size;
+        float my_d = 0.f;
+        std::uint32_t my_s = 0u;
+        // the list: in LDS when it fits there, else where it ends up — this partition's cells of the output arrays
+        // (distances as they are, the slot in the low word of the key cell until the end)
+        const std::uint64_t cells = ((std::uint64_t)partition * query_count + first_query + i) * wanted;
+        float* entries_d = lds_lists_ak ? lists_d + i * wanted : out_distances + cells;
+        std::uint32_t* entries_s = lds_lists_ak ? lists_s + i * wanted : reinterpret_cast<std::uint32_t*>(out_keys + cells);
+        constexpr std::uint32_t slot_pitch = lds_lists_ak ? 1u : 2u; // entry e of a key cell list: word 2e
+        // the whole list in registers, a lane per entry (read once: what follows never re-reads what it wrote)
+        if constexpr (lds_lists_ak) {
+            const std::uint32_t entry = mine ? lane : 0u;
+            const std::uint32_t read_d = lds_read(entries_d + entry), read_s = lds_read(entries_s + entry);
+            my_d = mine ? __builtin_bit_cast(float, read_d) : 0.f, my_s = mine ? read_s : 0u;
+        } else if (mine) {
+            my_d = entries_d[lane], my_s = entries_s[slot_pitch * lane];
+        }
+        if (size == wanted) { // full: the newcomer has to beat the last entry
+            const float last_d = __shfl(my_d, (int)(size - 1), 64);
+            const std::uint32_t last_s = (std::uint32_t)__shfl((int)my_s, (int)(size - 1), 64);
+            if (!goes_before(d, s, last_d, last_s))
+                return;
+        }
+        // position = entries that go before the newcomer; the ones at and after it move one cell down
+        const std::uint32_t position = (std::uint32_t)__popcll(__ballot(mine && goes_before(my_d, my_s, d, s)));
+        const std::uint32_t grown = size < wanted ? size + 1 : size;
+        // the new k-th best: the newcomer if it went last, else what was second to last
+        const std::uint32_t new_last = grown - 1;
+        const float shifted = __shfl(my_d, (int)(new_last ? new_last - 1 : 0), 64);
+        const float kth = position == new_last ? d : shifted;
+        if constexpr (lds_lists_ak) {
+            if (mine && lane >= position && lane + 1 < grown)
+                lds_write(entries_d + lane + 1, __builtin_bit_cast(std::uint32_t, my_d)), lds_write(entries_s + lane + 1, my_s);
+            if (lane == position)
+                lds_write(entries_d + position, __builtin_bit_cast(std::uint32_t, d)), lds_write(entries_s + position, s);
+            if (lane == 0) {
+                lds_write(top_n + i, grown);
+                if (grown == wanted) { // k rows at most this far exist: no partition needs anything farther for this query
+                    lds_write(limit + i, __builtin_bit_cast(std::uint32_t, kth));
+                    atomicMin(shared_bounds + first_query + i, ordered_bits(kth));
+                }
+            }
+            // this wave's next insert into the list reads these cells: the LDS pipe of a compute unit serves one wave's accesses in
+            // the order it issued them, and nobody else touches this wave's queries
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            if (mine && lane >= position && lane + 1 < grown)
+                entries_d[lane + 1] = my_d, entries_s[slot_pitch * (lane + 1)] = my_s;
+            if (lane == position)
+                entries_d[position] = d, entries_s[slot_pitch * position] = s;
+            if (lane == 0) {
+                top_n[i] = grown;
+                if (grown == wanted) {
+                    limit[i] = kth;
+                    atomicMin(shared_bounds + first_query + i, ordered_bits(kth));
+                }
+            }
+            // this wave's next insert into the list reads these cells
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    };
+
     /// The tile's 32 × 256 sums of this wave against its queries' lists; the accumulators are cleared for the next tile.
     auto fold_tile = [&]() {
         const std::uint64_t tile_row = first_row + (std::uint64_t)work_tile * wide_rows_k;
+        std::uint32_t lane_here = lane; // opaque: the addresses below are computed here, not held (and spilled) across the chunk loop
+        asm volatile("" : "+v"(lane_here));
         // the tile's Σb² and the shared bounds by hand-waited reads, like the fragments: a compiler-visible LDS read here would
         // drain the fills in flight. Registers 4j … 4j + 3 ↔ queries 8j + 4·(lane >> 5) + 0 … 3
         {
-            const std::uint32_t cells = lds_base + (std::uint32_t)((std::uint8_t*)(others + (work_tile & 1u) * 512 + wave * 64 + 4 * (lane >> 5)) - lds);
+            const std::uint32_t cells = lds_base + (std::uint32_t)((std::uint8_t*)(others + (work_tile & 1u) * 512 + wave * 64 + 4 * (lane_here >> 5)) - lds);
             u32x4_t s0, s1, s2, s3;
             asm volatile("ds_read_b128 %0, %4\n\t"
                          "ds_read_b128 %1, %4 offset:32\n\t"
@@ -668,7 +755,7 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                                               s2[0], s2[1], s2[2], s2[3], s3[0], s3[1], s3[2], s3[3]};
             float own[16];
             {
-                const std::uint32_t own_cells = lds_base + (std::uint32_t)((std::uint8_t*)(limit + wave * 32 + 4 * (lane >> 5)) - lds);
+                const std::uint32_t own_cells = lds_base + (std::uint32_t)((std::uint8_t*)(limit + wave * 32 + 4 * (lane_here >> 5)) - lds);
                 u32x4_t o0, o1, o2, o3;
                 asm volatile("ds_read_b128 %0, %4\n\t"
                              "ds_read_b128 %1, %4 offset:32\n\t"
@@ -685,7 +772,7 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
             }
             float roots[16] = {};
             if constexpr (metric_ak == metric_cos_k) {
-                const std::uint32_t root_cells = lds_base + (std::uint32_t)((std::uint8_t*)(roots_q + wave * 32 + 4 * (lane >> 5)) - lds);
+                const std::uint32_t root_cells = lds_base + (std::uint32_t)((std::uint8_t*)(roots_q + wave * 32 + 4 * (lane_here >> 5)) - lds);
                 u32x4_t q0, q1, q2, q3;
                 asm volatile("ds_read_b128 %0, %4\n\t"
                              "ds_read_b128 %1, %4 offset:32\n\t"
@@ -703,7 +790,7 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
             if (!(knock & 8u) || work_tile == 0)
                 refresh_thresholds(shared, own, roots);
         }
-        const std::uint32_t tile_norms = lds_base + (std::uint32_t)((std::uint8_t*)(norms_r + (work_tile & 1u) * wide_rows_k + (lane & 31)) - lds);
+        const std::uint32_t tile_norms = lds_base + (std::uint32_t)((std::uint8_t*)(norms_r + (work_tile & 1u) * wide_rows_k + (lane_here & 31)) - lds);
         std::uint32_t tile_b2[wide_blocks_k];
         asm volatile("ds_read_b32 %0, %8\n\t"
                      "ds_read_b32 %1, %8 offset:128\n\t"
@@ -783,57 +870,151 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                         sum = rr == r ? acc[u][rr] : sum;
                     sum = __shfl(sum, (int)source, 64);
                     const std::uint32_t source_b2 = (std::uint32_t)__shfl((int)b2, (int)source, 64);
-                    const float d = closing_distance<metric_ak, scalar_ak>(sum, norms_q[i], source_b2);
-                    if (d > limit[i]) // farther than this partition's k-th best (the test in the registers is a tile old): no list access
-                        continue;
-                    // the list: in LDS when it fits there, else where it ends up — this partition's cells of the output arrays
-                    // (distances as they are, the slot in the low word of the key cell until the end)
-                    const std::uint64_t cells = ((std::uint64_t)partition * query_count + first_query + i) * wanted;
-                    float* entries_d = lds_lists_ak ? lists_d + i * wanted : out_distances + cells;
-                    std::uint32_t* entries_s = lds_lists_ak ? lists_s + i * wanted : reinterpret_cast<std::uint32_t*>(out_keys + cells);
-                    constexpr std::uint32_t slot_pitch = lds_lists_ak ? 1u : 2u; // entry e of a key cell list: word 2e
-                    const std::uint32_t size = top_n[i];
-                    // the whole list in registers, a lane per entry (read once: what follows never re-reads what it wrote)
-                    const bool mine = lane < size;
-                    const float my_d = mine ? entries_d[lane] : 0.f;
-                    const std::uint32_t my_s = mine ? entries_s[slot_pitch * lane] : 0u;
-                    if (size == wanted) { // full: the newcomer has to beat the last entry
-                        const float last_d = __shfl(my_d, (int)(size - 1), 64);
-                        const std::uint32_t last_s = (std::uint32_t)__shfl((int)my_s, (int)(size - 1), 64);
-                        if (!goes_before(d, s, last_d, last_s))
-                            continue;
-                    }
-                    // position = entries that go before the newcomer; the ones at and after it move one cell down
-                    const std::uint32_t position = (std::uint32_t)__popcll(__ballot(mine && goes_before(my_d, my_s, d, s)));
-                    const std::uint32_t grown = size < wanted ? size + 1 : size;
-                    if (mine && lane >= position && lane + 1 < grown)
-                        entries_d[lane + 1] = my_d, entries_s[slot_pitch * (lane + 1)] = my_s;
-                    if (lane == position)
-                        entries_d[position] = d, entries_s[slot_pitch * position] = s;
-                    // the new k-th best: the newcomer if it went last, else what was second to last
-                    const std::uint32_t new_last = grown - 1;
-                    const float shifted = __shfl(my_d, (int)(new_last ? new_last - 1 : 0), 64);
-                    const float kth = position == new_last ? d : shifted;
-                    if (lane == 0) {
-                        top_n[i] = grown;
-                        if (grown == wanted) { // k rows at most this far exist: no partition needs anything farther for this query
-                            limit[i] = kth;
-                            atomicMin(shared_bounds + first_query + i, ordered_bits(kth));
-                        }
-                    }
-                    // this wave's next insert into the list reads these cells
-                    if constexpr (lds_lists_ak) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-                    } else {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    }
+                    const float d = closing_distance<metric_ak, scalar_ak>(sum, lds_read(norms_q + i), source_b2);
+                    offer(i, s, d);
                 }
             }
         }
+    };
+
+    /**
+     *  The fold of f16 cos / ip with the thresholds INSIDE the sums. The test "may this sum enter its query's list" is
+     *  Σab ≥ threshold(query) · √Σb²(row) (ip: · 1): one more step of the summation with −threshold in the query operand and √Σb² in
+     *  the row operand — eight MFMAs per tile and wave next to the 384 of the product — leaves Σab − threshold·√Σb² in the
+     *  accumulators, and a block of 32 × 32 sums is tested by the maximum of a lane's sixteen (eight three-way maxima) and ONE
+     *  compare; the general fold spends 16 multiply-adds per block on the same question, and a threshold refresh per REGISTER where
+     *  this one has it per LANE (a lane ↔ a query in the operand layout). The vector ALU was what the epilogue cost
+     *  (profiles/r05_exact: 33 of 174 ms, 28 of them the per-block tests). Both factors are rounded to f16; the threshold is
+     *  loosened by 2⁻⁹ of itself first, which covers the two roundings (2⁻¹¹ each) whatever the signs: the test stays conservative.
+     *  A sum that passes gets what was put in taken out again (Σab = sum + threshold₁₆·norm₁₆, the product exact in f32) and goes
+     *  through the closing arithmetic and the list as in the general fold. Rows whose norm f16 cannot carry (zero, < 2⁻¹², > 60 000)
+     *  get a zero in the operand and always pass. Returns false — nothing touched — while a query of the wave has no finite
+     *  threshold yet (its list and everybody else's still filling: the first tile of a launch; a query of zero norm): the general
+     *  fold takes the tile.
+     */
+    auto fold_tile_fused = [&]() -> bool {
+        const std::uint64_t tile_row = first_row + (std::uint64_t)work_tile * wide_rows_k;
+        // (the lane number through an opaque move: what is computed from it here is computed HERE, not hoisted out of the chunk loop
+        // into registers that the loop then has to spill — a spill's reload waits for every fill in flight)
+        std::uint32_t lane_here = lane;
+        asm volatile("" : "+v"(lane_here));
+        const std::uint32_t my_query = wave * 32 + (lane_here & 31);
+        std::uint32_t shared_bits, own_bits, root_bits;
+        {
+            const std::uint32_t shared_cell = lds_base + (std::uint32_t)((std::uint8_t*)(others + (work_tile & 1u) * 512 + wave * 64 + (lane_here & 31)) - lds);
+            const std::uint32_t own_cell = lds_base + (std::uint32_t)((std::uint8_t*)(limit + my_query) - lds);
+            const std::uint32_t root_cell = lds_base + (std::uint32_t)((std::uint8_t*)(roots_q + my_query) - lds);
+            asm volatile("ds_read_b32 %0, %3\n\t"
+                         "ds_read_b32 %1, %4\n\t"
+                         "ds_read_b32 %2, %5\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(shared_bits), "=&v"(own_bits), "=&v"(root_bits)
+                         : "v"(shared_cell), "v"(own_cell), "v"(root_cell));
+        }
+        const float other = from_ordered_bits(shared_bits), own = __builtin_bit_cast(float, own_bits);
+        const float my_bound = other < own ? other : own; // a NaN ("nothing published") keeps our own
+        float my_threshold = metric_ak == metric_cos_k ? (1.f - (my_bound + 1e-5f)) * __builtin_bit_cast(float, root_bits) : 1.f - my_bound;
+        my_threshold -= __builtin_fabsf(my_threshold) * 0x1p-9f;                                  // room for the two roundings
+        my_threshold = __builtin_fabsf(my_threshold) < 0x1p-13f ? -0x1p-13f : my_threshold;       // clear of f16's subnormals
+        my_threshold = first_query + my_query < query_count ? my_threshold : 60000.f;            // a query outside the batch: never
+        if (__ballot(!(__builtin_fabsf(my_threshold) <= 60000.f))) // infinite, a NaN, or beyond f16
+            return false;
+        const _Float16 threshold16 = (_Float16)my_threshold;
+        {
+            const float put_in = (float)threshold16;
+            const std::uint32_t cell = lds_base + (std::uint32_t)((std::uint8_t*)(folded + my_query) - lds);
+            asm volatile("ds_write_b32 %0, %1" : : "v"(cell), "v"(put_in) : "memory");
+        }
+        const std::uint32_t low_half = lane_here < 32 ? 0xFFFFu : 0u; // element 0 of the summation step lives in lanes 0 … 31
+        const u32x4_t query_operand = {((std::uint32_t)__builtin_bit_cast(std::uint16_t, threshold16) ^ 0x8000u) & low_half, 0u, 0u, 0u};
+        std::uint32_t tile_b2[wide_blocks_k] = {};
+        if constexpr (metric_ak == metric_cos_k) {
+            const std::uint32_t tile_norms = lds_base + (std::uint32_t)((std::uint8_t*)(norms_r + (work_tile & 1u) * wide_rows_k + (lane_here & 31)) - lds);
+            asm volatile("ds_read_b32 %0, %8\n\t"
+                         "ds_read_b32 %1, %8 offset:128\n\t"
+                         "ds_read_b32 %2, %8 offset:256\n\t"
+                         "ds_read_b32 %3, %8 offset:384\n\t"
+                         "ds_read_b32 %4, %8 offset:512\n\t"
+                         "ds_read_b32 %5, %8 offset:640\n\t"
+                         "ds_read_b32 %6, %8 offset:768\n\t"
+                         "ds_read_b32 %7, %8 offset:896\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(tile_b2[0]), "=&v"(tile_b2[1]), "=&v"(tile_b2[2]), "=&v"(tile_b2[3]), "=&v"(tile_b2[4]), "=&v"(tile_b2[5]),
+                           "=&v"(tile_b2[6]), "=&v"(tile_b2[7])
+                         : "v"(tile_norms));
+        }
+        float put_in_row[wide_blocks_k]; // the f16 norm that went into the row operand, as a float (0: a row that always passes)
+        std::uint32_t forced = 0;        // bit u: this lane's row of block u always passes
+#pragma unroll
+        for (int u = 0; u < wide_blocks_k; ++u) {
+            float norm = 1.f;
+            if constexpr (metric_ak == metric_cos_k) {
+                norm = __builtin_sqrtf(__builtin_bit_cast(float, tile_b2[u]));
+                const bool carried = norm >= 0x1p-12f && norm <= 60000.f;
+                forced |= (carried ? 0u : 1u) << u;
+                norm = carried ? norm : 0.f;
+            }
+            const _Float16 norm16 = (_Float16)norm;
+            put_in_row[u] = (float)norm16;
+            const u32x4_t row_operand = {(std::uint32_t)__builtin_bit_cast(std::uint16_t, norm16) & low_half, 0u, 0u, 0u};
+            acc[u] = multiply<scalar_ak>(__builtin_bit_cast(uint4, query_operand), __builtin_bit_cast(uint4, row_operand), acc[u]);
+        }
+        const bool check_members = ix.has_tombstones || allow_bits != nullptr;
+#pragma unroll
+        for (int u = 0; u < wide_blocks_k; ++u) {
+            const std::uint64_t my_row = tile_row + u * 32 + (lane_here & 31);
+            bool live = my_row < last_row;
+            if (check_members) {
+                if (ix.has_tombstones && live)
+                    live = ix.keys[my_row] != free_key_k;
+                if (allow_bits && live) // the caller's predicate, one bit per slot (index.hpp:4260-4263)
+                    live = ((allow_bits[my_row >> 5] >> (my_row & 31)) & 1u) != 0;
+            }
+            const bool always = (forced >> u) & 1u;
+            const float m = __builtin_fmaxf(
+                __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(acc[u][0], acc[u][1]), __builtin_fmaxf(acc[u][2], acc[u][3])),
+                                __builtin_fmaxf(__builtin_fmaxf(acc[u][4], acc[u][5]), __builtin_fmaxf(acc[u][6], acc[u][7]))),
+                __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(acc[u][8], acc[u][9]), __builtin_fmaxf(acc[u][10], acc[u][11])),
+                                __builtin_fmaxf(__builtin_fmaxf(acc[u][12], acc[u][13]), __builtin_fmaxf(acc[u][14], acc[u][15]))));
+            if (__ballot((!(m < 0.f) || always) && live) == 0 || (knock & 64u))
+                continue;
+            // ---- the rare path, lane-parallel up to the list: every lane with a sum that passed takes what was put in out again,
+            //      closes the distance and holds it against its query's limit — all of them at once, a round per passed sum of a
+            //      lane (seldom a second one) — and only what is still in the running goes to the lists, one insert at a time
+            std::uint32_t may = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                may |= ((!(acc[u][r] < 0.f) || always) ? 1u : 0u) << r;
+            may = live ? may & exists : 0u;
+            while (__ballot(may != 0u)) {
+                const bool candidate = may != 0u;
+                const std::uint32_t r = candidate ? (std::uint32_t)__builtin_ctz(may) : 0u;
+                may &= may - 1u;
+                float sum = acc[u][0];
+#pragma unroll
+                for (int rr = 1; rr < 16; ++rr)
+                    sum = r == (std::uint32_t)rr ? acc[u][rr] : sum;
+                const std::uint32_t i = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane_here >> 5);
+                std::uint32_t put_in_bits, norm_bits, limit_bits;
+                asm volatile("ds_read_b32 %0, %3\n\t"
+                             "ds_read_b32 %1, %4\n\t"
+                             "ds_read_b32 %2, %5\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(put_in_bits), "=&v"(norm_bits), "=&v"(limit_bits)
+                             : "v"(lds_address(folded + i)), "v"(lds_address(norms_q + i)), "v"(lds_address(limit + i))
+                             : "memory");
+                sum = __builtin_fmaf(__builtin_bit_cast(float, put_in_bits), put_in_row[u], sum); // Σab again
+                const float d = closing_distance<metric_ak, scalar_ak>(sum, norm_bits, tile_b2[u]);
+                std::uint64_t pending = __ballot(candidate && !(d > __builtin_bit_cast(float, limit_bits)));
+                while (pending) {
+                    const std::uint32_t source = (std::uint32_t)__ffsll((long long)pending) - 1;
+                    pending &= pending - 1;
+                    offer((std::uint32_t)__shfl((int)i, (int)source, 64), (std::uint32_t)(tile_row + u * 32 + (source & 31)),
+                          __shfl(d, (int)source, 64));
+                }
+            }
+        }
+        return true;
     };
 
     // ---- the pipeline: chunk c is multiplied out of buffer c & 1 while the DMA fills the other buffer with chunk c + 1. A wave
@@ -859,8 +1040,24 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
             multiply_chunk(std::false_type{}, c & 1u, filling, (c + 1) & 1u);
         UA_PHASE_TICK(0)
         if (++work_chunk == chunks) {
-            if (!(knock & 1u))
-                fold_tile();
+            if (!(knock & 1u)) {
+                // the fold is vector-ALU work: above the multiply's priority, so that a wave that folds while its SIMD's other wave
+                // still multiplies gets its instructions through (a matrix instruction wants one issue slot in 32 cycles) instead
+                // of waiting for the other's stream to dry up — the two then fold one after the other, not both at the end
+                if (knock & 128u)
+                    __builtin_amdgcn_s_setprio(3);
+                bool folded_already = false;
+                if constexpr (scalar_ak == scalar_f16_k && (metric_ak == metric_cos_k || metric_ak == metric_ip_k))
+                    folded_already = !(knock & 32u) && fold_tile_fused();
+#ifdef USEARCH_AMD_EXACT_PHASES
+                if (thread == 0)
+                    atomicAdd(exact_phase_ticks + (folded_already ? 5 : 6), 1ull); // tiles the fused / the general fold took
+#endif
+                if (!folded_already)
+                    fold_tile();
+                if (knock & 128u)
+                    __builtin_amdgcn_s_setprio(0);
+            }
             work_chunk = 0, ++work_tile;
         }
         UA_PHASE_TICK(1)
@@ -1120,7 +1317,7 @@ const char* exact_search_tiled_device(metric_kind_t metric, scalar_kind_t scalar
         UA_HIP(hipMemcpyFromSymbol(ticks, HIP_SYMBOL(exact_phase_ticks), sizeof(ticks)));
         const double chunks_done = (double)std::max<unsigned long long>(ticks[4], 1);
         std::fprintf(stderr, "[usearch_amd] exact phases, shader-clock ticks per chunk (wave 0 of every workgroup): multiply %.0f fold %.0f "
-                             "own fills %.0f barrier %.0f\n", ticks[0] / chunks_done, ticks[1] / chunks_done, ticks[2] / chunks_done, ticks[3] / chunks_done);
+                             "own fills %.0f barrier %.0f; tiles folded with the thresholds inside the sums %llu, by the general fold %llu\n", ticks[0] / chunks_done, ticks[1] / chunks_done, ticks[2] / chunks_done, ticks[3] / chunks_done, ticks[5], ticks[6]);
         unsigned long long zeros[8] = {0};
         UA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(exact_phase_ticks), zeros, sizeof(zeros)));
     }
