@@ -607,45 +607,65 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
     /// Multiplies the chunk in `buffer`; with `filling`, the next chunk goes into `target` meanwhile, a part of its fills behind each
     /// step's MFMAs. `fresh` (a tile's first chunk): the first step's MFMAs take a literal zero as their addend — the accumulators
     /// are never cleared by moves.
-    auto multiply_chunk = [&](auto fresh_tag, std::uint32_t buffer, bool filling, std::uint32_t target) {
+    ///
+    /// The workgroup's rendezvous sits in the MIDDLE of a chunk's last step. Once a wave's last fragment reads of the buffer have
+    /// landed (the wait in front of the step's second half) it has no business left with the buffer: it waits for its own fills of
+    /// the next chunk and meets the others there, the step's last four MFMAs still to come — their operands are in registers. On
+    /// the far side of the barrier (the top of the next call, `fresh` = false) it first requests the next chunk's first fragments,
+    /// then issues those four MFMAs, and the requests fly meanwhile. Before (all of a chunk, barrier, requests) every chunk opened
+    /// with eight waves waiting for their first LDS reads and the matrix pipes empty. A tile's LAST chunk is finished in place — the
+    /// fold needs the sums, and it has to stay in front of the barrier (behind it, a fast wave's next tile head would land on the
+    /// Σb² a slow wave's fold is still reading) — so a tile's first chunk (`fresh`) has nothing deferred to issue.
+    /// What crosses the barrier and the loop's back-edge are five LANDED fragments (`a_odd`, `h0` … `h3`); a register with a read
+    /// still in flight never leaves a straight run of these statements — the compiler knows nothing of the read behind an asm
+    /// statement's output and is free to copy or spill such a register anywhere else (it did: results went wrong).
+    u32x4_t a_odd, h0, h1, h2, h3;
+    auto multiply_chunk = [&](auto fresh_tag, std::uint32_t buffer, bool filling, std::uint32_t target, bool last_of_tile) {
         constexpr bool fresh = decltype(fresh_tag)::value;
         const accumulator_t zero = {};
         const std::uint32_t buffer_bytes = buffer * wide_stage_bytes_k;
-        u32x4_t a_even, a_odd, l0, l1, l2, l3, h0, h1, h2, h3;
-        UA_REQUEST_QUERY(a_even, 0)
-        UA_REQUEST_ROWS(l0, l1, l2, l3, 0, 0)
-        UA_REQUEST_ROWS(h0, h1, h2, h3, 4, 0)
+        u32x4_t a_even, l0, l1, l2, l3;
         __builtin_amdgcn_s_setprio(1);
-#define UA_STEP(a_now, a_next, step, has_next, fill_statement)                                                                         \
+#define UA_LOW_HALF(a_now, step)                                                                                                       \
         UA_AWAIT(4, a_now, l0, l1, l2, l3) /* the query fragment and the low half are there; the high half may be in flight */       \
         acc[0] = product(a_now, l0, fresh && (step) == 0 ? zero : acc[0]);                                                             \
         acc[1] = product(a_now, l1, fresh && (step) == 0 ? zero : acc[1]);                                                             \
         acc[2] = product(a_now, l2, fresh && (step) == 0 ? zero : acc[2]);                                                             \
-        acc[3] = product(a_now, l3, fresh && (step) == 0 ? zero : acc[3]);                                                             \
-        if (has_next) {                                                                                                                \
-            UA_REQUEST_QUERY(a_next, (step) + 1)                                                                                       \
-            UA_REQUEST_ROWS(l0, l1, l2, l3, 0, (step) + 1)                                                                             \
-            UA_AWAIT(5, a_now, h0, h1, h2, h3) /* the high half is there; the five just requested may be in flight */                  \
-        } else {                                                                                                                       \
-            UA_AWAIT(0, a_now, h0, h1, h2, h3)                                                                                         \
-        }                                                                                                                              \
-        acc[4] = product(a_now, h0, fresh && (step) == 0 ? zero : acc[4]);                                                             \
-        acc[5] = product(a_now, h1, fresh && (step) == 0 ? zero : acc[5]);                                                             \
-        acc[6] = product(a_now, h2, fresh && (step) == 0 ? zero : acc[6]);                                                             \
-        acc[7] = product(a_now, h3, fresh && (step) == 0 ? zero : acc[7]);                                                             \
-        if (has_next) {                                                                                                                \
-            UA_REQUEST_ROWS(h0, h1, h2, h3, 4, (step) + 1)                                                                             \
-        }                                                                                                                              \
+        acc[3] = product(a_now, l3, fresh && (step) == 0 ? zero : acc[3]);
+#define UA_HIGH_HALF(a_now, first_of_tile)                                                                                             \
+        acc[4] = product(a_now, h0, (first_of_tile) ? zero : acc[4]);                                                                  \
+        acc[5] = product(a_now, h1, (first_of_tile) ? zero : acc[5]);                                                                  \
+        acc[6] = product(a_now, h2, (first_of_tile) ? zero : acc[6]);                                                                  \
+        acc[7] = product(a_now, h3, (first_of_tile) ? zero : acc[7]);
+#define UA_STEP(a_now, a_next, step, fill_statement)                                                                                   \
+        UA_LOW_HALF(a_now, step)                                                                                                       \
+        UA_REQUEST_QUERY(a_next, (step) + 1)                                                                                           \
+        UA_REQUEST_ROWS(l0, l1, l2, l3, 0, (step) + 1)                                                                                 \
+        UA_AWAIT(5, a_now, h0, h1, h2, h3) /* the high half is there; the five just requested may be in flight */                      \
+        UA_HIGH_HALF(a_now, fresh && (step) == 0)                                                                                      \
+        UA_REQUEST_ROWS(h0, h1, h2, h3, 4, (step) + 1)                                                                                 \
         if (filling) {                                                                                                                 \
             fill_statement;                                                                                                            \
         }
-        // the dataset rows first — they come from HBM, the queries from L2 — and nothing behind the last step: what is issued there
-        // has the whole fold to land, not just the wait in front of the barrier
-        UA_STEP(a_even, a_odd, 0, true, fill_rows(target, 0); fill_rows(target, 2))
-        UA_STEP(a_odd, a_even, 1, true, fill_queries(target, 0))
-        UA_STEP(a_even, a_odd, 2, true, fill_queries(target, 2); fill_tile_head_and_advance())
-        UA_STEP(a_odd, a_even, 3, false, (void)0)
+        UA_REQUEST_QUERY(a_even, 0)
+        UA_REQUEST_ROWS(l0, l1, l2, l3, 0, 0)
+        if constexpr (!fresh) { // what the chunk before left for this side of the barrier
+            UA_HIGH_HALF(a_odd, false)
+        }
+        UA_REQUEST_ROWS(h0, h1, h2, h3, 4, 0)
+        // the dataset rows first — they come from HBM, the queries from L2 — and nothing behind the third step: the wave waits for
+        // its fills in the middle of the fourth
+        UA_STEP(a_even, a_odd, 0, fill_rows(target, 0); fill_rows(target, 2))
+        UA_STEP(a_odd, a_even, 1, fill_queries(target, 0))
+        UA_STEP(a_even, a_odd, 2, fill_queries(target, 2); fill_tile_head_and_advance())
+        UA_LOW_HALF(a_odd, 3)
+        UA_AWAIT(0, a_odd, h0, h1, h2, h3) // every read this wave makes of the buffer has landed
+        if (last_of_tile) {
+            UA_HIGH_HALF(a_odd, false)
+        }
 #undef UA_STEP
+#undef UA_LOW_HALF
+#undef UA_HIGH_HALF
         __builtin_amdgcn_s_setprio(0);
     };
 #undef UA_REQUEST_QUERY
@@ -685,7 +705,12 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
             const std::uint32_t read_d = lds_read(entries_d + entry), read_s = lds_read(entries_s + entry);
             my_d = mine ? __builtin_bit_cast(float, read_d) : 0.f, my_s = mine ? read_s : 0u;
         } else if (mine) {
-            my_d = entries_d[lane], my_s = entries_s[slot_pitch * lane];
+            // past the compute unit's vector cache: this wave's own stores of the insert before went THROUGH that cache to L2, and a
+            // line it still holds from the read before that is stale (the fills that stream through the cache used to push such
+            // lines out before the next insert came; with the rendezvous moved they no longer do)
+            my_d = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<std::uint32_t*>(entries_d) + lane, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT));
+            my_s = __hip_atomic_load(entries_s + slot_pitch * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (size == wanted) { // full: the newcomer has to beat the last entry
             const float last_d = __shfl(my_d, (int)(size - 1), 64);
@@ -1033,19 +1058,15 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
     std::uint64_t phase_ticks[4] = {0, 0, 0, 0}, phase_mark = __builtin_amdgcn_s_memtime();
 #endif
     for (std::uint32_t c = 0; c < total; ++c) {
-        const bool filling = c + 1 < total && !(knock & 2u);
+        const bool more = c + 1 < total, filling = more && !(knock & 2u);
+        const bool last_of_tile = work_chunk + 1 == chunks;
         if (work_chunk == 0)
-            multiply_chunk(std::true_type{}, c & 1u, filling, (c + 1) & 1u);
+            multiply_chunk(std::true_type{}, c & 1u, filling, (c + 1) & 1u, last_of_tile);
         else
-            multiply_chunk(std::false_type{}, c & 1u, filling, (c + 1) & 1u);
+            multiply_chunk(std::false_type{}, c & 1u, filling, (c + 1) & 1u, last_of_tile);
         UA_PHASE_TICK(0)
         if (++work_chunk == chunks) {
             if (!(knock & 1u)) {
-                // the fold is vector-ALU work: above the multiply's priority, so that a wave that folds while its SIMD's other wave
-                // still multiplies gets its instructions through (a matrix instruction wants one issue slot in 32 cycles) instead
-                // of waiting for the other's stream to dry up — the two then fold one after the other, not both at the end
-                if (knock & 128u)
-                    __builtin_amdgcn_s_setprio(3);
                 bool folded_already = false;
                 if constexpr (scalar_ak == scalar_f16_k && (metric_ak == metric_cos_k || metric_ak == metric_ip_k))
                     folded_already = !(knock & 32u) && fold_tile_fused();
@@ -1055,14 +1076,12 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
 #endif
                 if (!folded_already)
                     fold_tile();
-                if (knock & 128u)
-                    __builtin_amdgcn_s_setprio(0);
             }
             work_chunk = 0, ++work_tile;
         }
         UA_PHASE_TICK(1)
         if (!(knock & 4u)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's share of the next chunk is in LDS
             UA_PHASE_TICK(2)
             __builtin_amdgcn_s_barrier();
         }
