@@ -509,6 +509,11 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
     const __amdgpu_buffer_rsrc_t query_resource = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<std::uint8_t*>(padded_queries + (std::uint64_t)first_query * padded_stride), 0, (int)(wide_queries_k * query_stride),
         resource_flags);
+    // (the two pass strides as scalars the compiler cannot re-derive from the kernel's arguments: short of scalar registers it
+    // would otherwise RE-LOAD an argument in the middle of a chunk, and the wait for that load — the counter it shares with LDS —
+    // sits out the fragment reads in flight)
+    std::uint32_t query_pass_bytes = 64u * query_stride, row_pass_bytes = 64u * row_stride;
+    asm volatile("" : "+s"(query_pass_bytes), "+s"(row_pass_bytes));
     const std::uint32_t query_offset = fill_row * query_stride + fill_piece * 16; // + (64·pass rows + the chunk) in the scalar offset
     const std::uint32_t row_offset = fill_row * row_stride + fill_piece * 16;
     const bool ragged = row_bytes % chunk_bytes_k != 0; // the last chunk of a row ends before 128 bytes
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
         for (int pass = first_pass; pass < first_pass + 2; ++pass)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(query_resource, (lds_bytes_t)(stage + (pass * 64 + wave * 8) * chunk_bytes_k), 16,
                                                      (int)query_offset,
-                                                     (int)__builtin_amdgcn_readfirstlane(pass * 64 * query_stride + fetch_chunk * chunk_bytes_k), 0, 0);
+                                                     (int)__builtin_amdgcn_readfirstlane(pass * query_pass_bytes + fetch_chunk * chunk_bytes_k), 0, 0);
     };
     auto fill_rows = [&](std::uint32_t buffer, int first_pass) { // two of the four row passes
         std::uint8_t* stage = lds + buffer * wide_stage_bytes_k;
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
         for (int pass = first_pass; pass < first_pass + 2; ++pass)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(row_resource, (lds_bytes_t)(stage + (wide_queries_k + pass * 64 + wave * 8) * chunk_bytes_k),
                                                      16, (int)offset,
-                                                     (int)__builtin_amdgcn_readfirstlane(pass * 64 * row_stride + fetch_chunk * chunk_bytes_k), 0, 0);
+                                                     (int)__builtin_amdgcn_readfirstlane(pass * row_pass_bytes + fetch_chunk * chunk_bytes_k), 0, 0);
     };
     auto fill_tile_head_and_advance = [&]() {
         if (fetch_chunk == 0) { // this wave's 32 queries' shared bounds as they stand now (lanes 32 … 63 repeat them), same DMA
@@ -974,7 +979,7 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
         for (int u = 0; u < wide_blocks_k; ++u) {
             float norm = 1.f;
             if constexpr (metric_ak == metric_cos_k) {
-                norm = __builtin_sqrtf(__builtin_bit_cast(float, tile_b2[u]));
+                norm = __builtin_amdgcn_sqrtf(__builtin_bit_cast(float, tile_b2[u])); // the bare instruction (1 ulp): the margin is 2⁻⁹
                 const bool carried = norm >= 0x1p-12f && norm <= 60000.f;
                 forced |= (carried ? 0u : 1u) << u;
                 norm = carried ? norm : 0.f;
@@ -985,10 +990,12 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
             acc[u] = multiply<scalar_ak>(__builtin_bit_cast(uint4, query_operand), __builtin_bit_cast(uint4, row_operand), acc[u]);
         }
         const bool check_members = ix.has_tombstones || allow_bits != nullptr;
+        // rows of the tile that exist: 256 but for a partition's last tile (one 32-bit compare per block instead of a 64-bit one)
+        const std::uint32_t rows_here = last_row - tile_row < wide_rows_k ? (std::uint32_t)(last_row - tile_row) : (std::uint32_t)wide_rows_k;
 #pragma unroll
         for (int u = 0; u < wide_blocks_k; ++u) {
             const std::uint64_t my_row = tile_row + u * 32 + (lane_here & 31);
-            bool live = my_row < last_row;
+            bool live = u * 32 + (lane_here & 31) < rows_here;
             if (check_members) {
                 if (ix.has_tombstones && live)
                     live = ix.keys[my_row] != free_key_k;
