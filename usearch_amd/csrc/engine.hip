@@ -20,6 +20,21 @@
 
 namespace usearch_amd {
 
+/// Experiment switch of round 5 (profiles/r05_short_rows/): the block of per-wave visited-set slabs in another kind of device memory —
+/// USEARCH_AMD_SCRATCH_MEMORY = 1: `hipDeviceMallocUncached`, 2: `hipDeviceMallocFinegrained` — to see whether the two-microsecond
+/// trip of a probe (a compare-and-swap executed at the memory side) belongs to the memory type. Default: `block_malloc`.
+static hipError_t scratch_malloc(void** out, std::size_t bytes) {
+    const std::size_t kind = env_size("USEARCH_AMD_SCRATCH_MEMORY", 0);
+    if (kind == 1 || kind == 2) {
+        const hipError_t e = hipExtMallocWithFlags(out, bytes, kind == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
+        if (e == hipSuccess)
+            return e;
+        (void)hipGetLastError();
+    }
+    return block_malloc(out, bytes);
+}
+
+
 
 void row_geometry(std::size_t bytes, std::uint32_t& lanes, std::uint32_t& row_stride, std::uint32_t& chunks) {
     // lanes per row (G): the smallest power of two covering the row's 16-byte chunks, at most 8 (= one 128-byte line per
@@ -130,7 +145,7 @@ const char* workspace_t::reserve(std::size_t queries_wanted, std::size_t scratch
             placed_free(d_scratch);
         d_scratch = nullptr;
         scratch_bytes = 0;
-        UA_HIP(block_malloc((void**)&d_scratch, scratch_wanted)); // big blocks for chip-filling launches are drawn by run_ladder
+        UA_HIP(scratch_malloc((void**)&d_scratch, scratch_wanted)); // big blocks for chip-filling launches are drawn by run_ladder
         scratch_bytes = scratch_wanted;
     }
     return nullptr;
@@ -1022,7 +1037,7 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
                 std::fprintf(stderr, " ms\n");
             }
             for (; drawn < scratch_draws && !failure; ++drawn) {
-                if (block_malloc(&candidates[drawn], slab * grid) != hipSuccess) {
+                if (scratch_malloc(&candidates[drawn], slab * grid) != hipSuccess) {
                     (void)hipGetLastError();
                     candidates[drawn] = nullptr;
                     break;
