@@ -131,7 +131,7 @@ const char* snapshot_t::grow_for_build(std::uint64_t capacity, std::uint64_t lis
         void* fresh = nullptr;
         if (array.pointer == &d_vectors_) { // the matrix the walk gathers rows from (placement.hpp)
             UA_HIP(placed_malloc(&fresh, array.new_bytes, row_stride, &placement_));
-            placement_trials_left_ = placement_max_draws_k, placement_losses_ = 0; // a new matrix: its placement is judged anew
+            placement_trials_left_ = placement_max_draws_k, placement_losses_ = 0, placement_last_ef_ = 0, placement_reopens_ = 0; // a new matrix: its placement is judged anew
             vectors_bytes_ = array.new_bytes;
         } else if (array.pointer == &d_nbr0_) {
             UA_HIP(placed_malloc(&fresh, array.new_bytes, (std::size_t)m0 * 4, nullptr));

@@ -1074,7 +1074,13 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         // ---- the matrix of stored rows: up to `placement_max_draws_k` trials over the first launches that fill the chip, judged like
         //      the scratch block — by this launch's own first queries at the caller's expansion (placement.hpp)
         const std::uint32_t matrix_draws = (std::uint32_t)std::min<std::size_t>(placement_max_draws_k, env_size("USEARCH_AMD_PLACEMENT_DRAWS", placement_max_draws_k));
-        if (placement_trials_left_ && matrix_draws > 1 && placement_.draws < matrix_draws && call.passes == 0 && !call.have_todo &&
+        // A host that tunes its expansion walks up through the regimes (bench.py's recall sweep: 64, 96, 128 … 608): trials judged at a
+        // small expansion — differences of hundredths of a millisecond — must not be the last word for launches several times as
+        // wide. A launch more than twice as wide as the last trial's reopens a search that has ended, for three trials, twice at most.
+        if (!placement_trials_left_ && matrix_draws > 1 && placement_reopens_ < 2 && placement_last_ef_ &&
+            call.ef > 2u * placement_last_ef_ && call.passes == 0 && !call.have_todo && pending >= 2ull * grid)
+            placement_trials_left_ = 3, placement_losses_ = 0, ++placement_reopens_;
+        if (placement_trials_left_ && matrix_draws > 1 && placement_.draws < matrix_draws + 3u * placement_reopens_ && call.passes == 0 && !call.have_todo &&
             !params.team && pending >= 2ull * grid && grid >= 2u * (std::uint32_t)compute_units_ && !view_.nbr0_rows && d_vectors_ &&
             vectors_bytes_ >= env_size("USEARCH_AMD_PLACEMENT_MIN_BYTES", (std::size_t)1 << 30) && !args.query_ids && !args.allow_bits &&
             !args.descent_only && !args.beam_level && !env_size("USEARCH_AMD_SCRATCH_REDRAW", 0)) {
@@ -1089,6 +1095,7 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
                 return hip_message(created);
             }
             args.count = grid; // one query per wave: the launch's steady state; their results are computed again by the launch proper
+            placement_last_ef_ = call.ef;
             const char* failure = try_matrix_placement(
                 [&](const snapshot_view_t& view, float& ms) -> const char* {
                     hipError_t e = hipMemsetAsync(ws.d_queue, 0, 8, stream);

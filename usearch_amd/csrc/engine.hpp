@@ -283,6 +283,7 @@ class snapshot_t {
     placement_t placement_{};
     std::uint32_t placement_trials_left_ = placement_max_draws_k; ///< trials `try_matrix_placement` may still make
     std::uint32_t placement_losses_ = 0;                          ///< trials in a row the incumbent has won
+    std::uint32_t placement_last_ef_ = 0, placement_reopens_ = 0; ///< the expansion of the last trial; how often a wider regime reopened the search
     bool placing_ = false;            ///< a trial owns the matrix: `take` waits (guarded by pool_mutex_)
     std::size_t vectors_bytes_ = 0;   ///< bytes allocated behind d_vectors_
     int compute_units_ = 256;
