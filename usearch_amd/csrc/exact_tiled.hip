@@ -624,18 +624,6 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
     /// What crosses the barrier and the loop's back-edge are five LANDED fragments (`a_odd`, `h0` … `h3`); a register with a read
     /// still in flight never leaves a straight run of these statements — the compiler knows nothing of the read behind an asm
     /// statement's output and is free to copy or spill such a register anywhere else (it did: results went wrong).
-    // The product build has NO branch in the multiply but the tile's last half-step: the fills never stop (a workgroup's last chunk
-    // fetches a tile past its partition's end — an empty resource, zeros — and the queries' first chunk once more, into the buffer
-    // nobody reads again), and the knock-outs that sit in the loop exist in the diagnostic build only (`-DUSEARCH_AMD_EXACT_KNOCKOUTS`,
-    // scripts/exact_knockout.py). Every branch ends a basic block, and the compiler schedules MFMAs, fragment requests and fills
-    // inside one: nine more uniform branches in this loop cost the kernel 13 % (profiles/r05_exact/README.md §2).
-#ifdef USEARCH_AMD_EXACT_KNOCKOUTS
-#define UA_IF_FILLING if (filling)
-#define UA_KNOCKED(bit) (knock & (bit))
-#else
-#define UA_IF_FILLING
-#define UA_KNOCKED(bit) false
-#endif
     u32x4_t a_odd, h0, h1, h2, h3;
     auto multiply_chunk = [&](auto fresh_tag, std::uint32_t buffer, bool filling, std::uint32_t target, bool last_of_tile) {
         constexpr bool fresh = decltype(fresh_tag)::value;
@@ -661,7 +649,7 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
         UA_AWAIT(5, a_now, h0, h1, h2, h3) /* the high half is there; the five just requested may be in flight */                      \
         UA_HIGH_HALF(a_now, fresh && (step) == 0)                                                                                      \
         UA_REQUEST_ROWS(h0, h1, h2, h3, 4, (step) + 1)                                                                                 \
-        UA_IF_FILLING {                                                                                                                \
+        if (filling) {                                                                                                                 \
             fill_statement;                                                                                                            \
         }
         UA_REQUEST_QUERY(a_even, 0)
@@ -1077,8 +1065,7 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
     std::uint64_t phase_ticks[4] = {0, 0, 0, 0}, phase_mark = __builtin_amdgcn_s_memtime();
 #endif
     for (std::uint32_t c = 0; c < total; ++c) {
-        const bool filling = c + 1 < total && !UA_KNOCKED(2u); // read by the diagnostic build only: the product build always fills
-        (void)filling;
+        const bool more = c + 1 < total, filling = more && !(knock & 2u);
         const bool last_of_tile = work_chunk + 1 == chunks;
         if (work_chunk == 0)
             multiply_chunk(std::true_type{}, c & 1u, filling, (c + 1) & 1u, last_of_tile);
@@ -1100,7 +1087,7 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
             work_chunk = 0, ++work_tile;
         }
         UA_PHASE_TICK(1)
-        if (!UA_KNOCKED(4u)) {
+        if (!(knock & 4u)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's share of the next chunk is in LDS
             UA_PHASE_TICK(2)
             __builtin_amdgcn_s_barrier();
