@@ -1207,10 +1207,14 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
         const uint4 empty = {none_slot_k, none_slot_k, none_slot_k, none_slot_k};
         for (std::uint32_t i = lane; i < args.hash_cap / 4; i += 64)
             cells[i] = empty;
+#ifdef USEARCH_AMD_EXPERIMENT_NO_SLAB_CLEAR_WAIT // profiles/r05_short_rows/: what a clear-free visited set could save at most in TIME — the
+        wave_sync<false>();                        // clear's stores still go out, nobody waits for them (a probe may meet an uncleared cell)
+#else
         if constexpr (mode_ak == scratch_hash_k) // the stores must have reached L2 before this wave's atomics probe the cells
             wave_sync<true>();
         else
             wave_sync<false>();
+#endif
     }
 
     std::uint32_t computed = 0, cycles = 0; // context_t counters, index.hpp:2208-2211
