@@ -694,7 +694,7 @@ def main() -> None:
     #      (read again after the timed steps: trials may still be under way during the warm-up).
     placement_policy = ("engine: scratch block drawn by run_ladder when a chip-filling launch needs a new one (<= 8 candidates timed by the "
                         "launch's first queries); matrix: one fresh device-to-device copy per chip-filling launch judged against the incumbent "
-                        "on that launch's first queries at the caller's expansion (<= 8 trials, ended by three wins of the incumbent in a row)")
+                        "on that launch's first queries at the caller's expansion (<= 8 trials, ended by three wins of the incumbent in a row; a launch more than twice as wide as the last trial's reopens the search for three more, twice at most)")
 
     # ---- warmup, then EXACTLY `steps` timed steps between barriers
     flush_native_stdio()

@@ -118,7 +118,8 @@ USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_device_bytes(usearch_amd_snapshot
  *  and hands out by rules of its own), and no synthetic probe tells the placements apart. So the first launches that fill the chip
  *  each try ONE fresh device-to-device copy of the matrix against the incumbent — both timed on that launch's own first queries at
  *  the caller's expansion — and keep the faster (csrc/placement.hpp, `snapshot_t::try_matrix_placement`; at most
- *  USEARCH_AMD_PLACEMENT_DRAWS = 8 trials, 1 = off, ended early by three wins of the incumbent in a row; arrays under
+ *  USEARCH_AMD_PLACEMENT_DRAWS = 8 trials, 1 = off, ended early by three wins of the incumbent in a row, reopened for three more —
+ *  twice at most — by a launch more than twice as wide as the last trial's: a host that tunes its expansion walks up; arrays under
  *  USEARCH_AMD_PLACEMENT_MIN_BYTES = 1 GiB stay where they are). `*draws` = trials made so far, `*kept` = how many moved the
  *  matrix, `judge_ms[i]` / `incumbent_ms[i]` = the candidate's / the incumbent's milliseconds in trial i (up to 8 each),
  *  `*probe_ms` = what the trials have cost in all. */
