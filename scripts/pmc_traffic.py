@@ -54,7 +54,9 @@ def main():
         try:
             line = json.load(open(sys.argv[4]))
             kernel = line["roofline"].get("kernel_instantiation") or kernel
-            last = int(line["steps"]) + int(line["warmup"])
+            # the timed steps alone: the engine's placement trials (judge launches of this very instantiation at this very grid) run
+            # among the warm-up launches, never among the timed ones when the warm-up is long enough (PROFILE_WARMUP)
+            last = int(line["steps"])
         except (OSError, ValueError, KeyError):
             pass
     fetch_kib, fetch_n, kernel_name = mean_counter(fetch_csv, "FETCH_SIZE", kernel, last)

@@ -20,7 +20,10 @@ if [ -z "${PROFILE_EF:-}" ]; then
 else
   EF=$PROFILE_EF   # the expansion is known (an earlier session picked it): no sweep
 fi
-QUICK="$* --expansion $EF --recall-queries 0 --no-cpu-baseline --no-stress-rows --no-host-api --no-placement-check --steps 5 --warmup 1"
+# (PROFILE_WARMUP: enough warm-up launches for the engine's placement trials — up to 8 + 3 + 3, one per chip-filling launch — to be over
+#  before the timed steps: a trial inside them would put its judge launches among "the last launches" the trace is trimmed to)
+WARMUP=${PROFILE_WARMUP:-1}
+QUICK="$* --expansion $EF --recall-queries 0 --no-cpu-baseline --no-stress-rows --no-host-api --no-placement-check --steps 5 --warmup $WARMUP"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python "$REPO/bench.py" $QUICK > "$OUT/stats_bench.json" 2> "$OUT/stats.log"
 find "$OUT/stats" -name "*kernel_stats.csv" | head -1 | while read f; do cp "$f" "$OUT/kernel_stats.csv"; done
 # the timed launches alone (the whole-process average above also covers the placement draws' candidates)
@@ -41,6 +44,6 @@ done
 rm -rf "$OUT/stats"
 python "$REPO/scripts/pmc_traffic.py" "$OUT/pmc_FETCH_SIZE.csv" "$OUT/pmc_WRITE_SIZE.csv" search_kernel "$OUT/stats_bench.json" \
     "$OUT/pmc_TCC_EA0_RDREQ_sum_TCC_EA0_RDREQ_32B_sum_.csv" "$OUT/pmc_TCC_EA0_WRREQ_sum_TCC_EA0_WRREQ_64B_sum_.csv" > "$OUT/traffic.json" && cat "$OUT/traffic.json"
-python "$REPO/bench.py" "$@" --expansion $EF --traffic-json "$OUT/traffic.json" --wave-clock > "$OUT/bench.json" 2> "$OUT/bench.log"
+python "$REPO/bench.py" "$@" --expansion $EF --traffic-json "$OUT/traffic.json" --wave-clock --warmup $WARMUP > "$OUT/bench.json" 2> "$OUT/bench.log"
 cat "$OUT/bench.json"
 du -sh "$OUT"; head -8 "$OUT/kernel_stats.csv"

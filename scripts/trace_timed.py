@@ -16,7 +16,7 @@ import sys
 def main(trace_path: str, line_path: str) -> None:
     line = json.loads(open(line_path).read().strip().splitlines()[-1])
     instantiation = line["roofline"]["kernel_instantiation"]
-    wanted = line["steps"] + line["warmup"]
+    wanted = line["steps"]  # the timed steps alone: placement trials run among the warm-up launches (see pmc_traffic.py)
     with open(trace_path, newline="") as handle:
         rows = list(csv.DictReader(handle))
     name_column = next(c for c in rows[0] if c.lower() == "kernel_name")
