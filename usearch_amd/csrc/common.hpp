@@ -140,6 +140,8 @@ struct search_args_t {
     std::uint32_t team_offset;      ///< team_search_kernel: where in the workgroup's LDS the shared `team_t` sits
     unsigned long long* wave_clock; ///< optional [grid][2] telemetry: 100-MHz wall clock at the start and the exit of every
                                     ///< persistent wave (how long the drain phase of a batch leaves the chip part-idle)
+    std::uint32_t seen_offset;      ///< short rows with the visited set in a global slab: where in the wave's LDS the `seen` cells
+    std::uint32_t seen_cells;       ///< sit, and how many (a power of two; 0 = none) — see `search_one`
 };
 
 enum : std::uint32_t { status_done_k = 0, status_overflow_k = 1 };

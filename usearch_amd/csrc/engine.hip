@@ -965,7 +965,27 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
     }
     if (call.mode != scratch_global_k) {
         // a team's workgroup carries the leader's LDS areas plus the shared block; one workgroup per query of the small batch
-        const std::uint64_t wave_lds_bytes = lds_bytes_for(call.mode, call.next_cap, call.hash_cap);
+        std::uint64_t wave_lds_bytes = lds_bytes_for(call.mode, call.next_cap, call.hash_cap);
+        // short rows over a global visited set: `seen` cells in LDS in front of it (kernels.hpp `search_one`) — as many as cost no
+        // resident wave (the walk lives on its residency), at most 2 048; USEARCH_AMD_SEEN_CELLS forces a number (0 = none)
+        args.seen_offset = 0, args.seen_cells = 0;
+        if (call.mode == scratch_hash_k && !params.team && lanes_ <= 2) {
+            const std::size_t forced = env_size("USEARCH_AMD_SEEN_CELLS", (std::size_t)-1);
+            std::uint32_t cells = 0;
+            if (forced != (std::size_t)-1) {
+                for (cells = 1; cells * 2 <= forced && cells < 8192; cells *= 2) {}
+                cells = forced ? cells : 0;
+            } else {
+                for (std::uint32_t candidate = 2048; candidate >= 128 && !cells; candidate /= 2)
+                    if (waves_for((wave_lds_bytes + 15) / 16 * 16 + candidate * 4ull) >= waves_for(wave_lds_bytes))
+                        cells = candidate;
+            }
+            if (cells && (wave_lds_bytes + 15) / 16 * 16 + cells * 4ull <= lds_budget) {
+                args.seen_offset = (std::uint32_t)((wave_lds_bytes + 15) / 16 * 16);
+                args.seen_cells = cells;
+                wave_lds_bytes = args.seen_offset + cells * 4ull;
+            }
+        }
         const std::uint64_t lds_bytes = params.team ? (wave_lds_bytes + 15) / 16 * 16 + team_bytes : wave_lds_bytes;
         args.team_offset = params.team ? (std::uint32_t)((wave_lds_bytes + 15) / 16 * 16) : 0u;
         const std::uint32_t grid = params.team ? pending

@@ -1217,6 +1217,26 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
 #endif
     }
 
+    // ---- `seen`: an exact, lossy memory of this query's probes in LDS, in front of the visited set in its global slab (short rows).
+    //      A probe of the slab is a compare-and-swap executed at the memory side, and the memory side turns over 27.5 G of them a
+    //      second whatever the number of waves, their dependence or the slabs' footprint (scripts/probes/atomic_rate_probe.hip):
+    //      the b1 walk of BASELINE's config 5 ran at 25 G. Four probes in ten ask about a slot that is already in the set — a
+    //      neighbour shared with a member expanded a few hops ago — and every slot a probe has asked about is remembered here,
+    //      direct-mapped: a lane whose slot is in its cell KNOWS the answer (visited) and skips the atomic; any other lane probes
+    //      the slab as before, which stays the authority. Same answers, fewer atomics.
+    constexpr bool seen_ak = lanes_ak <= 2 && mode_ak == scratch_hash_k && team_ak == 1;
+    std::uint32_t* seen = nullptr;
+    std::uint32_t seen_mask = 0;
+    if constexpr (seen_ak) {
+        if (args.seen_cells) {
+            seen = reinterpret_cast<std::uint32_t*>(query_lds + args.seen_offset);
+            seen_mask = args.seen_cells - 1;
+            for (std::uint32_t i = lane; i < args.seen_cells; i += 64)
+                seen[i] = none_slot_k;
+            wave_sync<false>();
+        }
+    }
+
     std::uint32_t computed = 0, cycles = 0; // context_t counters, index.hpp:2208-2211
     // `unroll_ak` carries the rows a lane group takes per round in its hundreds (search_kernel packs it that way)
     constexpr int loads_ak = unroll_ak % 100, rows_ak = unroll_ak / 100 + 1;
@@ -1579,7 +1599,15 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
             } else {
                 std::uint32_t h = hash_slot(neighbor) & visits_mask;
                 std::uint32_t old = neighbor; // an absent lane probes nothing
-                if (present)
+                bool asks = present;
+                std::uint32_t seen_cell = 0;
+                if constexpr (seen_ak) {
+                    if (seen) { // a slot this query has probed before is in the set: no atomic for it
+                        seen_cell = ((neighbor * 0x9E3779B1u) >> 9) & seen_mask;
+                        asks = present && seen[seen_cell] != neighbor;
+                    }
+                }
+                if (asks)
                     old = atomicCAS(visits + h, none_slot_k, neighbor);
                 if (!popped)
                     pop_now();
@@ -1588,6 +1616,10 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                     old = atomicCAS(visits + h, none_slot_k, neighbor);
                 }
                 fresh = present && old == none_slot_k;
+                if constexpr (seen_ak) {
+                    if (seen && asks)
+                        seen[seen_cell] = neighbor; // probed (inserted or found): in the set from now on
+                }
             }
             const std::uint64_t fresh_mask = ballot(fresh);
             tick(2);
