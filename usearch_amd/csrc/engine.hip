@@ -984,6 +984,8 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
                 args.seen_offset = (std::uint32_t)((wave_lds_bytes + 15) / 16 * 16);
                 args.seen_cells = cells;
                 wave_lds_bytes = args.seen_offset + cells * 4ull;
+                if (env_size("USEARCH_AMD_PROBE_LOAD_FIRST", 0)) // experiment switch (kernels.hpp `load_first`): rides in the offset's lowest bit
+                    args.seen_offset |= 1u;
             }
         }
         const std::uint64_t lds_bytes = params.team ? (wave_lds_bytes + 15) / 16 * 16 + team_bytes : wave_lds_bytes;

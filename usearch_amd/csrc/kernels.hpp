@@ -1229,7 +1229,7 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     std::uint32_t seen_mask = 0;
     if constexpr (seen_ak) {
         if (args.seen_cells) {
-            seen = reinterpret_cast<std::uint32_t*>(query_lds + args.seen_offset);
+            seen = reinterpret_cast<std::uint32_t*>(query_lds + (args.seen_offset & ~15u));
             seen_mask = args.seen_cells - 1;
             for (std::uint32_t i = lane; i < args.seen_cells; i += 64)
                 seen[i] = none_slot_k;
@@ -1607,13 +1607,34 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                         asks = present && seen[seen_cell] != neighbor;
                     }
                 }
-                if (asks)
-                    old = atomicCAS(visits + h, none_slot_k, neighbor);
+                // `load_first` (short rows, USEARCH_AMD_PROBE_LOAD_FIRST=1; off by default): a cell is LOADED and an atomic spent only to
+                // claim an empty one — a slot that is already in the set (four probes in ten) then costs no atomic at all, a fresh one a
+                // load and the atomic. Loads see what the memory side's compare-and-swaps wrote (scripts/probes/atomic_then_load_probe.hip),
+                // a cell never changes once it is set, and a claim that loses to another lane of the same instruction reads the winner
+                // and moves on: the same answers as probing by compare-and-swap alone.
+                bool load_first = false;
+                if constexpr (seen_ak)
+                    load_first = (args.seen_offset & 1u) != 0; // (the offset is a multiple of 16: its lowest bit carries the switch)
+                if (asks) {
+                    if (load_first) {
+                        old = __hip_atomic_load(visits + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (old == none_slot_k)
+                            old = atomicCAS(visits + h, none_slot_k, neighbor);
+                    } else {
+                        old = atomicCAS(visits + h, none_slot_k, neighbor);
+                    }
+                }
                 if (!popped)
                     pop_now();
                 while (old != none_slot_k && old != neighbor) { // linear probing, index.hpp:1085-1211
                     h = (h + 1) & visits_mask;
-                    old = atomicCAS(visits + h, none_slot_k, neighbor);
+                    if (load_first) {
+                        old = __hip_atomic_load(visits + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (old == none_slot_k)
+                            old = atomicCAS(visits + h, none_slot_k, neighbor);
+                    } else {
+                        old = atomicCAS(visits + h, none_slot_k, neighbor);
+                    }
                 }
                 fresh = present && old == none_slot_k;
                 if constexpr (seen_ak) {
