@@ -272,6 +272,47 @@ PRESETS = {
 }
 
 
+def secondary_lines(presets, timeout_seconds: float) -> list:
+    """BASELINE.json's other configurations (`PRESETS`), each run by this script in a process of its own — `python bench.py --config cN
+    --no-secondary …`: its own index at the configuration's full size, its own recall sweep, roofline and reference baseline — and
+    summarised for `config.secondary` of the default line. A configuration that fails or overruns is reported as such, never hidden."""
+    import subprocess
+    out = []
+    for name in presets:
+        command = [sys.executable, os.path.abspath(__file__), "--config", name, "--no-secondary", "--no-stress-rows", "--steps", "10",
+                   "--warmup", "2", "--cpu-seconds", "4", "--recall-queries", "2000", "--no-load-timing"]
+        t0 = time.time()
+        entry = {"preset": name, "what": PRESETS[name]["what"], "command": " ".join(["python", "bench.py"] + command[2:])}
+        try:
+            done = subprocess.run(command, capture_output=True, text=True, timeout=timeout_seconds, cwd=ROOT)
+            lines = [text for text in done.stdout.splitlines() if text.startswith("{")]
+            if done.returncode != 0 or not lines:
+                raise RuntimeError(f"exit code {done.returncode}: {done.stderr.strip().splitlines()[-1] if done.stderr.strip() else 'no output'}")
+            line = json.loads(lines[-1])
+            roofline, cpu, config = line["roofline"], line.get("cpu_baseline") or {}, line["config"]
+            entry.update({
+                "workload": config["workload"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
+                "steps": line["steps"], "dtype": line["dtype"], "expansion_search": config["expansion_search"],
+                "recall_at_k": config["recall_at_k"], "recall_ci": config["recall_ci"], "recall_queries": config["recall_queries"],
+                "index_build_seconds": config["index_build_seconds"], "kernel_passes": config["kernel_passes"],
+                "visited_set_probe": config.get("visited_set_probe"),
+                "roofline": {key: roofline.get(key) for key in ("bound", "achieved", "peak", "unit", "frac", "lines_touched_frac", "kernel",
+                                                                "kernel_ms", "kernel_instantiation", "algorithmic_bytes_per_launch",
+                                                                "kernel_ms_second_load", "traffic", "traffic_source")},
+                "cpu_baseline": {key: cpu.get(key) for key in ("value", "unit", "cores", "kind", "label_agreement_with_the_gpu",
+                                                               "ground_truth_check", "sample")}})
+        except subprocess.TimeoutExpired:
+            entry["error"] = f"no line within {timeout_seconds:.0f} s"
+        except (RuntimeError, ValueError, KeyError, OSError) as error:
+            entry["error"] = str(error)[:300]
+        entry["wall_seconds"] = round(time.time() - t0, 1)
+        log(f"[bench] secondary {name}: " + (entry.get("error") or f"{entry['value']:,.0f} {entry['unit']}, {entry['ms_per_step']:.2f} ms/step, "
+            f"frac {entry['roofline']['frac']:.3f} (whole lines {entry['roofline']['lines_touched_frac']:.3f}), recall {entry['recall_at_k']}") +
+            f" [{entry['wall_seconds']} s]")
+        out.append(entry)
+    return out
+
+
 def memory_plan(n: int, dim: int, dtype: str, connectivity: int, queries: int, k: int) -> dict:
     """HBM one rank needs for its index of `n` vectors (the flat arrays of `snapshot_view_t`), the builder's transient
     peak, and the batch — what `--dry` prints and what an N-GPU run is checked against before anything is allocated."""
@@ -419,6 +460,141 @@ def run_exact(args) -> None:
         dist.destroy_process_group()
 
 
+def join_ranks(args, on_cpu: bool = False):
+    """This process as one rank of the run: RANK / LOCAL_RANK / WORLD_SIZE from the launcher (one rank per GPU over RCCL), the process
+    group, and the preflight of an N > 1 run — N ranks on N DIFFERENT devices, the launcher's world equal to `--gpus`.
+    BENCH_REHEARSAL=1: every rank on cuda:0 with gloo collectives — the N > 1 control flow (decisions broadcast from rank 0,
+    barriers, the max over ranks, the sharded step's exchange) on a box with ONE GPU; RCCL refuses two ranks on one device, so this
+    is a rehearsal of the launcher path, never a measurement. `on_cpu` (BENCH_REHEARSAL=cpu, `rehearse_on_cpu`): no device at all."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    rehearsal = os.environ.get("BENCH_REHEARSAL") in ("1", "cpu")
+    if rehearsal:
+        local_rank = 0
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # every rank is on this box
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cpu") if on_cpu else torch.device("cuda", local_rank)
+    if not on_cpu:
+        torch.cuda.set_device(local_rank)
+    preflight = {"world": world, "devices": 1}
+    if world > 1:
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+        if on_cpu:
+            mine = (local_rank, "cpu")
+        else:
+            identity = torch.cuda.get_device_properties(device)
+            mine = (local_rank, str(getattr(identity, "uuid", "")) or f"{identity.name}#{local_rank}")
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        preflight["devices"] = len({uuid for _, uuid in everyone})
+        preflight["local_ranks"] = [r for r, _ in everyone]
+        if not rehearsal and preflight["devices"] != world:
+            raise SystemExit(f"{world} ranks share {preflight['devices']} device(s): one process per GPU is the contract")
+    return rank, world, local_rank, rehearsal, device, preflight
+
+
+def rank_zero_decides(flag: bool, rank: int, world: int, device) -> bool:
+    """Rank 0 decides, everybody follows (the recall sweep is made of collectives when the index is sharded)."""
+    if world == 1:
+        return flag
+    import torch
+    import torch.distributed as dist
+    box = torch.tensor([1 if (flag and rank == 0) else 0], device=device)
+    dist.broadcast(box, 0)
+    return bool(box.item())
+
+
+def timed_steps(step, steps: int, world: int, device) -> float:
+    """EXACTLY `steps` calls of `step(i)` between a barrier + device synchronisation on both sides; the seconds of the slowest rank."""
+    import torch
+    import torch.distributed as dist
+    on_gpu = device.type == "cuda"
+    if on_gpu:
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    if on_gpu:
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def rehearse_on_cpu(args) -> None:
+    """BENCH_REHEARSAL=cpu — the launcher path of `bench.py --gpus N --sharded` WITHOUT a GPU (tests/test_bench_helpers.py runs it with
+    two ranks every round): torch.distributed.run → `join_ranks` (gloo) → the expansion chosen by rank 0 and followed by all → warm-up →
+    `timed_steps` (barriers, max over ranks) → ONE JSON line from rank 0. Every step goes through the product's own sharded entry point
+    (`usearch_amd_sharded_search_many`: query broadcast, one packed all-gather, the merge) over the host transport; ONLY the local
+    search of a shard is a seeded stand-in, because the search itself exists on the device alone — the line says so and is not a
+    measurement of anything."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world, _, _, device, preflight = join_ranks(args, on_cpu=True)
+    from usearch_amd.sharded import Communicator
+    queries_count, wanted, stride = min(args.queries, 64), args.k, 16
+
+    def local_search(queries: np.ndarray, count: int, k: int, expansion: int):
+        rng = np.random.default_rng(int(queries.astype(np.int64).sum()) % 1000 + 17 * rank + expansion)
+        distances = np.sort(rng.integers(0, 64, size=(count, k)).astype(np.float32), axis=1)
+        keys = (rng.integers(0, args.n, size=(count, k)).astype(np.uint64) + np.uint64(rank * args.n))
+        return keys, distances, np.full(count, k, dtype=np.uint64)
+
+    communicator = Communicator.on_host(
+        rank, world,
+        lambda send, receive: dist.all_gather_into_tensor(torch.from_numpy(receive), torch.from_numpy(send)) if world > 1 else receive.__setitem__(slice(None), send),
+        lambda buffer, root: dist.broadcast(torch.from_numpy(buffer), src=root) if world > 1 else None, local_search)
+    queries = np.full((queries_count, stride), 1 + rank, dtype=np.uint8)
+    keys = np.zeros((queries_count, wanted), dtype=np.uint64)
+    distances = np.zeros((queries_count, wanted), dtype=np.float32)
+    counts = np.zeros(queries_count, dtype=np.uint64)
+    last = {}
+
+    def search_step(expansion: int):
+        last["stats"], last["step"] = communicator.search_raw(None, queries.ctypes.data, queries_count, stride, wanted, expansion, 0,
+                                                              keys.ctypes.data, distances.ctypes.data, counts.ctypes.data, 0, 0)
+
+    expansion = 0
+    for candidate in (64, 96, 128):  # the sweep's shape: every rank steps, rank 0 scores and decides, everybody follows
+        search_step(candidate)
+        expansion = candidate
+        if rank_zero_decides(candidate >= 96, rank, world, device):
+            break
+    for _ in range(args.warmup):
+        search_step(expansion)
+    elapsed = timed_steps(lambda i: search_step(expansion), args.steps, world, device)
+    if rank == 0:
+        flush_native_stdio()
+        print(json.dumps({
+            "metric": f"REHEARSAL of the launcher path, {world} rank(s) on the CPU over gloo", "value": queries_count * args.steps * world / elapsed,
+            "unit": "shard-queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "REHEARSAL on the CPU: the local search of a shard is a seeded stand-in, nothing is measured",
+            "config": {"workload": "launcher rehearsal", "parallelism": f"shards{world}", "preflight": preflight, "expansion_search": expansion,
+                       "exchange": {"transport": communicator.kind, "block_bytes": int(last["step"].block_bytes),
+                                    "gathered_bytes": int(last["step"].gathered_bytes), "exchanges_per_step": int(last["step"].exchanges)}},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main() -> None:
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -458,7 +634,16 @@ def main() -> None:
                              "roofline.traffic when it was measured with the same sources")
     parser.add_argument("--wave-clock", action="store_true", help="record the batch-tail telemetry of the timed steps")
     parser.add_argument("--no-placement-check", action="store_true",
-                        help="skip re-timing the batch with the engine's placement draws switched off (roofline.frac_first_placement)")
+                        help="skip loading the image a SECOND time after the timed steps and timing the batch on that copy "
+                             "(roofline.kernel_ms_second_load: how reproducible the settled placement is)")
+    parser.add_argument("--no-reload", action="store_true",
+                        help="search the builder's own arrays instead of the saved image loaded back through the device loader "
+                             "(the default walks what `usearch_load` would give a user: matrix placed after the settle window)")
+    parser.add_argument("--no-secondary", action="store_true",
+                        help="skip BASELINE.json's other configurations (c1, c2, c4, c5 — each in a process of its own, summarised "
+                             "under config.secondary of the default line)")
+    parser.add_argument("--secondary", default="c1,c2,c4,c5", help="which presets ride along with the default line")
+    parser.add_argument("--secondary-timeout", type=float, default=600.0, help="seconds one secondary configuration may take")
     parser.add_argument("--exact", action="store_true",
                         help="time the exact (brute-force) search of the batch through the matrix-unit kernel instead of the graph walk")
     parser.add_argument("--max-batch", type=int, default=int(os.environ.get("BENCH_MAX_BATCH", 0)),
@@ -489,6 +674,8 @@ def main() -> None:
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_with_ranks(args.gpus)
+    if os.environ.get("BENCH_REHEARSAL") == "cpu":
+        return rehearse_on_cpu(args)
     if args.exact:
         return run_exact(args)
     metric = args.metric or ("hamming" if args.dtype == "b1" else "l2sq" if args.dtype == "i8" else "cos")
@@ -499,37 +686,7 @@ def main() -> None:
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    # BENCH_REHEARSAL=1: every rank on cuda:0 with gloo collectives — the N > 1 control flow (decisions broadcast from rank 0,
-    # barriers, the max over ranks, the sharded step's exchange) on a box with ONE GPU. RCCL refuses two ranks on one device, so
-    # this is a rehearsal of the launcher path, never a measurement.
-    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local_rank = 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # every rank is on this box
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    # preflight of an N > 1 run: N ranks on N DIFFERENT devices, and the launcher's world is what `--gpus` said
-    preflight = {"world": world, "devices": 1}
-    if world > 1:
-        if world != args.gpus:
-            raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
-        identity = torch.cuda.get_device_properties(device)
-        mine = (local_rank, str(getattr(identity, "uuid", "")) or f"{identity.name}#{local_rank}")
-        everyone = [None] * world
-        dist.all_gather_object(everyone, mine)
-        preflight["devices"] = len({uuid for _, uuid in everyone})
-        preflight["local_ranks"] = [r for r, _ in everyone]
-        if not rehearsal and preflight["devices"] != world:
-            raise SystemExit(f"{world} ranks share {preflight['devices']} device(s): one process per GPU is the contract")
+    rank, world, local_rank, rehearsal, device, preflight = join_ranks(args)
 
     import usearch_amd
 
@@ -538,7 +695,7 @@ def main() -> None:
     sharded = args.sharded
     data_seed = 42 + (rank if sharded else 0)
     key_base = rank * args.n if sharded else 0
-    build_seconds, build_stats, ref_index, image, built = 0.0, None, None, None, None
+    build_seconds, build_stats, ref_index, image, built, reload_seconds = 0.0, None, None, None, None, None
     t_generate = time.time()
     if args.builder == "gpu":
         data = synthetic_vectors_device(args.n, args.dim, args.dtype, data_seed, device)
@@ -558,6 +715,28 @@ def main() -> None:
             log(f"[bench] generated {args.n}x{args.dim} {args.dtype} in HBM in {generate_seconds:.1f}s; GPU build "
                 f"{build_seconds:.1f}s ({args.n / build_seconds:,.0f} vectors/s; search {build_stats['seconds_search']:.1f}s, "
                 f"link {build_stats['seconds_link']:.1f}s, {build_stats['batches']} batches, max level {build_stats['max_level']})")
+        if not args.no_reload:
+            # What a user of the reference's API walks is a LOADED index (`usearch_load` / `usearch_view`): the image the builder
+            # saves goes back through the device loader — which places the matrix of stored rows after the settle window
+            # (csrc/placement.hpp: the driver hands freed frames back late; an array allocated once they are back lands on the
+            # frames it prefers, the fast ones, every time). The builder's own arrays were allocated next to 15 GB of generated data.
+            t1 = time.time()
+            image = built.save_buffer()
+            index = None
+            built.close()
+            built = None
+            torch.cuda.empty_cache()
+            usearch_amd.note_device_free()  # torch's blocks went back through another allocator: the loader waits for them too
+            t2 = time.time()
+            index = usearch_amd.Index.restore(image, device=local_rank)
+            torch.cuda.synchronize()
+            reload_seconds = {"save_buffer": round(t2 - t1, 2), "settle_and_load": round(time.time() - t2, 2),
+                              "settle_ms": index.placement["settle_ms"]}
+            if rank == 0:
+                log(f"[bench] image of {image.nbytes / 1e9:.1f} GB saved in {t2 - t1:.1f}s, loaded back in {time.time() - t2:.1f}s "
+                    f"(of which {index.placement['settle_ms']:.0f} ms waiting for freed frames)")
+            if world > 1 or (args.no_cpu_baseline and args.no_placement_check):
+                image = None  # only the reference leg and the second load (rank 0, N = 1) need it again
     else:
         from oracle import refbind  # the reference builds the index on the host; never on the timed GPU path
         vectors = synthetic_vectors(args.n, args.dim, args.dtype, seed=data_seed)
@@ -658,12 +837,8 @@ def main() -> None:
         log(f"[bench] ef={ef}: recall@{args.k} = {mean:.4f} +- {half:.4f} on {sample} queries")
         return mean, half
 
-    def agreed(flag: bool) -> bool:  # rank 0 decides, everybody follows (the sweep is made of collectives when sharded)
-        if world == 1:
-            return flag
-        box = torch.tensor([1 if flag else 0], device=device)
-        dist.broadcast(box, 0)
-        return bool(box.item())
+    def agreed(flag: bool) -> bool:
+        return rank_zero_decides(flag, rank, world, device)
 
     if sample:
         below = 0
@@ -692,9 +867,11 @@ def main() -> None:
     #      (csrc/placement.hpp). The ENGINE tries placements inside the launches that fill the chip — the sweep above was made of such
     #      launches — and lets the walk itself judge them on the caller's queries: nothing to do here but to report what it did
     #      (read again after the timed steps: trials may still be under way during the warm-up).
-    placement_policy = ("engine: scratch block drawn by run_ladder when a chip-filling launch needs a new one (<= 8 candidates timed by the "
-                        "launch's first queries); matrix: one fresh device-to-device copy per chip-filling launch judged against the incumbent "
-                        "on that launch's first queries at the caller's expansion (<= 8 trials, ended by three wins of the incumbent in a row; a launch more than twice as wide as the last trial's reopens the search for three more, twice at most)")
+    placement_policy = ("settle, then allocate: the loader places the matrix once, after USEARCH_AMD_SETTLE_MS (1000) since the last big "
+                        "release (csrc/placement.hpp); no online trials (USEARCH_AMD_PLACEMENT_DRAWS > 1 turns them back on); the scratch "
+                        "block is drawn by run_ladder when a chip-filling launch needs a new one (<= 8 candidates timed by the launch's "
+                        "first queries)")
+    draws_before_timing = index.placement["draws"]
 
     # ---- warmup, then EXACTLY `steps` timed steps between barriers
     flush_native_stdio()
@@ -707,26 +884,21 @@ def main() -> None:
         ramp_steps += 1
     for _ in range(args.warmup):
         search_step(expansion, False)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    kernel_ms, passes, tails = [], 0, []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    kernel_ms, tails, step_stats = [], [], []
+
+    def timed_step(_):
         stats = search_step(expansion, True)
         kernel_ms.append(stats.kernel_ms)
-        passes = max(passes, stats.passes)
         tails.append(stats.tail_idle)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        step_stats.append(stats)
 
-    placement = {"matrix": index.placement, "policy": placement_policy}
+    elapsed = timed_steps(timed_step, args.steps, world, device)
+    stats = step_stats[-1]
+    passes = max(int(each.passes) for each in step_stats)
+
+    placement = {"matrix": index.placement, "policy": placement_policy, "reload": reload_seconds}
+    # nothing may have moved the matrix (or timed copies of it) inside the timed steps
+    assert placement["matrix"]["draws"] == draws_before_timing, "a placement trial ran inside the timed region"
 
     # ---- algorithmic bytes of one step from the per-query counters:
     #      B_q = computed·bpv + visited·(4·M0) + k·8 + bpv        (upper-level lists counted at the level-0 size)
@@ -740,7 +912,8 @@ def main() -> None:
     # row still one) — the bound that applies when rows are shorter than a line
     row_lines = -(-index.row_stride // 128) if index.row_stride >= 128 else 1
     list_bytes = 128 * -(-4 * m0 // 128)
-    if index.inline_rows:  # the neighbours' rows lie next to the list: a hop is one contiguous block, whatever is fresh
+    inline_rows, lanes_per_row = bool(index.inline_rows), index.lanes_per_row
+    if inline_rows:  # the neighbours' rows lie next to the list: a hop is one contiguous block, whatever is fresh
         touched_bytes = float(np.sum(visited * (list_bytes + 128 * -(-m0 * 16 // 128)) + 128 + row_lines * 128))
     else:
         touched_bytes = float(np.sum(computed * row_lines * 128 + visited * list_bytes + 128 + row_lines * 128))
@@ -776,6 +949,23 @@ def main() -> None:
             log(f"[bench] serialized {image.nbytes / 1e9:.1f} GB for the reference in {time.time() - t1:.1f}s")
         ref_index.expansion_search = expansion
         threads = cores
+        # the gate of the metric is recall against EXACT search: SURVEY §8(d) names the reference's `search(…, exact = true)`
+        # (index.hpp:4252-4268) as the ground truth. The sweep above scored against the product's own exact kernel; a bounded sample of
+        # it is held against the reference's here (about two exact queries a second on these cores for the headline index).
+        truth_check = None
+        if truth is not None and sample:
+            checked = int(min(sample, 32, max(4, 2.5e11 / max(1.0, args.n * bpv))))
+            t1 = time.perf_counter()
+            tkeys, tdists, *_ = ref_index.search(queries_host[:checked], args.k, dtype=args.dtype, exact=True, threads=threads)
+            if by_distance:  # integer-valued metrics tie: the k-th distances must agree, the keys need not
+                same = float(np.mean(tdists[:, -1] == truth_distances[:checked, -1]))
+            else:
+                same = float(np.mean(tkeys == truth[:checked]))
+            truth_check = {"queries": checked, "seconds": round(time.perf_counter() - t1, 1),
+                           "agreement_of_the_products_exact_kernel_with_reference_exact": same,
+                           "what": "k-th distances equal" if by_distance else "labels equal, position by position"}
+            log(f"[bench] ground truth: the product's exact kernel against the reference's search(exact=true) on {checked} queries: "
+                f"{same:.4f} ({truth_check['what']}; {truth_check['seconds']}s)")
         pilot = min(args.queries, 16 * threads)
         t1 = time.perf_counter()
         ref_index.search(queries_host[:pilot], args.k, dtype=args.dtype, threads=threads)
@@ -827,7 +1017,8 @@ def main() -> None:
             ref_index.search(queries_host[i:i + 1], args.k, dtype=args.dtype, threads=1)
         reference_single_us = (time.perf_counter() - t1) / 32 * 1e6
         cpu = {"value": sample_q / cpu_seconds, "unit": "shard-queries/s" if sharded else "queries/s", "cores": threads,
-               "kind": "reference", "frontier_check": frontier_check,
+               "kind": "reference", "label_agreement_with_the_gpu": agree, "frontier_check": frontier_check,
+               "ground_truth_check": truth_check,
                "sample": f"{sample_q} of the step's {args.queries} queries, same index, same ef={expansion}, "
                          f"OpenMP static,32 loop of cpp/bench.cpp:352-377; serial (auto-vectorised) metrics, SimSIMD "
                          f"unavailable offline; {cpu_seconds:.1f}s; label agreement with the GPU {agree:.4f}; one query at a "
@@ -852,52 +1043,56 @@ def main() -> None:
             log(f"[bench] loading the {image.nbytes / 1e9:.1f} GB image: {ours:.1f}s into HBM (device flattener), {theirs:.1f}s for the "
                 f"reference's usearch_load_buffer")
             ref_index = None
-        del image
         cpu["load_seconds"] = load_seconds
 
-    # ---- the same batch with the engine's placement draws switched off (a fresh copy of the index, first placement of everything):
-    #      what a caller would get without them. Outside the timed region; `roofline.frac_first_placement`.
-    first_placement = None
-    if rank == 0 and world == 1 and not sharded and not args.no_placement_check and built is not None:
-        saved = {name: os.environ.get(name) for name in ("USEARCH_AMD_SCRATCH_DRAWS", "USEARCH_AMD_PLACEMENT_DRAWS")}
-        os.environ["USEARCH_AMD_SCRATCH_DRAWS"] = os.environ["USEARCH_AMD_PLACEMENT_DRAWS"] = "1"
+    # ---- how reproducible the placement is: the index is closed, the very same image loaded a SECOND time (settle window and all) and
+    #      the batch timed on that copy. Outside the timed region; `roofline.kernel_ms_second_load`.
+    second_load = None
+    if rank == 0 and world == 1 and not sharded and not args.no_placement_check and (image is not None or built is not None):
         try:
-            undrawn = usearch_amd.Index.restore(built.save_buffer(), device=local_rank)
-            times = []
-            for step in range(6):
-                stats_first = undrawn.search_device(queries_dev.data_ptr(), args.queries, queries_dev.stride(0), args.k, expansion,
-                                                    keys_dev.data_ptr(), dist_dev.data_ptr(), counts_dev.data_ptr(),
-                                                    visited_dev.data_ptr(), computed_dev.data_ptr(), stream=stream.cuda_stream, timed=True)
-                if step:
-                    times.append(stats_first.kernel_ms)
-            first_placement = {"kernel_ms": float(np.mean(times)), "frac": step_bytes / (float(np.mean(times)) / 1e3) / 1e9 / HBM_PEAK_GBPS}
-            undrawn.close()
-            del undrawn
-            # ... and the engine's own placement once more AFTER it, so that the order of the two measurements cannot make the sign
-            again = []
-            for step in range(6):
-                stats_again = search_step(expansion, True)
-                if step:
-                    again.append(stats_again.kernel_ms)
-            first_placement["kernel_ms_placed_before"] = kernel_s * 1e3
-            first_placement["kernel_ms_placed_after"] = float(np.mean(again))
-            log(f"[bench] with the placement trials off (a fresh copy, first placement of everything): kernel {first_placement['kernel_ms']:.2f} ms; "
-                f"the engine's placement before / after that measurement: {kernel_s * 1e3:.2f} / {first_placement['kernel_ms_placed_after']:.2f} ms")
+            if image is None:
+                image = built.save_buffer()
+            ref_index = None
+            index.close()
+            if built is not None:
+                built.close()
+                built = None
+            torch.cuda.empty_cache()
+            usearch_amd.note_device_free()
+            index = usearch_amd.Index.restore(image, device=local_rank)
+            t_ramp = time.perf_counter()
+            while time.perf_counter() - t_ramp < 0.75:
+                search_step(expansion, False)
+                torch.cuda.synchronize()
+            again = [search_step(expansion, True).kernel_ms for _ in range(8)][2:]
+            second_load = {"kernel_ms": float(np.mean(again)), "settle_ms": index.placement["settle_ms"],
+                           "frac": step_bytes / (float(np.mean(again)) / 1e3) / 1e9 / HBM_PEAK_GBPS}
+            log(f"[bench] the same image loaded a second time: kernel {second_load['kernel_ms']:.2f} ms against {kernel_s * 1e3:.2f} ms in the "
+                f"timed steps ({(second_load['kernel_ms'] / (kernel_s * 1e3) - 1) * 100:+.1f} %)")
         except (RuntimeError, MemoryError) as error:
-            log(f"[bench] no first-placement check: {error}")
-        finally:
-            for name, value in saved.items():
-                if value is None:
-                    os.environ.pop(name, None)
-                else:
-                    os.environ[name] = value
-        torch.cuda.empty_cache()
+            log(f"[bench] no second-load check: {error}")
+    image = None
 
     stress = None
     if rank == 0 and world == 1 and not sharded and not args.no_stress_rows:
-        del built
+        built = None
         torch.cuda.empty_cache()
         stress = stress_rows(args, metric, device, local_rank, expansion)
+
+    # ---- BASELINE.json's other configurations, each at its full size in a process of its own (this one has released the GPU by then):
+    #      the driver's run of the default line observes them all. Only the default workload carries them.
+    secondary = None
+    default_workload = (args.config in (None, "c3") and (args.n, args.dim, args.dtype, args.queries) == (10_000_000, 768, "f16", 10_000))
+    if rank == 0 and world == 1 and not sharded and not args.no_secondary and default_workload:
+        try:
+            index.close()
+        except Exception:
+            pass
+        index = built = None
+        del queries_dev, keys_dev, dist_dev, counts_dev, visited_dev, computed_dev
+        torch.cuda.empty_cache()
+        secondary = secondary_lines([name for name in args.secondary.split(",") if name in PRESETS and name != "c3"],
+                                    args.secondary_timeout)
 
     if rank == 0:
         workload = (f"{args.n}x{args.dim} {args.dtype} {metric}, batch {args.queries}, k={args.k}, "
@@ -963,22 +1158,23 @@ def main() -> None:
                        # per round (2 x 12 loads), 5 = four waves per query (small batches)
                        "kernel_variant": stats.variant,
                        "persistent_waves": stats.grid, "lds_bytes_per_wave": stats.lds_bytes,
-                       "rows_inline_with_lists": bool(index.inline_rows),
+                       "rows_inline_with_lists": inline_rows,
+                       "visited_set_probe": {"mode": {0: "compare-and-swap", 1: "load, then compare-and-swap", 2: "loads and plain stores, no atomic"}.get(stats.probe_mode),
+                                             "seen_cells": stats.seen_cells, "claim_bits": stats.claim_bits} if stats.mode == 2 else None,
                        "batch_tail_idle": float(np.mean(tails)) if args.wave_clock else None,
                        "host_buffer_api_qps_pcie_inclusive": host_api_qps,
                        "single_query_latency_us_host_api": single_query_us,
-                       "sources": sources, "stress_rows": stress},
+                       "sources": sources, "stress_rows": stress, "secondary": secondary},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
-                         "frac_first_placement": first_placement["frac"] if first_placement else None,
-                         "kernel_ms_first_placement": first_placement["kernel_ms"] if first_placement else None,
-                         "kernel_ms_after_first_placement_check": first_placement["kernel_ms_placed_after"] if first_placement else None,
+                         "kernel_ms_second_load": second_load["kernel_ms"] if second_load else None,
+                         "frac_second_load": second_load["frac"] if second_load else None,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "search_kernel", "kernel_ms": kernel_s * 1e3,
                          # template arguments of the timed instantiation as rocprofv3 prints them: metric and scalar codes, lanes
                          # per row, build, scratch mode, `top` cells per lane, frontier
                          "kernel_instantiation": (f"search_kernel<{ord({'tanimoto': 't', 'jaccard': 't'}.get(metric, {'cos': 'c', 'ip': 'i', 'l2sq': 'e', 'hamming': 'b', 'pearson': 'p', 'haversine': 'h', 'divergence': 'd', 'sorensen': 's'}.get(metric, '?')))}, "
-                                                  f"{ {'b1': 1, 'bf16': 4, 'f64': 10, 'f32': 11, 'f16': 12, 'i8': 23}[args.dtype]}, {index.lanes_per_row}, "
+                                                  f"{ {'b1': 1, 'bf16': 4, 'f64': 10, 'f32': 11, 'f16': 12, 'i8': 23}[args.dtype]}, {lanes_per_row}, "
                                                   f"{stats.variant - 1}, {stats.mode - 1}, {stats.top_cells}, {stats.frontier - 1}>"),
                          "algorithmic_bytes_per_launch": step_bytes,
                          "lines_touched_bytes_per_launch": touched_bytes,

@@ -79,6 +79,10 @@ typedef struct usearch_amd_stats_t {
     float span_ms;           /**< with wave_clock: first wave start → last wave exit, device wall clock */
     uint32_t top_cells;      /**< cells of `top` per lane in registers (1, 4, 8, 16), 0 = `top` in scratch memory; with mode,
                                   variant and frontier this names the kernel instantiation of the first launch */
+    uint32_t probe_mode;     /**< short rows over a global visited-set slab: 0 = one compare-and-swap per probe, 1 = a load first and the
+                                  swap only to claim, 2 = no atomic at all (loads, plain stores, claims settled by bits in LDS) */
+    uint32_t seen_cells;     /**< … `seen` cells in LDS in front of the slab */
+    uint32_t claim_bits;     /**< … claim bits in LDS (probe_mode 2) */
 } usearch_amd_stats_t;
 
 /** Number of visible HIP devices; 0 (and an error) when the runtime finds none. */
@@ -126,6 +130,19 @@ USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_device_bytes(usearch_amd_snapshot
 USEARCH_AMD_EXPORT void usearch_amd_snapshot_placement(usearch_amd_snapshot_t snapshot, uint32_t* draws, uint32_t* kept,
                                                        float* judge_ms, float* probe_ms);
 USEARCH_AMD_EXPORT void usearch_amd_snapshot_placement_incumbents(usearch_amd_snapshot_t snapshot, float* incumbent_ms);
+/**
+ *  Settle, then allocate (csrc/placement.hpp; round 6). The driver hands a freed block's frames back to its allocator 0.3 … 1 s
+ *  after the free, and a multi-gigabyte array allocated inside that window lands on other — slower — frames than the ones the driver
+ *  prefers when everything is free (the headline batch: 44.8 ms on the preferred frames every time, 51 ms every other time without
+ *  the wait). Every loader and builder of this library therefore waits, before it allocates the matrix of stored rows, until
+ *  USEARCH_AMD_SETTLE_MS (default 1000; 0 = off) have passed since the last release of ≥ 64 MB it knows of: its own, and those a
+ *  host announces here after freeing device memory through ANOTHER allocator (`torch.cuda.empty_cache()`, `hipFree` of its own).
+ *  `usearch_amd_settle` waits out the window explicitly (before a host's own big allocation) and returns the milliseconds waited;
+ *  `usearch_amd_snapshot_settle_ms` = what this snapshot's matrix waited when it was allocated.
+ */
+USEARCH_AMD_EXPORT void usearch_amd_note_device_free(void);
+USEARCH_AMD_EXPORT float usearch_amd_settle(void);
+USEARCH_AMD_EXPORT float usearch_amd_snapshot_settle_ms(usearch_amd_snapshot_t snapshot);
 /** The placement probe alone, on the resident matrix or a part of it: GB/s of a dependency-free gather of random stored rows
  *  among rows [first_row, first_row + rows) (`rows` = 0: to the end). Diagnostics (scripts/placement_study.py). */
 USEARCH_AMD_EXPORT float usearch_amd_snapshot_gather_probe(usearch_amd_snapshot_t snapshot, uint64_t first_row, uint64_t rows,

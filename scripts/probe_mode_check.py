@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""scripts/probe_mode_check.py — the three ways a short-row walk probes its wave-private visited-set slab (common.hpp `probe_mode_t`,
+USEARCH_AMD_PROBE_MODE = 0 compare-and-swap | 1 a load first, the swap to claim | 2 no atomic: loads, plain stores, claims settled
+by bits in LDS) on the same index and the same batch: keys / distance bits / counts / both traversal counters compared query by
+query against mode 0, then the kernel time of each on a 100 000-query batch.
+
+    python scripts/probe_mode_check.py [--vectors 2000000] [--queries 20000] [--timed-queries 100000]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main() -> None:
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--vectors", type=int, default=2_000_000)
+    parser.add_argument("--queries", type=int, default=20_000)
+    parser.add_argument("--timed-queries", type=int, default=100_000)
+    parser.add_argument("--modes", type=int, nargs="+", default=[0, 1, 2])
+    args = parser.parse_args()
+    import torch
+
+    import bench
+    import usearch_amd
+    from usearch_amd import Tuning
+    device = torch.device("cuda", 0)
+    n = args.vectors
+    for dtype, metric, dim, expansion in (("b1", "hamming", 128, 64), ("i8", "l2sq", 96, 80), ("i8", "l2sq", 96, 64)):
+        data = bench.synthetic_vectors_device(n, dim, dtype, 42, device)
+        built = usearch_amd.build(None, metric, dtype, device_pointer=data.data_ptr(), count=n, stride=data.stride(0), ndim=dim)
+        index = built.index
+        queries = bench.synthetic_vectors_device(max(args.queries, args.timed_queries), dim, dtype, 43, device).cpu().numpy().view(bench.NUMPY_STORAGE[dtype])
+        answers = {}
+        for mode in args.modes:
+            os.environ["USEARCH_AMD_PROBE_MODE"] = str(mode)
+            got = index.search(queries[:args.queries], 10, expansion=expansion, dtype=dtype, tuning=Tuning(mode=2))
+            times = []
+            for _ in range(4):
+                timed = index.search(queries[:args.timed_queries], 10, expansion=expansion, dtype=dtype, tuning=Tuning(mode=2))
+                times.append(timed.stats.kernel_ms)
+            answers[mode] = (got, float(np.min(times[1:])), timed.stats)
+        base = answers[args.modes[0]][0]
+        for mode in args.modes:
+            got, ms, stats = answers[mode]
+            same = (np.array_equal(base.keys, got.keys) and np.array_equal(base.distances.view(np.uint32), got.distances.view(np.uint32))
+                    and np.array_equal(base.counts, got.counts) and np.array_equal(base.visited_per_query, got.visited_per_query)
+                    and np.array_equal(base.computed_per_query, got.computed_per_query))
+            print(f"{n}x{dim} {dtype} {metric} ef {expansion}: probe mode {mode} (ran {stats.probe_mode}, scratch mode {stats.mode}, {stats.grid} waves, "
+                  f"{stats.lds_bytes} B LDS/wave, seen {stats.seen_cells}, claim bits {stats.claim_bits}): {ms:.3f} ms for {args.timed_queries} queries = "
+                  f"{args.timed_queries / ms / 1e3:.2f} M QPS; identical to mode {args.modes[0]} on {args.queries} queries (keys, bits, counts, both counters): {same}",
+                  flush=True)
+        del index, built, data
+        torch.cuda.empty_cache()
+    os.environ.pop("USEARCH_AMD_PROBE_MODE", None)
+
+
+if __name__ == "__main__":
+    main()

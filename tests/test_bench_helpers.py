@@ -65,3 +65,34 @@ def test_memory_plan_and_dry_run():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["dry_run"] and line["fits"] and line["vectors_in_all"] == 1_000_000_000
     assert "--nproc-per-node 8" in line["command"] and "--master-addr 127.0.0.1" in line["command"] and "--dry" not in line["command"]
+
+
+def test_launcher_path_of_the_sharded_bench_two_ranks_on_the_cpu():
+    """`BENCH_REHEARSAL=cpu python bench.py --gpus 2 --sharded`: the script re-executes itself under torch.distributed.run with two
+    ranks, which join over gloo, follow rank 0's choice of the expansion, run warm-up and timed steps through the product's sharded
+    entry point (host transport; the shard search is a stand-in — there is no search without a device) between barriers, and rank 0
+    prints ONE JSON line. The control flow of an N-GPU run, exercised every round although no multi-GPU node ever was available."""
+    import json
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_REHEARSAL="cpu", GLOO_SOCKET_IFNAME="lo")
+    for name in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(name, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sharded", "--config", "c5", "--steps", "4",
+                          "--warmup", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [text for text in out.stdout.splitlines() if text.startswith("{")]
+    assert len(lines) == 1, out.stdout  # rank 0 alone speaks
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 2 and line["scaling"] == "weak"
+    assert "REHEARSAL" in line["data"] and line["roofline"] is None and line["cpu_baseline"] is None
+    assert line["config"]["preflight"]["world"] == 2 and line["config"]["parallelism"] == "shards2"
+    assert line["config"]["expansion_search"] == 96  # what rank 0 decided
+    exchange = line["config"]["exchange"]
+    assert exchange["exchanges_per_step"] == 1 and exchange["gathered_bytes"] == 2 * exchange["block_bytes"]
+    # a world that is not what --gpus said is refused before anything runs
+    env3 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--sharded", "--steps", "1", "--warmup", "0"],
+                          capture_output=True, text=True, timeout=120, env=env3).returncode == 0

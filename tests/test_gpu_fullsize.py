@@ -1,11 +1,14 @@
-"""Parity at the BASELINE configurations' own scale, under the driver: config 2 at full size (1M x 768 f32 cosine) and 2M-vector
-slices of configs 4 and 5 (96-d i8 L2, 128-bit Hamming) — index built on the device, saved, and handed to the REAL reference
+"""Parity at the BASELINE configurations' OWN sizes, under the driver: config 2 (1M x 768 f32 cosine), config 3 — the headline —
+(10M x 768 f16 cosine at the headline's expansion 608: the `u12x2` build over the global visited set that bench.py times),
+config 4 (100M x 96 i8 L2 at its expansion 80) and one shard of config 5 (125M x 128 b1 Hamming), plus 2M-vector slices of
+the short-row shapes — index built on the device, saved, and handed to the REAL reference
 (`oracle/_ref`, `usearch_view_buffer`); the same >= 512 queries searched by both (more than two per compute unit: the one-wave
 kernel the bench lines time, not the team build of small batches). Integer-valued pairs: keys, distance bits,
 counts and both traversal counters identical, ties included. Float pair: the oracle in the kernels' summation layout bit for
 bit, the reference within the stated tolerance with IDENTICAL labels at every position whose neighbouring reference distances
-are farther apart than twice that tolerance (tests/util.py `assert_float_parity`). (The 10M / 100M / 125M configurations themselves
-carry the same comparison inside bench.py: "label agreement with the GPU" in every line.)"""
+are farther apart than twice that tolerance (tests/util.py `assert_float_parity`; the reference's own bar at this scale
+is cpp/test.cpp:499-503: counts within the index size, distances non-decreasing — asserted too). The full-size rows take about
+a minute each (build 4 … 50 s, image 3 … 25 GB on the host); USEARCH_AMD_SKIP_FULL_SIZE=1 leaves them out of a quick run."""
 import os
 import sys
 
@@ -21,10 +24,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+FULL = pytest.mark.skipif(os.environ.get("USEARCH_AMD_SKIP_FULL_SIZE") == "1", reason="USEARCH_AMD_SKIP_FULL_SIZE=1")
 CONFIGS = [  # (vectors, dimensions, dtype, metric, queries, k, expansion)
     (1_000_000, 768, "f32", "cos", 640, 10, 64),   # > 2 queries per CU: the one-wave kernel every BASELINE line times
     (2_000_000, 96, "i8", "l2sq", 512, 10, 64),
     (2_000_000, 128, "b1", "hamming", 512, 10, 64),
+    pytest.param(10_000_000, 768, "f16", "cos", 640, 10, 608, marks=FULL, id="headline-10M-768-f16-ef608"),
+    pytest.param(100_000_000, 96, "i8", "l2sq", 1024, 10, 80, marks=FULL, id="config4-100M-96-i8-ef80"),
+    pytest.param(125_000_000, 128, "b1", "hamming", 1024, 10, 64, marks=FULL, id="config5-shard-125M-128-b1-ef64"),
 ]
 
 
@@ -48,8 +55,14 @@ def test_baseline_shapes_at_scale_match_the_reference(reference, n, dim, dtype, 
     got = index.search(batch, k, expansion=expansion, dtype=dtype)
     assert got.stats.passes == 1, "the default scratch must hold these traversals"
     assert got.stats.variant != 5, "a batch of this size must walk with one wave per query (the benchmarked kernel), not the team build"
+    if (n, dtype, expansion) == (10_000_000, "f16", 608):  # the instantiation bench.py times: search_kernel<cos, f16, 8, u12x2, global hash, 16, in-top>
+        assert (got.stats.mode, got.stats.variant, got.stats.frontier, got.stats.top_cells) == (2, 4, 2, 16), \
+            (got.stats.mode, got.stats.variant, got.stats.frontier, got.stats.top_cells)
     rkeys, rdists, rcounts, rvisited, rcomputed = reference_index.search(batch, k, dtype=dtype, threads=0)
     assert np.array_equal(got.counts, rcounts)
+    # the reference's own bar at scale (cpp/test.cpp:499-503): no more results than members, distances non-decreasing
+    found = got.counts.astype(np.int64)
+    assert np.all(found <= min(n, k)) and np.all(np.diff(got.distances, axis=1)[np.arange(k - 1)[None, :] < found[:, None] - 1] >= 0)
     if util.exact_pair(metric, dtype):
         assert np.array_equal(got.keys, rkeys)
         assert util.same_float_bits(got.distances, rdists)
@@ -60,12 +73,19 @@ def test_baseline_shapes_at_scale_match_the_reference(reference, n, dim, dtype, 
             got.keys, got.distances, got.counts,
             lambda queries_, wanted: reference_index.search(queries_, wanted, dtype=dtype, threads=0), batch, k, dtype,
             what=f"{n} x {dim} {dtype}")
-        assert separated > 0.5 and agreement > 0.98
-        okeys, odists, ocounts, ovisited, ocomputed = oraclebind.OracleIndex(image).search(
-            batch, k, dtype=dtype, expansion=expansion, lanes=index.lanes_per_row, frontier_in_top=got.stats.frontier == 2)
+        print(f"[fullsize] {n} x {dim} {dtype} ef={expansion}: {separated:.3f} of the positions separated in the reference's distances, "
+              f"label agreement {agreement:.4f} on all positions")
+        # f16 rows at 10M: neighbouring distances crowd inside the f16 tolerance (2e-3), fewer positions are separated
+        assert (separated > 0.5 and agreement > 0.98) if dtype == "f32" else (separated > 0.02 and agreement > 0.5)
+        okeys, odists, ocounts, ovisited, ocomputed = util.oracle_search(
+            image, batch, k, dtype, expansion=expansion, lanes=index.lanes_per_row, frontier_in_top=got.stats.frontier == 2,
+            threads=min(8, os.cpu_count() or 1))
         assert np.array_equal(got.keys, okeys) and util.same_float_bits(got.distances, odists)
         assert np.array_equal(got.visited_per_query, ovisited) and np.array_equal(got.computed_per_query, ocomputed)
     # what the device loader makes of the saved image is the index that was built
+    if n >= 50_000_000:  # one copy of a 25 … 85 GB index in HBM at a time
+        del index, reference_index
+        built.close()
     restored = usearch_amd.Index.restore(image)
     again = restored.search(batch, k, expansion=expansion, dtype=dtype)
     assert np.array_equal(again.keys, got.keys) and util.same_float_bits(again.distances, got.distances)

@@ -53,8 +53,7 @@ struct device_block_t {
     std::vector<void*> pointers;
     ~device_block_t() {
         for (void* p : pointers)
-            if (p)
-                (void)hipFree(p);
+            placed_free(p); // time-stamps the release of large blocks (placement.hpp: settle, then allocate)
     }
     template <typename pointer_at> hipError_t allocate(pointer_at** out, std::size_t bytes) {
         void* p = nullptr;
@@ -143,10 +142,7 @@ const char* snapshot_t::grow_for_build(std::uint64_t capacity, std::uint64_t lis
         if (array.new_bytes > array.old_bytes)
             UA_HIP(hipMemset(static_cast<std::uint8_t*>(fresh) + array.old_bytes, array.fill, array.new_bytes - array.old_bytes));
         if (*array.pointer) {
-            if (array.pointer == &d_vectors_ || array.pointer == &d_nbr0_)
-                placed_free(*array.pointer);
-            else
-                (void)hipFree(*array.pointer);
+            placed_free(*array.pointer);
         }
         *array.pointer = fresh;
         device_bytes_ += std::max<std::size_t>(array.new_bytes, 16) - (array.old_bytes ? std::max<std::size_t>(array.old_bytes, 16) : 0);
@@ -226,8 +222,7 @@ builder_t::~builder_t() { release_workspace(); }
 
 void builder_t::release_workspace() {
     for (void* p : workspace_)
-        if (p)
-            (void)hipFree(p);
+        placed_free(p); // time-stamps the release of large blocks (placement.hpp: settle, then allocate)
     workspace_.clear();
     workspace_nodes_ = 0;
 }

@@ -109,6 +109,9 @@ void stats_to_c(const search_stats_t& s, usearch_amd_stats_t* out) {
     out->tail_idle = s.tail_idle;
     out->span_ms = s.span_ms;
     out->top_cells = s.top_cells;
+    out->probe_mode = s.probe_mode;
+    out->seen_cells = s.seen_cells;
+    out->claim_bits = s.claim_bits;
 }
 
 void fail(usearch_amd_error_t* error, const char* message) {
@@ -272,6 +275,9 @@ void usearch_amd_snapshot_placement_incumbents(usearch_amd_snapshot_t s, float* 
     for (int i = 0; i < placement_max_draws_k; ++i)
         incumbent_ms[i] = placement.incumbent_ms[i];
 }
+void usearch_amd_note_device_free(void) { note_release((std::size_t)1 << 40); }
+float usearch_amd_settle(void) { return settle_before_placing(); }
+float usearch_amd_snapshot_settle_ms(usearch_amd_snapshot_t s) { return as_snapshot(s)->placement().settle_ms; }
 int usearch_amd_snapshot_scalar_kind(usearch_amd_snapshot_t s) { return scalar_to_c(as_snapshot(s)->scalar()); }
 int usearch_amd_snapshot_metric_kind(usearch_amd_snapshot_t s) { return metric_to_c(as_snapshot(s)->metric()); }
 size_t usearch_amd_snapshot_lanes_per_row(usearch_amd_snapshot_t s) { return as_snapshot(s)->lanes_per_row(); }

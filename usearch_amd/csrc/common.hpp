@@ -142,8 +142,22 @@ struct search_args_t {
                                     ///< persistent wave (how long the drain phase of a batch leaves the chip part-idle)
     std::uint32_t seen_offset;      ///< short rows with the visited set in a global slab: where in the wave's LDS the `seen` cells
     std::uint32_t seen_cells;       ///< sit, and how many (a power of two; 0 = none) — see `search_one`
+    std::uint32_t probe_mode;       ///< how those walks probe the slab (`probe_mode_t`): compare-and-swap, a load first and the swap
+                                    ///< only to claim, or no atomic at all (loads + plain stores, claims settled in LDS)
+    std::uint32_t claim_offset;     ///< `probe_plain_k`: where in the wave's LDS the claim bits sit, and how many (a power of two,
+    std::uint32_t claim_bits;       ///< ≤ hash_cap; one bit per cell when equal, else cell & (bits − 1))
 };
 
 enum : std::uint32_t { status_done_k = 0, status_overflow_k = 1 };
+
+/// How a short-row walk probes its wave-private visited-set slab in global memory (kernels.hpp `search_one`).
+enum probe_mode_t : std::uint32_t {
+    probe_swap_k = 0,       ///< one compare-and-swap per probe (executed at the memory side: 27.5 G a second chip-wide)
+    probe_load_first_k = 1, ///< a load, and the swap only to claim an empty cell (round 5's experiment: two round trips per fresh slot)
+    probe_plain_k = 2,      ///< no atomic: a load that bypasses the vector cache, a plain store nobody waits for, and the claims of
+                            ///< one instruction's lanes on the same cell settled by an LDS bit per cell
+};
+/// What the engine picks unless USEARCH_AMD_PROBE_MODE says otherwise (engine.hip `run_ladder`).
+constexpr std::uint32_t default_probe_mode_k = probe_swap_k;
 
 } // namespace usearch_amd

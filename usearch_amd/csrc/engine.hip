@@ -253,8 +253,7 @@ void snapshot_t::release() {
         *p = nullptr;
     }
     for (void* p : {d_upper_ref_, d_upper_, d_keys_})
-        if (p)
-            (void)hipFree(p);
+        placed_free(p);
     {
         std::lock_guard<std::mutex> lock(pool_mutex_);
         for (auto& workspace : workspaces_)
@@ -283,13 +282,18 @@ __global__ void inline_rows_kernel(const std::uint8_t* vectors, const std::uint3
 }
 
 /// One trial (placement.hpp). `launch(view, ms)` runs the launch's first queries over `view` once and reports the milliseconds.
-const char* snapshot_t::try_matrix_placement(const std::function<const char*(const snapshot_view_t&, float&)>& launch, hipStream_t stream) {
+const char* snapshot_t::try_matrix_placement(std::uint32_t expansion, const std::function<const char*(const snapshot_view_t&, float&)>& launch, hipStream_t stream) {
     {   // the matrix must be this launch's alone: no other batch in flight, none admitted until the trial is over
         std::lock_guard<std::mutex> lock(pool_mutex_);
         if (placing_ || workspaces_.size() - idle_.size() != 1)
             return nullptr;
         placing_ = true;
+        placement_last_ef_ = expansion; // a trial that actually runs: what a later, wider launch is compared with
     }
+    auto end_trials = [&]() {
+        std::lock_guard<std::mutex> lock(pool_mutex_);
+        placement_trials_left_ = 0;
+    };
     struct release_t {
         snapshot_t& owner;
         ~release_t() {
@@ -304,20 +308,20 @@ const char* snapshot_t::try_matrix_placement(const std::function<const char*(con
     std::size_t free_bytes = 0, total_bytes = 0;
     if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess || free_bytes < vectors_bytes_ + ((std::size_t)4 << 30)) {
         (void)hipGetLastError();
-        placement_trials_left_ = 0; // no room for a second copy of the matrix: it stays where it is
+        end_trials(); // no room for a second copy of the matrix: it stays where it is
         return nullptr;
     }
     void* candidate = nullptr;
     if (placed_malloc(&candidate, vectors_bytes_, view_.row_stride, nullptr) != hipSuccess) {
         (void)hipGetLastError();
-        placement_trials_left_ = 0;
+        end_trials();
         return nullptr;
     }
     if (hipMemcpyAsync(candidate, d_vectors_, vectors_bytes_, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
         hipStreamSynchronize(stream) != hipSuccess) {
         (void)hipGetLastError();
         placed_free(candidate);
-        placement_trials_left_ = 0;
+        end_trials();
         return nullptr;
     }
     snapshot_view_t other = view_;
@@ -345,22 +349,27 @@ const char* snapshot_t::try_matrix_placement(const std::function<const char*(con
     if (trial < (std::uint32_t)placement_max_draws_k)
         placement_.judge_ms[trial] = candidate_ms, placement_.incumbent_ms[trial] = incumbent_ms;
     ++placement_.draws;
-    --placement_trials_left_;
     // a candidate has to win by more than the judge's noise (two hundredths); three trials in a row that the incumbent wins end the
     // search — it sits on frames as good as this device hands out
     const bool swap = candidate_ms < incumbent_ms * 0.98f;
-    if (swap) {
-        void* previous = d_vectors_;
-        d_vectors_ = candidate;
-        view_.vectors = other.vectors;
-        placed_free(previous);
-        ++placement_.kept;
-        placement_losses_ = 0;
-    } else {
-        placed_free(candidate);
-        if (++placement_losses_ >= 3)
+    void* loser = candidate;
+    {
+        std::lock_guard<std::mutex> lock(pool_mutex_);
+        --placement_trials_left_;
+        if (swap) {
+            loser = d_vectors_;
+            d_vectors_ = candidate;
+            view_.vectors = other.vectors;
+            ++placement_.kept;
+            placement_losses_ = 0;
+        } else if (++placement_losses_ >= 3) {
             placement_trials_left_ = 0;
+        }
     }
+    // readers that hold no workspace lease (exact search on a caller's stream, the builder's `save_buffer`) may still have work
+    // enqueued over the old matrix: nothing of this device may be running when its memory goes back
+    (void)hipDeviceSynchronize();
+    placed_free(loser);
     placement_.probe_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - started).count();
     if (env_size("USEARCH_AMD_PLACEMENT_LOG", 0))
         std::fprintf(stderr, "[usearch_amd] matrix placement trial %u (%.2f GB): incumbent %.3f ms, fresh copy %.3f ms over the launch's first queries: %s; %u trials left\n",
@@ -528,8 +537,7 @@ const char* snapshot_t::build(const image_t& image, int device) {
         std::vector<void*> pointers;
         ~scratch_t() {
             for (void* p : pointers)
-                if (p)
-                    (void)hipFree(p);
+                placed_free(p); // time-stamps the release of large blocks (placement.hpp: settle, then allocate)
         }
         hipError_t allocate(void** out, std::size_t bytes) {
             *out = nullptr;
@@ -969,7 +977,32 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         // short rows over a global visited set: `seen` cells in LDS in front of it (kernels.hpp `search_one`) — as many as cost no
         // resident wave (the walk lives on its residency), at most 2 048; USEARCH_AMD_SEEN_CELLS forces a number (0 = none)
         args.seen_offset = 0, args.seen_cells = 0;
+        args.probe_mode = probe_swap_k, args.claim_offset = 0, args.claim_bits = 0;
         if (call.mode == scratch_hash_k && !params.team && lanes_ <= 2) {
+            // how the slab is probed (common.hpp `probe_mode_t`): USEARCH_AMD_PROBE_MODE = 0 | 1 | 2
+            // (USEARCH_AMD_PROBE_LOAD_FIRST=1, round 5's name for mode 1, still answers)
+            std::size_t probe_mode = env_size("USEARCH_AMD_PROBE_MODE", default_probe_mode_k);
+            if (env_size("USEARCH_AMD_PROBE_LOAD_FIRST", 0))
+                probe_mode = probe_load_first_k;
+            if (probe_mode == probe_plain_k) {
+                // one claim bit per cell of the slab where that costs no resident wave, else as many as do not (a smaller bitmap only
+                // adds false alarms: a lane that loses a claim looks at its cell again); USEARCH_AMD_CLAIM_BITS forces a number
+                std::uint32_t bits = call.hash_cap;
+                const std::size_t forced = env_size("USEARCH_AMD_CLAIM_BITS", 0);
+                if (forced)
+                    for (bits = 64; bits * 2 <= forced && bits < call.hash_cap; bits *= 2) {}
+                else
+                    while (bits > 512 && waves_for((wave_lds_bytes + 15) / 16 * 16 + bits / 8) < waves_for(wave_lds_bytes))
+                        bits /= 2;
+                if ((wave_lds_bytes + 15) / 16 * 16 + bits / 8 <= lds_budget) {
+                    args.probe_mode = probe_plain_k;
+                    args.claim_offset = (std::uint32_t)((wave_lds_bytes + 15) / 16 * 16);
+                    args.claim_bits = bits;
+                    wave_lds_bytes = args.claim_offset + bits / 8ull;
+                }
+            } else if (probe_mode == probe_load_first_k) {
+                args.probe_mode = probe_load_first_k;
+            }
             const std::size_t forced = env_size("USEARCH_AMD_SEEN_CELLS", (std::size_t)-1);
             std::uint32_t cells = 0;
             if (forced != (std::size_t)-1) {
@@ -984,9 +1017,10 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
                 args.seen_offset = (std::uint32_t)((wave_lds_bytes + 15) / 16 * 16);
                 args.seen_cells = cells;
                 wave_lds_bytes = args.seen_offset + cells * 4ull;
-                if (env_size("USEARCH_AMD_PROBE_LOAD_FIRST", 0)) // experiment switch (kernels.hpp `load_first`): rides in the offset's lowest bit
-                    args.seen_offset |= 1u;
             }
+            call.stats.probe_mode = args.probe_mode;
+            call.stats.seen_cells = args.seen_cells;
+            call.stats.claim_bits = args.claim_bits;
         }
         const std::uint64_t lds_bytes = params.team ? (wave_lds_bytes + 15) / 16 * 16 + team_bytes : wave_lds_bytes;
         args.team_offset = params.team ? (std::uint32_t)((wave_lds_bytes + 15) / 16 * 16) : 0u;
@@ -1095,14 +1129,22 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         }
         // ---- the matrix of stored rows: up to `placement_max_draws_k` trials over the first launches that fill the chip, judged like
         //      the scratch block — by this launch's own first queries at the caller's expansion (placement.hpp)
-        const std::uint32_t matrix_draws = (std::uint32_t)std::min<std::size_t>(placement_max_draws_k, env_size("USEARCH_AMD_PLACEMENT_DRAWS", placement_max_draws_k));
+        //      OFF unless USEARCH_AMD_PLACEMENT_DRAWS = 2 … 8 asks for them (round 6): the matrix is placed once, at load time, after
+        //      the settle window (placement.hpp) — deterministic, no second copy of the matrix in HBM during a search call, nothing
+        //      swapped under a reader. The trials stay for hosts whose matrix was allocated while other gigabytes were held.
+        const std::uint32_t matrix_draws = (std::uint32_t)std::min<std::size_t>(placement_max_draws_k, env_size("USEARCH_AMD_PLACEMENT_DRAWS", 1));
         // A host that tunes its expansion walks up through the regimes (bench.py's recall sweep: 64, 96, 128 … 608): trials judged at a
         // small expansion — differences of hundredths of a millisecond — must not be the last word for launches several times as
         // wide. A launch more than twice as wide as the last trial's reopens a search that has ended, for three trials, twice at most.
-        if (!placement_trials_left_ && matrix_draws > 1 && placement_reopens_ < 2 && placement_last_ef_ &&
-            call.ef > 2u * placement_last_ef_ && call.passes == 0 && !call.have_todo && pending >= 2ull * grid)
-            placement_trials_left_ = 3, placement_losses_ = 0, ++placement_reopens_;
-        if (placement_trials_left_ && matrix_draws > 1 && placement_.draws < matrix_draws + 3u * placement_reopens_ && call.passes == 0 && !call.have_todo &&
+        bool try_placement = false;
+        if (matrix_draws > 1) { // the trials' bookkeeping is shared by every batch in flight: under the pool's mutex
+            std::lock_guard<std::mutex> lock(pool_mutex_);
+            if (!placement_trials_left_ && placement_reopens_ < 2 && placement_last_ef_ && call.ef > 2u * placement_last_ef_ &&
+                call.passes == 0 && !call.have_todo && pending >= 2ull * grid)
+                placement_trials_left_ = 3, placement_losses_ = 0, ++placement_reopens_;
+            try_placement = placement_trials_left_ != 0;
+        }
+        if (try_placement && placement_.draws < matrix_draws + 3u * placement_reopens_ && call.passes == 0 && !call.have_todo &&
             !params.team && pending >= 2ull * grid && grid >= 2u * (std::uint32_t)compute_units_ && !view_.nbr0_rows && d_vectors_ &&
             vectors_bytes_ >= env_size("USEARCH_AMD_PLACEMENT_MIN_BYTES", (std::size_t)1 << 30) && !args.query_ids && !args.allow_bits &&
             !args.descent_only && !args.beam_level && !env_size("USEARCH_AMD_SCRATCH_REDRAW", 0)) {
@@ -1117,8 +1159,8 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
                 return hip_message(created);
             }
             args.count = grid; // one query per wave: the launch's steady state; their results are computed again by the launch proper
-            placement_last_ef_ = call.ef;
             const char* failure = try_matrix_placement(
+                call.ef,
                 [&](const snapshot_view_t& view, float& ms) -> const char* {
                     hipError_t e = hipMemsetAsync(ws.d_queue, 0, 8, stream);
                     if (e == hipSuccess)

@@ -49,6 +49,9 @@ struct search_stats_t {
                                          ///< that waves spent gone (the drain phase of the batch), first launch
     float span_ms = 0.f;                 ///< with `wave_clock`: first start → last exit on the device's 100-MHz clock
     std::uint32_t top_cells = 0;         ///< `top` cells per lane in registers of the first launch (0 = scratch memory)
+    std::uint32_t probe_mode = 0;        ///< short rows over a global slab: `probe_mode_t` of the last launch
+    std::uint32_t seen_cells = 0;        ///< … its `seen` cells in LDS
+    std::uint32_t claim_bits = 0;        ///< … its claim bits in LDS (`probe_plain_k`)
 };
 
 /// What index construction asks of the search on top of a plain query batch (see search_args_t).
@@ -261,7 +264,7 @@ class snapshot_t {
     /// One placement trial of the matrix of stored rows inside a launch that fills the chip (placement.hpp): a fresh device-to-device
     /// copy, incumbent and candidate timed alternately over the launch's first `grid` queries (`launch(view, ms)` runs them once and
     /// times them), the faster one stays. Needs the matrix to itself (no other batch in flight); does nothing otherwise.
-    const char* try_matrix_placement(const std::function<const char*(const snapshot_view_t&, float&)>& launch, hipStream_t stream);
+    const char* try_matrix_placement(std::uint32_t expansion, const std::function<const char*(const snapshot_view_t&, float&)>& launch, hipStream_t stream);
     void release();
 
     snapshot_view_t view_{};

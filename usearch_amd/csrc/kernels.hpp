@@ -1229,10 +1229,16 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     std::uint32_t seen_mask = 0;
     if constexpr (seen_ak) {
         if (args.seen_cells) {
-            seen = reinterpret_cast<std::uint32_t*>(query_lds + (args.seen_offset & ~15u));
+            seen = reinterpret_cast<std::uint32_t*>(query_lds + args.seen_offset);
             seen_mask = args.seen_cells - 1;
             for (std::uint32_t i = lane; i < args.seen_cells; i += 64)
                 seen[i] = none_slot_k;
+            wave_sync<false>();
+        }
+        if (args.probe_mode == probe_plain_k) { // the claim bits (zero between probe rounds; zeroed once more per query: free)
+            std::uint32_t* claim = reinterpret_cast<std::uint32_t*>(query_lds + args.claim_offset);
+            for (std::uint32_t i = lane; i < args.claim_bits / 32; i += 64)
+                claim[i] = 0u;
             wave_sync<false>();
         }
     }
@@ -1607,14 +1613,55 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                         asks = present && seen[seen_cell] != neighbor;
                     }
                 }
-                // `load_first` (short rows, USEARCH_AMD_PROBE_LOAD_FIRST=1; off by default): a cell is LOADED and an atomic spent only to
-                // claim an empty one — a slot that is already in the set (four probes in ten) then costs no atomic at all, a fresh one a
-                // load and the atomic. Loads see what the memory side's compare-and-swaps wrote (scripts/probes/atomic_then_load_probe.hip),
-                // a cell never changes once it is set, and a claim that loses to another lane of the same instruction reads the winner
-                // and moves on: the same answers as probing by compare-and-swap alone.
-                bool load_first = false;
+                // How the slab is probed (`probe_mode_t`, short rows only; the engine's choice rides in `args.probe_mode`):
+                //  * `probe_swap_k` — a compare-and-swap per probe round, executed at the memory side.
+                //  * `probe_load_first_k` (round 5's experiment) — a cell is LOADED and an atomic spent only to claim an empty one: a slot
+                //    already in the set costs no atomic, a fresh one a load and the atomic — two round trips on the hop's chain.
+                //  * `probe_plain_k` — NO atomic. The slab is private to this wave, so the only accesses that can race are those of the
+                //    lanes of one instruction: a cell is loaded past the vector cache (`sc1`: nothing is allocated there per lane), an
+                //    empty one is claimed with a plain store nobody waits for, and lanes of one round that want the SAME cell settle
+                //    it in LDS — one bit per cell, `ds_or_rtn`: LDS serves the lanes of an instruction one after the other, the first
+                //    to set the bit has the cell, the others look at it again next round and read the winner's slot (a wave's accesses
+                //    to one address are served in issue order). The words touched go back to zero behind the ORs. A list holds every
+                //    slot once (duplicates were removed on upload), so no two lanes of a round insert the same slot. One round trip
+                //    per probe round, same members in the set, same answers (which CELL a member lands in is not observable).
+                std::uint32_t probe_mode = probe_swap_k;
                 if constexpr (seen_ak)
-                    load_first = (args.seen_offset & 1u) != 0; // (the offset is a multiple of 16: its lowest bit carries the switch)
+                    probe_mode = args.probe_mode;
+                const bool load_first = probe_mode == probe_load_first_k;
+                if (probe_mode == probe_plain_k) {
+                    std::uint32_t* claim = reinterpret_cast<std::uint32_t*>(query_lds + args.claim_offset);
+                    const std::uint32_t claim_mask = args.claim_bits - 1;
+                    bool looking = asks;
+                    for (;;) {
+                        std::uint32_t cell_value = none_slot_k;
+                        if (looking)
+                            cell_value = __hip_atomic_load(visits + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!popped)
+                            pop_now(); // LDS and register work in the shadow of the first round trip
+                        const bool wants = looking && cell_value == none_slot_k;
+                        if (looking && cell_value == neighbor)
+                            looking = false; // in the set (`old` still names the slot itself: not fresh)
+                        if (ballot(wants)) {
+                            const std::uint32_t bit = h & claim_mask;
+                            bool won = false;
+                            if (wants) {
+                                const std::uint32_t before = __hip_atomic_fetch_or(claim + (bit >> 5), 1u << (bit & 31u), __ATOMIC_RELAXED,
+                                                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                                won = ((before >> (bit & 31u)) & 1u) == 0u;
+                                claim[bit >> 5] = 0u;
+                            }
+                            if (won) {
+                                __hip_atomic_store(visits + h, neighbor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                old = none_slot_k, looking = false;
+                            }
+                        }
+                        if (looking && !wants)
+                            h = (h + 1) & visits_mask; // linear probing, index.hpp:1085-1211
+                        if (!ballot(looking))
+                            break;
+                    }
+                } else {
                 if (asks) {
                     if (load_first) {
                         old = __hip_atomic_load(visits + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1635,6 +1682,7 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                     } else {
                         old = atomicCAS(visits + h, none_slot_k, neighbor);
                     }
+                }
                 }
                 fresh = present && old == none_slot_k;
                 if constexpr (seen_ak) {

@@ -8,11 +8,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "host_util.hpp"
 
 namespace usearch_amd {
+
+/// Releases smaller than this do not open a settle window (placement.hpp): workspaces' status arrays, staging buffers.
+constexpr std::size_t settle_counts_from_k = (std::size_t)64 << 20;
 
 namespace {
 
@@ -241,10 +245,67 @@ void placed_free(void* pointer) {
                 for (auto handle : record.handles)
                     (void)hipMemRelease(handle);
                 (void)hipMemAddressFree(record.base, record.bytes);
+                note_release(record.bytes);
                 return;
             }
     }
+    std::size_t bytes = 0;
+    if (hipMemPtrGetInfo(pointer, &bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        bytes = settle_counts_from_k; // a block of unknown size counts
+    }
     (void)hipFree(pointer);
+    note_release(bytes);
+}
+
+namespace {
+std::mutex settle_mutex;
+std::chrono::steady_clock::time_point last_release{}; // epoch = nothing released yet
+bool released_once = false;
+float settle_waited_ms = 0.f;
+std::uint32_t settle_waits = 0;
+} // namespace
+
+void note_release(std::size_t bytes) {
+    if (bytes < settle_counts_from_k)
+        return;
+    std::lock_guard<std::mutex> lock(settle_mutex);
+    last_release = std::chrono::steady_clock::now();
+    released_once = true;
+}
+
+float settle_before_placing() {
+    const std::size_t window_ms = env_size("USEARCH_AMD_SETTLE_MS", 1000);
+    std::chrono::steady_clock::time_point since;
+    {
+        std::lock_guard<std::mutex> lock(settle_mutex);
+        if (!released_once || !window_ms)
+            return 0.f;
+        since = last_release;
+    }
+    const auto ready = since + std::chrono::milliseconds(window_ms);
+    const auto now = std::chrono::steady_clock::now();
+    if (now >= ready)
+        return 0.f;
+    (void)hipDeviceSynchronize(); // nothing of ours may still be running on what was freed; the wait below is for the DRIVER
+    std::this_thread::sleep_until(ready);
+    const float waited = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - now).count();
+    {
+        std::lock_guard<std::mutex> lock(settle_mutex);
+        settle_waited_ms += waited;
+        ++settle_waits;
+    }
+    if (env_size("USEARCH_AMD_PLACEMENT_LOG", 0))
+        std::fprintf(stderr, "[usearch_amd] waited %.0f ms for freed frames to come back before placing an array\n", waited);
+    return waited;
+}
+
+void settle_totals(float* milliseconds, std::uint32_t* waits) {
+    std::lock_guard<std::mutex> lock(settle_mutex);
+    if (milliseconds)
+        *milliseconds = settle_waited_ms;
+    if (waits)
+        *waits = settle_waits;
 }
 
 hipError_t translation_probe(const void* base, std::size_t bytes, float* rate) {
@@ -373,6 +434,9 @@ hipError_t placed_malloc(void** out, std::size_t bytes, std::size_t, placement_t
     bytes = std::max<std::size_t>(bytes, 16);
     if (bytes < env_size("USEARCH_AMD_PLACEMENT_MIN_BYTES", (std::size_t)1 << 30))
         return block_malloc(out, bytes);
+    const float waited = settle_before_placing(); // placement.hpp: settle, then allocate
+    if (report)
+        report->settle_ms = waited;
     return draw(out, bytes);
 }
 

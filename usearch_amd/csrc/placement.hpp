@@ -43,6 +43,7 @@ struct placement_t {
     float judge_ms[placement_max_draws_k] = {0};     ///< trial i: the candidate's milliseconds over the launch's first queries
     float incumbent_ms[placement_max_draws_k] = {0}; ///< trial i: the incumbent's milliseconds over the same queries
     float probe_ms = 0.f;                            ///< wall time the trials have cost, allocation and copies included
+    float settle_ms = 0.f;                           ///< what the allocation of the matrix waited for freed frames to come back
 };
 
 /**
@@ -59,6 +60,22 @@ hipError_t block_malloc(void** out, std::size_t bytes);
 
 /// Releases what `placed_malloc` returned (some placements are mapped through the virtual-memory API, not `hipMalloc`).
 void placed_free(void* pointer);
+
+/**
+ *  SETTLE, THEN ALLOCATE (round 6: the deterministic form of round 5's lever). The driver hands a freed block's frames back to its
+ *  allocator 0.3 … 1 s after the free; an array of gigabytes allocated inside that window lands on other frames than the ones the
+ *  driver prefers when everything is free — and those are the fast ones (profiles/r05_placement/README.md §2: with one second between
+ *  a free and the next allocation every copy of the headline index ran at the best level, four of four; without it every other one).
+ *  So every release of a large block through this library is time-stamped (`note_release`; a host that frees device memory through
+ *  another allocator — torch's `empty_cache()` — says so with `usearch_amd_note_device_free`), and `placed_malloc` of an array of
+ *  at least USEARCH_AMD_PLACEMENT_MIN_BYTES waits until USEARCH_AMD_SETTLE_MS (default 1000; 0 = never wait) have passed since
+ *  the last one. At most one second, at load time, and only when something big was freed just before.
+ */
+void note_release(std::size_t bytes);
+/// Waits out what is left of the settle window; returns the milliseconds waited (0 when nothing was released lately).
+float settle_before_placing();
+/// Milliseconds `settle_before_placing` has waited in this process so far, and how often it had to.
+void settle_totals(float* milliseconds, std::uint32_t* waits);
 
 /// The probe alone: GB/s of a dependency-free gather of random `row_bytes`-byte rows of `base[0 .. bytes)`.
 hipError_t gather_probe(const void* base, std::size_t bytes, std::size_t row_bytes, float* gbps);

@@ -51,7 +51,7 @@ class Stats(C.Structure):
     _fields_ = [("passes", C.c_uint32), ("retried_lds", C.c_uint32), ("retried_global", C.c_uint32),
                 ("kernel_ms", C.c_float), ("mode", C.c_uint32), ("grid", C.c_uint32), ("lds_bytes", C.c_uint32),
                 ("frontier", C.c_uint32), ("variant", C.c_uint32), ("tail_idle", C.c_float), ("span_ms", C.c_float),
-                ("top_cells", C.c_uint32)]
+                ("top_cells", C.c_uint32), ("probe_mode", C.c_uint32), ("seen_cells", C.c_uint32), ("claim_bits", C.c_uint32)]
 
 
 class BuildConfig(C.Structure):
@@ -80,7 +80,8 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_snapshot_from_parts",
     "usearch_amd_snapshot_free", "usearch_amd_snapshot_size", "usearch_amd_snapshot_dimensions",
     "usearch_amd_snapshot_connectivity", "usearch_amd_snapshot_max_level", "usearch_amd_snapshot_bytes_per_vector",
-    "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_placement", "usearch_amd_snapshot_placement_incumbents", "usearch_amd_snapshot_gather_probe", "usearch_amd_snapshot_translation_probe", "usearch_amd_snapshot_latency_probe",
+    "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_placement", "usearch_amd_snapshot_placement_incumbents",
+    "usearch_amd_note_device_free", "usearch_amd_settle", "usearch_amd_snapshot_settle_ms", "usearch_amd_snapshot_gather_probe", "usearch_amd_snapshot_translation_probe", "usearch_amd_snapshot_latency_probe",
     "usearch_amd_snapshot_scalar_kind",
     "usearch_amd_snapshot_metric_kind", "usearch_amd_snapshot_lanes_per_row", "usearch_amd_snapshot_inline_rows",
     "usearch_amd_search_many",
@@ -152,6 +153,12 @@ def library() -> C.CDLL:
         f.argtypes = [C.c_void_p]
     L.usearch_amd_snapshot_placement_incumbents.restype = None
     L.usearch_amd_snapshot_placement_incumbents.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.usearch_amd_note_device_free.restype = None
+    L.usearch_amd_note_device_free.argtypes = []
+    L.usearch_amd_settle.restype = C.c_float
+    L.usearch_amd_settle.argtypes = []
+    L.usearch_amd_snapshot_settle_ms.restype = C.c_float
+    L.usearch_amd_snapshot_settle_ms.argtypes = [C.c_void_p]
     L.usearch_amd_snapshot_placement.restype = None
     L.usearch_amd_snapshot_placement.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                                  C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -417,7 +424,8 @@ class Index:
         library().usearch_amd_snapshot_placement(self._handle, C.byref(draws), C.byref(kept), rates, C.byref(probe_ms))
         library().usearch_amd_snapshot_placement_incumbents(self._handle, incumbents)
         shown = min(int(draws.value), 8)
-        return {"draws": int(draws.value), "kept": int(kept.value), "probe_ms": round(float(probe_ms.value), 2),
+        return {"settle_ms": round(float(library().usearch_amd_snapshot_settle_ms(self._handle)), 1),
+                "draws": int(draws.value), "kept": int(kept.value), "probe_ms": round(float(probe_ms.value), 2),
                 "judge_ms": [round(float(rates[i]), 3) for i in range(shown)],
                 "incumbent_ms": [round(float(incumbents[i]), 3) for i in range(shown)]}
 
@@ -805,6 +813,17 @@ def merge_many_device(distances_ptr: int, keys_ptr: int, counts_ptr: int, shards
                                             C.c_void_p(out_keys_ptr), C.c_void_p(out_counts_ptr), C.c_void_p(stream),
                                             C.byref(err))
     _raise(err, "usearch_amd_merge_many_device")
+
+
+def note_device_free() -> None:
+    """Tells the engine that the host just released device memory through another allocator (`torch.cuda.empty_cache()`): the next
+    loader or builder waits out the driver's settle window before it places its matrix (csrc/placement.hpp)."""
+    library().usearch_amd_note_device_free()
+
+
+def settle() -> float:
+    """Waits out what is left of the settle window (at most USEARCH_AMD_SETTLE_MS = 1000); returns the milliseconds waited."""
+    return float(library().usearch_amd_settle())
 
 
 def device_count() -> int:
