@@ -125,11 +125,11 @@ USEARCH_AMD_EXPORT size_t usearch_amd_snapshot_device_bytes(usearch_amd_snapshot
  *  USEARCH_AMD_PLACEMENT_DRAWS = 8 trials, 1 = off, ended early by three wins of the incumbent in a row, reopened for three more —
  *  twice at most — by a launch more than twice as wide as the last trial's: a host that tunes its expansion walks up; arrays under
  *  USEARCH_AMD_PLACEMENT_MIN_BYTES = 1 GiB stay where they are). `*draws` = trials made so far, `*kept` = how many moved the
- *  matrix, `judge_ms[i]` / `incumbent_ms[i]` = the candidate's / the incumbent's milliseconds in trial i (up to 8 each),
- *  `*probe_ms` = what the trials have cost in all. */
+ *  matrix, `judge_ms[i]` / `incumbent_ms[i]` = the candidate's / the incumbent's milliseconds in trial i (up to 8 each; either may
+ *  be null), `*probe_ms` = what the trials have cost in all. Since round 6 the trials are OFF unless USEARCH_AMD_PLACEMENT_DRAWS
+ *  = 2 … 8 asks for them: the matrix is placed once, after the settle window (below). */
 USEARCH_AMD_EXPORT void usearch_amd_snapshot_placement(usearch_amd_snapshot_t snapshot, uint32_t* draws, uint32_t* kept,
-                                                       float* judge_ms, float* probe_ms);
-USEARCH_AMD_EXPORT void usearch_amd_snapshot_placement_incumbents(usearch_amd_snapshot_t snapshot, float* incumbent_ms);
+                                                       float* judge_ms, float* incumbent_ms, float* probe_ms);
 /**
  *  Settle, then allocate (csrc/placement.hpp; round 6). The driver hands a freed block's frames back to its allocator 0.3 … 1 s
  *  after the free, and a multi-gigabyte array allocated inside that window lands on other — slower — frames than the ones the driver
@@ -143,17 +143,21 @@ USEARCH_AMD_EXPORT void usearch_amd_snapshot_placement_incumbents(usearch_amd_sn
 USEARCH_AMD_EXPORT void usearch_amd_note_device_free(void);
 USEARCH_AMD_EXPORT float usearch_amd_settle(void);
 USEARCH_AMD_EXPORT float usearch_amd_snapshot_settle_ms(usearch_amd_snapshot_t snapshot);
-/** The placement probe alone, on the resident matrix or a part of it: GB/s of a dependency-free gather of random stored rows
- *  among rows [first_row, first_row + rows) (`rows` = 0: to the end). Diagnostics (scripts/placement_study.py). */
-USEARCH_AMD_EXPORT float usearch_amd_snapshot_gather_probe(usearch_amd_snapshot_t snapshot, uint64_t first_row, uint64_t rows,
-                                                           usearch_amd_error_t* error);
-/** A probe of the address-translation path over the resident matrix: million touches per second of random 4-KB pages, 16 bytes
- *  each (csrc/placement.hpp `translation_probe`). Diagnostics. */
-USEARCH_AMD_EXPORT float usearch_amd_snapshot_translation_probe(usearch_amd_snapshot_t snapshot, usearch_amd_error_t* error);
-/** Nanoseconds per dependent read of a random stored row (`which` = 0) or of a random level-0 neighbour list (1): chains of reads
- *  in which the next address depends on the bytes just read, few enough in flight that nothing queues (csrc/placement.hpp
- *  `latency_probe`). Diagnostics. */
-USEARCH_AMD_EXPORT float usearch_amd_snapshot_latency_probe(usearch_amd_snapshot_t snapshot, int which, usearch_amd_error_t* error);
+/** The HBM-resident arrays of a snapshot, read-only, for a host's own kernels over them (csrc/common.hpp `snapshot_view_t`): the
+ *  padded matrix of stored rows `vectors[size][row_stride]`, the level-0 lists `level0[size][2 × connectivity]` (u32 slots,
+ *  0xFFFFFFFF = empty cell) and the keys `keys[size]` (u64). Valid until the snapshot is freed or — for an index under
+ *  construction — extended. */
+typedef struct usearch_amd_arrays_t {
+    void const* vectors;
+    uint32_t const* level0;
+    uint64_t const* keys;
+    uint64_t size;
+    uint32_t row_stride;
+    uint32_t level0_cells;
+    int device;
+    uint32_t reserved;
+} usearch_amd_arrays_t;
+USEARCH_AMD_EXPORT void usearch_amd_snapshot_arrays(usearch_amd_snapshot_t snapshot, usearch_amd_arrays_t* arrays);
 /** Storage scalar kind (C enumerator) and metric kind (`usearch_metric_kind_t` value, c/usearch.h:40-52). */
 USEARCH_AMD_EXPORT int usearch_amd_snapshot_scalar_kind(usearch_amd_snapshot_t snapshot);
 USEARCH_AMD_EXPORT int usearch_amd_snapshot_metric_kind(usearch_amd_snapshot_t snapshot);

@@ -8,12 +8,15 @@
  *
  *    search        `usearch_search`, `usearch_filtered_search`, `usearch_exact_search` and the additive batched
  *                  `usearch_search_many` run on the MI355X through an HBM snapshot of the index (include/usearch_amd.h).
- *                  A filter callback is a host function: it is evaluated once per member into one bit per slot, which the
- *                  traversal applies where the reference applies the predicate (index.hpp:4200-4205, 4236-4240).
+ *                  A filter callback is a host function: it is evaluated lazily, for the members the walk wants to admit —
+ *                  about as many calls as the reference makes (index.hpp:4200-4205, 4236-4240; see "filtered search" below).
  *    construction  `usearch_add` stages the vector on the host (and, like the reference, fails without reserved room:
- *                  index.hpp:2812-2818); the next search / save links what was staged on the device — everything in one batched
- *                  build the first time, afterwards only the members added since (the graph is extended in place, the batch-
- *                  deferred form of index.hpp:2780-2879). `usearch_remove` writes the tombstone and `usearch_rename` the new key
+ *                  index.hpp:2812-2818) and links it on the device before it returns WHEN SEARCHES INTERLEAVE WITH ADDS (any
+ *                  search arrived since the add before: a reader racing a writer finds a member the moment its `add` is back,
+ *                  as in the reference); adds in a row with nobody searching are linked together by the next search / save —
+ *                  everything in one batched build the first time, afterwards only the members added since (the graph is
+ *                  extended in place, the batch-deferred form of index.hpp:2780-2879). USEARCH_AMD_IMMEDIATE_ADD = 1 / 0
+ *                  forces either behaviour. `usearch_remove` writes the tombstone and `usearch_rename` the new key
  *                  in place in HBM; only `usearch_change_metric_kind` costs a rebuild. Limits of the device builder are said
  *                  at `usearch_init`: connectivity ≤ 64 (base layer ≤ 128), expansion_add ≤ 1024.
  *    concurrency   searches share the index (one engine workspace per call in flight, `usearch_change_threads_search` sizes
@@ -185,21 +188,28 @@ USEARCH_EXPORT void usearch_search_exact_many(usearch_index_t index, void const*
                                               size_t* counts, usearch_error_t* error);
 /* ---- filtered search without a callback per member ------------------------------------------------------------------------
  *  `usearch_filtered_search` (c/usearch.h:391-395 → c/lib.cpp:413-429 → index_dense.hpp:774-779, 2071-2084) takes a host callback.
- *  The reference runs it inside the traversal — a few thousand calls per query (index.hpp:4200-4205, 4236-4240). A host function
- *  cannot run on the device, so this library evaluates it over EVERY member first (one bit per slot, which the kernels then test
- *  where the reference calls the predicate): O(members) callbacks per `usearch_filtered_search` call. That entry point stays, for
- *  compatibility; a caller that searches more than once under one predicate, or that can say what the predicate IS, makes a
- *  filter instead: a bitmap built once (by a kernel over the keys in HBM for ranges and key sets) that any number of batches
- *  reuse. A filter describes the index as it was when the filter was made: after `usearch_add / remove / rename / load / view /
- *  clear / usearch_gpu_release` searches under it fail with "The index changed since the filter was made".
+ *  The reference runs it inside the traversal, for the members it is about to admit to the result buffer — a few hundred to a few
+ *  thousand calls per query (index.hpp:4200-4205, 4236-4240). A host function cannot run on the device; this library evaluates it
+ *  LAZILY (round 6, csrc/dropin.hip `lazy_predicate_t`): the walk runs with two bits per slot in HBM — "the host has answered for
+ *  this member" and its answer — treats a member it wants to admit that is not known yet as allowed while posting its key to an ask
+ *  list; the host answers what was asked and the query runs again, until a run asks nothing. That run has seen the true predicate
+ *  wherever it looked: it is the reference's traversal (same keys, distances, counters). Every member is asked about at most once
+ *  per call, and about as many as the reference asks about (tests/test_gpu_dropin.py: no more than twice its count at
+ *  selectivities 1 … 1/20). A predicate that rejects nearly everything keeps pushing the walk outward: after 12 runs the rest is
+ *  evaluated for every member (`USEARCH_AMD_FILTER_LAZY=0`, read at `usearch_init`, does that from the start: one callback per
+ *  member per call, the behaviour up to round 5). A caller that searches more than once under one predicate, or that can say what
+ *  the predicate IS, still does better with a filter made once: a bitmap (built by a kernel over the keys in HBM for ranges and key
+ *  sets) that any number of batches reuse. A filter describes the index as it was when the filter was made: after `usearch_add /
+ *  remove / rename / load / view / clear / usearch_gpu_release` searches under it fail with "The index changed since the filter was
+ *  made".
  *
- *  What the callback must be, either way: a PURE function of the key for the duration of the call (it is asked about members in
- *  slot order, before the walk starts, including members the reference's walk would never have shown it; it must not call back
- *  into the index). For binaries that cannot be changed, `USEARCH_AMD_FILTER_MEMO=1` in the environment (read at `usearch_init`)
- *  keeps the bitmap of the last eight (callback, filter_state pointer) pairs per index version: a repeated
+ *  What the callback must be: a PURE function of the key for the duration of the call (a provisional run may show it a member the
+ *  reference's walk would not have; it must not call back into the index). For binaries that cannot be changed and whose predicate
+ *  stays the same between calls, `USEARCH_AMD_FILTER_MEMO=1` in the environment (read at `usearch_init`) evaluates it for every
+ *  member once and keeps the bitmap of the last eight (callback, filter_state pointer) pairs per index version: a repeated
  *  `usearch_filtered_search` under the same pair then makes no callback at all. That asks for MORE than purity per call — the
- *  predicate must not change while its state pointer stays the same (a threshold edited in place behind the same pointer would
- *  not be seen) — hence opt-in. Every mutation of the index forgets the remembered bitmaps.
+ *  predicate must not change while its state pointer stays the same — hence opt-in. Every mutation of the index forgets the
+ *  remembered bitmaps.
  * ---------------------------------------------------------------------------------------------------------------------------- */
 typedef void* usearch_filter_t;
 

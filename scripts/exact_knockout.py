@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """scripts/exact_knockout.py — where the wide exact tile's time goes, by taking parts of it out (timing only: with any part out the
-results are wrong). `USEARCH_AMD_EXACT_KNOCKOUT` is read per launch (csrc/exact_tiled.hip: 1 = no fold, 2 = no fills after the
+results are wrong). Needs a library built with the knock-outs compiled in — `make -C usearch_amd/csrc EXTRA=-DUSEARCH_AMD_EXPERIMENT_EXACT_KNOCKOUT
+OUT=$PWD/usearch_amd/lib_knockout OBJ=$PWD/usearch_amd/lib_knockout/obj`, loaded with USEARCH_AMD_LIBRARY=usearch_amd/lib_knockout/libusearch_amd.so; the
+product library compiles them away. `USEARCH_AMD_EXACT_KNOCKOUT` is read per launch (csrc/exact_tiled.hip: 1 = no fold, 2 = no fills after the
 prologue's, 4 = no wait for the fills and no barrier, 8 = thresholds refreshed once, 16 = no per-block tests). Prints kernel ms and T(FL)OP/s per combination, same process, same data.
 
     python scripts/exact_knockout.py [--n 10000000] [--dim 768] [--queries 10000] [--dtype f16] [--combos 0,1,4,5,3,7]

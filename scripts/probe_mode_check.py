@@ -32,16 +32,22 @@ def main() -> None:
         data = bench.synthetic_vectors_device(n, dim, dtype, 42, device)
         built = usearch_amd.build(None, metric, dtype, device_pointer=data.data_ptr(), count=n, stride=data.stride(0), ndim=dim)
         index = built.index
-        queries = bench.synthetic_vectors_device(max(args.queries, args.timed_queries), dim, dtype, 43, device).cpu().numpy().view(bench.NUMPY_STORAGE[dtype])
+        count = max(args.queries, args.timed_queries)
+        queries_dev = bench.synthetic_vectors_device(count, dim, dtype, 43, device)
+        queries = queries_dev.cpu().numpy().view(bench.NUMPY_STORAGE[dtype])
+        outs = [torch.zeros((count, 10), dtype=torch.int64, device=device), torch.zeros((count, 10), dtype=torch.float32, device=device)] + \
+               [torch.zeros(count, dtype=torch.int64, device=device) for _ in range(3)]
         answers = {}
         for mode in args.modes:
             os.environ["USEARCH_AMD_PROBE_MODE"] = str(mode)
             got = index.search(queries[:args.queries], 10, expansion=expansion, dtype=dtype, tuning=Tuning(mode=2))
             times = []
-            for _ in range(4):
-                timed = index.search(queries[:args.timed_queries], 10, expansion=expansion, dtype=dtype, tuning=Tuning(mode=2))
-                times.append(timed.stats.kernel_ms)
-            answers[mode] = (got, float(np.min(times[1:])), timed.stats)
+            for _ in range(5):
+                stats = index.search_device(queries_dev.data_ptr(), args.timed_queries, queries_dev.stride(0), 10, expansion, outs[0].data_ptr(),
+                                            outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), outs[4].data_ptr(), timed=True,
+                                            tuning=Tuning(mode=2))
+                times.append(stats.kernel_ms)
+            answers[mode] = (got, float(np.min(times[1:])), stats)
         base = answers[args.modes[0]][0]
         for mode in args.modes:
             got, ms, stats = answers[mode]

@@ -476,8 +476,9 @@ def test_filtered_search_remembers_a_pure_predicate_when_told_to(lib, monkeypatc
     even_c, third_c = FILTER(even), FILTER(third)
     keys, distances = np.zeros(k, dtype=np.uint64), np.zeros(k, dtype=np.float32)
     answers = {}
-    for memo in ("0", "1"):
-        monkeypatch.setenv("USEARCH_AMD_FILTER_MEMO", memo)
+    for memo in ("0", "1", "lazy"):
+        monkeypatch.setenv("USEARCH_AMD_FILTER_MEMO", "1" if memo == "1" else "0")
+        monkeypatch.setenv("USEARCH_AMD_FILTER_LAZY", "1" if memo == "lazy" else "0")
         index, _ = filled_index(lib, n, dims, options=options, data=data)
         per_call = []
         for callback in (even_c, even_c, third_c, even_c):
@@ -499,12 +500,56 @@ def test_filtered_search_remembers_a_pure_predicate_when_told_to(lib, monkeypatc
                                                 C.byref(err))
             ok(err)
             assert calls[0] == n + 1 and found == k and n in keys.tolist()
-        else:
+        elif memo == "0":
             assert [c for c, _, _ in per_call] == [n, n, n, n]
+        else:  # the default: only the members the walk wants to admit are asked about, afresh in every call
+            assert all(0 < c < n // 3 for c, _, _ in per_call), [c for c, _, _ in per_call]
         lib.usearch_free(index, C.byref(err))
-    for (_, keys_off, distances_off), (_, keys_on, distances_on) in zip(answers["0"], answers["1"]):
-        assert np.array_equal(keys_off, keys_on) and np.array_equal(distances_off, distances_on)
+    for other in ("1", "lazy"):
+        for (_, keys_off, distances_off), (_, keys_on, distances_on) in zip(answers["0"], answers[other]):
+            assert np.array_equal(keys_off, keys_on) and np.array_equal(distances_off, distances_on)
     assert all(key % 2 == 0 for key in answers["1"][1][1]) and all(key % 3 == 0 for key in answers["1"][2][1])
+
+
+@pytest.mark.parametrize("metric,dtype", [("l2sq", "i8"), ("cos", "f32")])
+def test_filtered_search_calls_back_like_the_reference(lib, reference, metric, dtype):
+    """c/lib.cpp:413-429 → index.hpp:4200-4205, 4236-4240: the reference calls the predicate for the members its traversal is about
+    to admit to `top`, a few hundred per query. The drop-in (no environment switch) evaluates the callback lazily — provisional runs
+    that ask the host about what they met, until a run asks nothing (dropin.hip `lazy_predicate_t`): the same results as the
+    reference's `usearch_filtered_search` on the same image, and no more than twice its callbacks, at every selectivity (the
+    integer-valued pair: keys and distance bits identical)."""
+    err = C.c_char_p()
+    n, dims, k = 20_000, 96, 10
+    image, vectors, theirs = util.build_image(n, dims, metric, dtype, seed=31)
+    queries = util.make_vectors(12, dims, dtype, seed=32)
+    index = lib.usearch_init(None, C.byref(err))
+    lib.usearch_view_buffer(index, ptr(image), image.size, C.byref(err))
+    ok(err)
+    keys, distances = np.zeros(k, dtype=np.uint64), np.zeros(k, dtype=np.float32)
+    for modulus in (1, 2, 5, 20):  # selectivity 1, 1/2, 1/5, 1/20
+        ours, reference_calls = [0], [0]
+
+        def allowed(key, state, modulus=modulus):
+            ours[0] += 1
+            return int(key % modulus == 0)
+
+        def reference_allowed(key, modulus=modulus):
+            reference_calls[0] += 1
+            return key % modulus == 0
+        callback = FILTER(allowed)
+        for query in queries:
+            ours[0] = reference_calls[0] = 0
+            found = lib.usearch_filtered_search(index, ptr(query), SCALAR[dtype], k, callback, None, ptr(keys), ptr(distances), C.byref(err))
+            ok(err)
+            rfound, rkeys, rdistances = theirs.filtered_search(query, k, reference_allowed, dtype=dtype)
+            assert found == rfound and all(key % modulus == 0 for key in keys[:found].tolist())
+            if util.exact_pair(metric, dtype):
+                assert np.array_equal(keys[:found], rkeys[:found]) and util.same_float_bits(distances[:found], rdistances[:found])
+            else:
+                assert np.allclose(distances[:found], rdistances[:found], rtol=0, atol=util.tolerance(dtype))
+            assert 0 < ours[0] <= 2 * reference_calls[0], (modulus, ours[0], reference_calls[0])
+            assert ours[0] < n // 4, "the predicate must not be evaluated for every member"
+    lib.usearch_free(index, C.byref(err))
 
 
 def test_batch_and_buffers_match_the_reference(lib, reference):
@@ -604,13 +649,17 @@ def test_add_after_a_search_links_only_the_new_members(lib):
     lib.usearch_free(index, C.byref(err))
 
 
-@pytest.mark.parametrize("immediate", ["0", "1"])
+@pytest.mark.parametrize("immediate", ["auto", "0", "1"])
 def test_readers_racing_a_writer_find_what_was_added(lib, monkeypatch, immediate):
-    """index.hpp:2780-2879: a member is findable the moment `add` returns. The drop-in links staged members at the next search
-    (the default) or inside `usearch_add` itself (USEARCH_AMD_IMMEDIATE_ADD=1, read at `usearch_init`): either way four reader
-    threads racing one writer find every member whose `add` has returned, first and at distance zero."""
+    """index.hpp:2780-2879: a member is findable the moment `add` returns. The drop-in links staged members inside `usearch_add`
+    whenever searches interleave with adds (the default, "auto": readers are about), always (USEARCH_AMD_IMMEDIATE_ADD=1) or at the
+    next search (=0; read at `usearch_init`): every way four reader threads racing one writer find every member whose `add` has
+    returned, first and at distance zero."""
     import threading
-    monkeypatch.setenv("USEARCH_AMD_IMMEDIATE_ADD", immediate)
+    if immediate == "auto":
+        monkeypatch.delenv("USEARCH_AMD_IMMEDIATE_ADD", raising=False)
+    else:
+        monkeypatch.setenv("USEARCH_AMD_IMMEDIATE_ADD", immediate)
     err = C.c_char_p()
     dimensions, first, more = 24, 1500, 120
     options = create_options(dimensions, metric_kind=METRIC["l2sq"], connectivity=16, expansion_add=128, expansion_search=64)

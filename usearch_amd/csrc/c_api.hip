@@ -223,42 +223,17 @@ size_t usearch_amd_snapshot_max_level(usearch_amd_snapshot_t s) { return as_snap
 size_t usearch_amd_snapshot_bytes_per_vector(usearch_amd_snapshot_t s) { return as_snapshot(s)->view().bytes_per_vector; }
 size_t usearch_amd_snapshot_row_stride(usearch_amd_snapshot_t s) { return as_snapshot(s)->view().row_stride; }
 size_t usearch_amd_snapshot_device_bytes(usearch_amd_snapshot_t s) { return as_snapshot(s)->device_bytes(); }
-float usearch_amd_snapshot_gather_probe(usearch_amd_snapshot_t s, uint64_t first_row, uint64_t rows, usearch_amd_error_t* error) {
+void usearch_amd_snapshot_arrays(usearch_amd_snapshot_t s, usearch_amd_arrays_t* out) {
+    if (!out)
+        return;
     const snapshot_view_t& view = as_snapshot(s)->view();
-    if (first_row >= view.size)
-        return 0.f;
-    if (!rows || first_row + rows > view.size)
-        rows = view.size - first_row;
-    float gbps = 0.f;
-    if (hipSetDevice(as_snapshot(s)->device()) != hipSuccess)
-        return 0.f;
-    const hipError_t e = gather_probe(view.vectors + first_row * view.row_stride, rows * view.row_stride, view.row_stride, &gbps);
-    if (e != hipSuccess)
-        fail(error, hipGetErrorString(e));
-    return gbps;
+    *out = usearch_amd_arrays_t{};
+    out->vectors = view.vectors, out->level0 = view.nbr0, out->keys = view.keys;
+    out->size = view.size, out->row_stride = view.row_stride, out->level0_cells = view.m0;
+    out->device = as_snapshot(s)->device();
 }
-float usearch_amd_snapshot_translation_probe(usearch_amd_snapshot_t s, usearch_amd_error_t* error) {
-    const snapshot_view_t& view = as_snapshot(s)->view();
-    float rate = 0.f;
-    if (hipSetDevice(as_snapshot(s)->device()) != hipSuccess)
-        return 0.f;
-    const hipError_t e = translation_probe(view.vectors, (std::size_t)view.size * view.row_stride, &rate);
-    if (e != hipSuccess)
-        fail(error, hipGetErrorString(e));
-    return rate;
-}
-float usearch_amd_snapshot_latency_probe(usearch_amd_snapshot_t s, int which, usearch_amd_error_t* error) {
-    const snapshot_view_t& view = as_snapshot(s)->view();
-    float nanoseconds = 0.f;
-    if (hipSetDevice(as_snapshot(s)->device()) != hipSuccess)
-        return 0.f;
-    const hipError_t e = which ? latency_probe(view.nbr0, (std::size_t)view.size * view.m0 * 4, (std::size_t)view.m0 * 4, &nanoseconds)
-                               : latency_probe(view.vectors, (std::size_t)view.size * view.row_stride, view.row_stride, &nanoseconds);
-    if (e != hipSuccess)
-        fail(error, hipGetErrorString(e));
-    return nanoseconds;
-}
-void usearch_amd_snapshot_placement(usearch_amd_snapshot_t s, uint32_t* draws, uint32_t* kept, float* judge_ms, float* probe_ms) {
+void usearch_amd_snapshot_placement(usearch_amd_snapshot_t s, uint32_t* draws, uint32_t* kept, float* judge_ms, float* incumbent_ms,
+                                    float* probe_ms) {
     const placement_t& placement = as_snapshot(s)->placement();
     if (draws)
         *draws = placement.draws;
@@ -267,13 +242,11 @@ void usearch_amd_snapshot_placement(usearch_amd_snapshot_t s, uint32_t* draws, u
     if (judge_ms)
         for (int i = 0; i < placement_max_draws_k; ++i)
             judge_ms[i] = placement.judge_ms[i];
+    if (incumbent_ms)
+        for (int i = 0; i < placement_max_draws_k; ++i)
+            incumbent_ms[i] = placement.incumbent_ms[i];
     if (probe_ms)
         *probe_ms = placement.probe_ms;
-}
-void usearch_amd_snapshot_placement_incumbents(usearch_amd_snapshot_t s, float* incumbent_ms) {
-    const placement_t& placement = as_snapshot(s)->placement();
-    for (int i = 0; i < placement_max_draws_k; ++i)
-        incumbent_ms[i] = placement.incumbent_ms[i];
 }
 void usearch_amd_note_device_free(void) { note_release((std::size_t)1 << 40); }
 float usearch_amd_settle(void) { return settle_before_placing(); }

@@ -133,6 +133,15 @@ struct search_args_t {
                                     ///< `beam_level` and report the member it reached (one result per query)
     const std::uint32_t* allow_bits; ///< optional: one bit per slot, 0 = the caller's predicate rejects that member
                                      ///< (`usearch_filtered_search`, index_dense.hpp:2071-2081)
+    /// A predicate the host evaluates LAZILY (`usearch_filtered_search`'s callback, dropin.hip): `known_bits` says which members the
+    /// host has been asked about already (their answer is in `allow_bits`); a member the walk wants to admit to `top` that is not
+    /// known yet is posted to `ask_slots` / `ask_keys` (cursor `ask_cursor`, room `ask_cap`) and treated as allowed — the host
+    /// evaluates what was asked and runs the query again until a run asks nothing: that run IS the reference's traversal.
+    const std::uint32_t* known_bits;
+    std::uint32_t* ask_slots;
+    std::uint64_t* ask_keys;
+    std::uint32_t* ask_cursor;
+    std::uint32_t ask_cap;
     std::uint32_t exclude_own;       ///< 1 = query q's own stored row (`query_ids[q]`) routes but never becomes a result candidate:
                                      ///< `search_to_update_` (index.hpp:4087-4170), the insertion search of a member that is
                                      ///< being re-linked in place
@@ -157,7 +166,5 @@ enum probe_mode_t : std::uint32_t {
     probe_plain_k = 2,      ///< no atomic: a load that bypasses the vector cache, a plain store nobody waits for, and the claims of
                             ///< one instruction's lanes on the same cell settled by an LDS bit per cell
 };
-/// What the engine picks unless USEARCH_AMD_PROBE_MODE says otherwise (engine.hip `run_ladder`).
-constexpr std::uint32_t default_probe_mode_k = probe_swap_k;
 
 } // namespace usearch_amd

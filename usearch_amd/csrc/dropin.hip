@@ -24,6 +24,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -164,11 +165,23 @@ struct index_t {
     /// because it needs more than the ABI promises: the predicate must be a pure function of the key for as long as the state
     /// POINTER stays the same (the reference calls it afresh, a few thousand times per query: c/lib.cpp:413-429, index.hpp:4200-4205).
     bool filter_memo = env_size("USEARCH_AMD_FILTER_MEMO", 0) != 0;
-    /// `usearch_add` under USEARCH_AMD_IMMEDIATE_ADD=1 (read at `usearch_init`): the member is linked on the device before the call
-    /// returns, as the reference's `add` links it before it returns (index.hpp:2780-2879) — a reader racing a writer then sees what
-    /// it would see there. Off by default: a launch sequence per added vector where the batch-deferred form links thousands per
-    /// launch (bulk-load-then-search is what the device is for).
-    bool immediate_add = env_size("USEARCH_AMD_IMMEDIATE_ADD", 0) != 0;
+    /// `usearch_filtered_search` evaluates its callback LAZILY (the default; USEARCH_AMD_FILTER_LAZY=0, read at `usearch_init`, goes
+    /// back to one callback per member per call): only for the members the walk wants to admit to `top`, as the reference does
+    /// (c/lib.cpp:413-429 → index.hpp:4200-4205, 4236-4240) — see `lazy_predicate_t`.
+    bool filter_lazy = env_size("USEARCH_AMD_FILTER_LAZY", 1) != 0;
+    /// When `usearch_add` links the member on the device (USEARCH_AMD_IMMEDIATE_ADD, read at `usearch_init`). The reference's `add`
+    /// links before it returns (index.hpp:2780-2879): a reader racing a writer finds the member the moment `add` is back.
+    ///   unset / "auto": an `add` links at once WHEN SEARCHES INTERLEAVE WITH ADDS — any search arrived on this index since the add
+    ///                   before (or is waiting for the lock right now) — so a host that mixes readers and writers sees the
+    ///                   reference's visibility without any switch; a bulk loader (adds in a row, nobody searching) keeps the
+    ///                   batch-deferred form, thousands of members per launch (what the device is for);
+    ///   "1": every add links at once;   "0": never (the next search / save links everything pending).
+    int immediate_add = [] {
+        const char* text = std::getenv("USEARCH_AMD_IMMEDIATE_ADD");
+        return !text || !*text || !std::strcmp(text, "auto") ? 2 : std::atoi(text) != 0 ? 1 : 0;
+    }();
+    std::atomic<std::uint64_t> searches_arrived{0}; ///< bumped by every search BEFORE it asks for the lock
+    std::uint64_t searches_at_last_add = 0;         ///< … as of the add before (under the unique lock)
     struct filter_memo_t {
         int (*filter)(usearch_key_t, void*) = nullptr;
         void* state = nullptr;
@@ -407,6 +420,78 @@ static void callback_bits(index_t& index, int (*filter)(usearch_key_t key, void*
         if ((*member_keys)[slot] != free_key_k && filter((*member_keys)[slot], filter_state))
             bits[slot >> 5] |= 1u << (slot & 31);
 }
+
+/**
+ *  The host callback of `usearch_filtered_search`, evaluated lazily. The reference calls the predicate inside the traversal, for the
+ *  members it is about to admit to `top` — a few hundred to a few thousand per query (index.hpp:4200-4205, 4236-4240). A host
+ *  function cannot run inside a kernel, and evaluating it for EVERY member per call (what `callback_bits` does: 10 M callbacks on
+ *  the headline index) is not what an unchanged binary expects. So the device keeps two bits per slot — `known` (the host has
+ *  answered for this member) and `allow` (its answer) — and the walk treats a member it wants to admit that is not known yet as
+ *  allowed while posting (slot, key) to an ask list. The host answers what was asked and runs the query AGAIN; a run that asks
+ *  nothing has seen the true predicate wherever it looked: it is the reference's traversal, bit for bit (keys, distances, both
+ *  counters). Runs before it are provisional and discarded. Every member is asked about once at most; the runs converge because
+ *  each one is exact up to the first member it had to guess. After `rounds_limit_k` runs (a predicate that rejects nearly
+ *  everything keeps pushing the walk outward) the rest is evaluated for every member, as before.
+ */
+struct lazy_predicate_t {
+    static constexpr std::uint32_t ask_cap_k = 1u << 16;
+    static constexpr int rounds_limit_k = 12;
+    std::uint32_t *d_allow = nullptr, *d_known = nullptr, *d_ask_slots = nullptr, *d_cursor = nullptr;
+    std::uint64_t* d_ask_keys = nullptr;
+    std::vector<std::uint32_t> allow, known, ask_slots;
+    std::vector<std::uint64_t> ask_keys;
+    std::size_t words = 0;
+    std::size_t callbacks = 0;
+
+    ~lazy_predicate_t() {
+        for (void* p : {(void*)d_allow, (void*)d_known, (void*)d_ask_slots, (void*)d_cursor, (void*)d_ask_keys})
+            if (p)
+                (void)hipFree(p);
+    }
+    const char* open(std::size_t members) {
+        words = (members + 31) / 32 + 1;
+        allow.assign(words, 0u), known.assign(words, 0u);
+        if (hipMalloc((void**)&d_allow, words * 4) != hipSuccess || hipMalloc((void**)&d_known, words * 4) != hipSuccess ||
+            hipMalloc((void**)&d_ask_slots, ask_cap_k * 4) != hipSuccess || hipMalloc((void**)&d_ask_keys, ask_cap_k * 8) != hipSuccess ||
+            hipMalloc((void**)&d_cursor, 4) != hipSuccess || hipMemset(d_allow, 0, words * 4) != hipSuccess ||
+            hipMemset(d_known, 0, words * 4) != hipSuccess)
+            return (void)hipGetLastError(), "Out of device memory for the predicate's bitmaps";
+        return nullptr;
+    }
+    void fill(search_extras_t& extras) const {
+        extras.allow_bits = d_allow, extras.known_bits = d_known;
+        extras.ask_slots = d_ask_slots, extras.ask_keys = d_ask_keys, extras.ask_cursor = d_cursor, extras.ask_cap = ask_cap_k;
+    }
+    const char* before_run() { return hipMemset(d_cursor, 0, 4) == hipSuccess ? nullptr : "hipMemset failed"; }
+    /// What the run asked: answers it on the host, uploads the two bitmaps. `*asked` = members newly answered (0: the run is final);
+    /// `*overflow`: more was asked than the list holds.
+    const char* after_run(int (*filter)(usearch_key_t, void*), void* state, std::size_t* asked, bool* overflow) {
+        std::uint32_t cursor = 0;
+        if (hipMemcpy(&cursor, d_cursor, 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return "Failed to read the ask list";
+        *asked = 0, *overflow = cursor > ask_cap_k;
+        if (!cursor)
+            return nullptr;
+        const std::uint32_t listed = std::min(cursor, ask_cap_k);
+        ask_slots.resize(listed), ask_keys.resize(listed);
+        if (hipMemcpy(ask_slots.data(), d_ask_slots, listed * 4ull, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(ask_keys.data(), d_ask_keys, listed * 8ull, hipMemcpyDeviceToHost) != hipSuccess)
+            return "Failed to read the ask list";
+        for (std::uint32_t i = 0; i < listed; ++i) {
+            const std::uint32_t slot = ask_slots[i], word = slot >> 5, bit = 1u << (slot & 31);
+            if (word >= words || (known[word] & bit))
+                continue; // two queries of a batch (or a re-run rung) asked about the same member
+            known[word] |= bit;
+            ++callbacks, ++*asked;
+            if (filter(ask_keys[i], state))
+                allow[word] |= bit;
+        }
+        if (hipMemcpy(d_allow, allow.data(), words * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_known, known.data(), words * 4, hipMemcpyHostToDevice) != hipSuccess)
+            return "Failed to upload the predicate's bitmaps";
+        return nullptr;
+    }
+};
 
 /// Brings the device index up to date and wraps what `make` builds over it. `make` gets the snapshot (never null).
 template <typename make_at> usearch_filter_t make_filter(usearch_index_t handle, usearch_error_t* error, make_at&& make) {
@@ -845,7 +930,10 @@ void usearch_add(usearch_index_t handle, usearch_key_t key, void const* vector, 
             index.lookup.emplace(key, (std::uint32_t)slot);
         // the device index, if there is one, stays: the next search links the members added since (builder_t::extend) — or this
         // call does, for hosts that want the reference's visibility (a member is findable the moment `add` returns)
-        if (index.immediate_add) {
+        const std::uint64_t arrived = index.searches_arrived.load(std::memory_order_acquire);
+        const bool readers_about = arrived != index.searches_at_last_add;
+        index.searches_at_last_add = arrived;
+        if (index.immediate_add == 1 || (index.immediate_add == 2 && readers_about)) {
             snapshot_t* device_index = nullptr;
             if (const char* e = index.ready(&device_index))
                 return fail(error, e);
@@ -880,6 +968,7 @@ static size_t search_shared(index_t& index, void const* queries, scalar_kind_t k
     if (!queries_count || !count)
         return 0;
     std::size_t result = 0;
+    index.searches_arrived.fetch_add(1, std::memory_order_acq_rel); // readers are about: `usearch_add` links at once (index_t::immediate_add)
     guarded(error, [&] {
         for (;;) {
             {
@@ -902,6 +991,7 @@ static size_t search_shared(index_t& index, void const* queries, scalar_kind_t k
                     std::vector<std::uint32_t> bits;
                     search_extras_t extras;
                     std::shared_ptr<filter_t> remembered; // keeps a memoised bitmap alive while this call reads it
+                    bool answered_lazily = false;
                     if (made) {
                         // the predicate is already a bitmap in HBM (usearch_filter_from_*): nothing per member happens here
                         if (made->index != &index || made->version != index.version)
@@ -934,11 +1024,39 @@ static size_t search_shared(index_t& index, void const* queries, scalar_kind_t k
                                 index.memos.swap(kept);
                             }
                             extras.allow_bits = remembered->bits();
+                        } else if (index.filter_lazy && device_index) {
+                            // the callback only for the members the walk wants to admit (`lazy_predicate_t`): provisional runs until
+                            // one asks nothing; that one is the answer
+                            lazy_predicate_t lazy;
+                            if (const char* e = lazy.open(index.size()))
+                                return fail(error, e);
+                            bool settled = false;
+                            for (int round = 0; round < lazy_predicate_t::rounds_limit_k && !settled; ++round) {
+                                search_extras_t lazy_extras;
+                                lazy.fill(lazy_extras);
+                                if (const char* e = lazy.before_run())
+                                    return fail(error, e);
+                                if (const char* e = device_index->search_host(queries, kind, queries_count, queries_stride, count,
+                                                                              index.expansion_search, out_keys, out_distances, found.data(),
+                                                                              visited.data(), computed.data(), search_tuning_t{}, nullptr,
+                                                                              nullptr, &lazy_extras))
+                                    return fail(error, e);
+                                std::size_t asked = 0;
+                                bool overflow = false;
+                                if (const char* e = lazy.after_run(filter, filter_state, &asked, &overflow))
+                                    return fail(error, e);
+                                settled = asked == 0 && !overflow;
+                            }
+                            answered_lazily = settled;
+                            if (!settled) // a predicate that keeps pushing the walk outward: every member, as before
+                                callback_bits(index, filter, filter_state, bits);
                         } else {
                             callback_bits(index, filter, filter_state, bits);
                         }
                     }
-                    if (!device_index) { // nothing indexed yet: index.hpp:3034-3037
+                    if (answered_lazily) {
+                        // the last provisional run asked nothing: its results are the answer
+                    } else if (!device_index) { // nothing indexed yet: index.hpp:3034-3037
                         pad_results(reinterpret_cast<usearch_key_t*>(out_keys), out_distances, queries_count * count);
                     } else if (const char* e = device_index->search_host(
                                    queries, kind, queries_count, queries_stride, count, index.expansion_search, out_keys,

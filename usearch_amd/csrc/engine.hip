@@ -20,10 +20,14 @@
 
 namespace usearch_amd {
 
-/// Experiment switch of round 5 (profiles/r05_short_rows/): the block of per-wave visited-set slabs in another kind of device memory —
-/// USEARCH_AMD_SCRATCH_MEMORY = 1: `hipDeviceMallocUncached`, 2: `hipDeviceMallocFinegrained` — to see whether the two-microsecond
-/// trip of a probe (a compare-and-swap executed at the memory side) belongs to the memory type. Default: `block_malloc`.
+/// How the short-row walks probe their visited-set slabs unless USEARCH_AMD_PROBE_MODE says otherwise (common.hpp `probe_mode_t`).
+static constexpr std::uint32_t default_probe_mode_k = probe_swap_k;
+
+/// The block of per-wave visited-set slabs. (Round 5's experiment — the block in uncached or fine-grained device memory, to see whether
+/// the two-microsecond trip of a probe belongs to the memory type: it does not, profiles/r05_short_rows/ — compiles in only with
+/// -DUSEARCH_AMD_EXPERIMENT_SCRATCH_MEMORY: USEARCH_AMD_SCRATCH_MEMORY = 1 `hipDeviceMallocUncached`, 2 `hipDeviceMallocFinegrained`.)
 static hipError_t scratch_malloc(void** out, std::size_t bytes) {
+#ifdef USEARCH_AMD_EXPERIMENT_SCRATCH_MEMORY
     const std::size_t kind = env_size("USEARCH_AMD_SCRATCH_MEMORY", 0);
     if (kind == 1 || kind == 2) {
         const hipError_t e = hipExtMallocWithFlags(out, bytes, kind == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
@@ -31,10 +35,9 @@ static hipError_t scratch_malloc(void** out, std::size_t bytes) {
             return e;
         (void)hipGetLastError();
     }
+#endif
     return block_malloc(out, bytes);
 }
-
-
 
 void row_geometry(std::size_t bytes, std::uint32_t& lanes, std::uint32_t& row_stride, std::uint32_t& chunks) {
     // lanes per row (G): the smallest power of two covering the row's 16-byte chunks, at most 8 (= one 128-byte line per
@@ -882,6 +885,9 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
         args.emit_slots = extras->emit_slots ? 1u : 0u;
         args.descent_only = extras->descent_only ? 1u : 0u;
         args.allow_bits = extras->allow_bits;
+        args.known_bits = extras->known_bits;
+        args.ask_slots = extras->ask_slots, args.ask_keys = extras->ask_keys;
+        args.ask_cursor = extras->ask_cursor, args.ask_cap = extras->ask_cap;
         args.exclude_own = extras->exclude_own ? 1u : 0u;
     }
 

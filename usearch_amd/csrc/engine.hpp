@@ -61,6 +61,12 @@ struct search_extras_t {
     bool emit_slots = false;                  ///< slots instead of keys in the `keys` output
     bool descent_only = false;                ///< `cluster`: the greedy descent to `beam_level` alone, one result per query
     const std::uint32_t* allow_bits = nullptr; ///< device: one bit per slot, 0 = rejected by the caller's predicate
+    // a predicate evaluated lazily by the host (search_args_t::known_bits): all device pointers
+    const std::uint32_t* known_bits = nullptr;
+    std::uint32_t* ask_slots = nullptr;
+    std::uint64_t* ask_keys = nullptr;
+    std::uint32_t* ask_cursor = nullptr;
+    std::uint32_t ask_cap = 0;
     bool reference_frontier = false;          ///< keep the reference's heap whatever the pair (index construction does)
     bool exclude_own = false;                 ///< `search_to_update_`: a query's own stored row routes, never becomes a candidate
 };

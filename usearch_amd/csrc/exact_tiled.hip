@@ -413,6 +413,10 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
                                                                     std::uint32_t* shared_bounds, float* out_distances,
                                                                     std::uint64_t* out_keys, std::uint64_t* out_counts,
                                                                     std::uint32_t knock) {
+#ifndef USEARCH_AMD_EXPERIMENT_EXACT_KNOCKOUT
+    knock = 0u; // product builds: every knock-out below compiles away (`make EXTRA=-DUSEARCH_AMD_EXPERIMENT_EXACT_KNOCKOUT OUT=… OBJ=…`
+                // builds the copy scripts/exact_knockout.py loads through USEARCH_AMD_LIBRARY)
+#endif
     // `knock` (USEARCH_AMD_EXACT_KNOCKOUT, timing experiments only — results are wrong with any bit set): 1 = no fold, 2 = no fills
     // after the prologue's, 4 = no wait for the fills and no barrier, 8 = the fold's thresholds refreshed for the first tile only, 16 = the
     // fold without its per-block tests, 32 = the general fold where the fused one would run (results stay right), 64 = the fused fold without what follows a block's test
@@ -921,6 +925,13 @@ __global__ __launch_bounds__(wide_threads_k) void exact_wide_kernel(const snapsh
      *  get a zero in the operand and always pass. Returns false — nothing touched — while a query of the wave has no finite
      *  threshold yet (its list and everybody else's still filling: the first tile of a launch; a query of zero norm): the general
      *  fold takes the tile.
+     *  NOT BIT-REPRODUCIBLE ACROSS FOLDS: the accumulator was rounded once more with the threshold's term in it, so the Σab recovered
+     *  here can differ in its last bits from the one the general fold (or the 64-row tile) closes — which fold a tile takes depends
+     *  on where the launch's tiles begin and on zero-norm queries in the wave. Distances of the f16 cos / ip wide tile therefore
+     *  agree with the bit-exact wave kernel to float tolerance (tests/test_gpu_exact.py: 2e-6 relative; keys > 0.97 equal, the rest
+     *  are such near-ties), never bit for bit; i8 takes integer sums through the general fold and stays bit-identical. A sum that is
+     *  NaN fails every comparison: its row is dropped by the maximum — the general fold would offer it and the list would refuse
+     *  it (NaN orders before nothing), the same result.
      */
     auto fold_tile_fused = [&]() -> bool {
         const std::uint64_t tile_row = first_row + (std::uint64_t)work_tile * wide_rows_k;
@@ -1159,7 +1170,11 @@ hipError_t launch_wide(const snapshot_view_t& view, const std::uint8_t* queries,
     hipLaunchKernelGGL(kernel, dim3(workgroups), dim3(wide_threads_k), lds_bytes, stream, view,
                        (const std::uint8_t*)padded, padded_stride, query_count, wanted, rows_per_partition, query_tiles, tiles_per_xcd, row_norms,
                        query_norms, map_keys ? 1u : 0u, allow_bits, shared_bounds, out_distances, out_keys, out_counts,
+#ifdef USEARCH_AMD_EXPERIMENT_EXACT_KNOCKOUT
                        (std::uint32_t)env_size("USEARCH_AMD_EXACT_KNOCKOUT", 0));
+#else
+                       0u);
+#endif
     return hipGetLastError();
 }
 

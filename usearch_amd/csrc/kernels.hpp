@@ -1273,8 +1273,20 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
         bool ok = !(args.exclude_own && slot == (std::uint32_t)query_row); // index.hpp:4111, 4161: `updated_slot` never enters `top`
         if (ok && ix.has_tombstones)
             ok = ix.keys[slot] != free_key_k;
-        if (ok && args.allow_bits)
-            ok = ((args.allow_bits[slot >> 5] >> (slot & 31)) & 1u) != 0;
+        if (ok && args.allow_bits) {
+            const std::uint32_t word = slot >> 5, bit = 1u << (slot & 31);
+            if (args.known_bits && !(args.known_bits[word] & bit)) {
+                // the host has not been asked about this member yet (`search_args_t::known_bits`): ask, and go on as if it were
+                // allowed — this run's results are provisional, the host runs the query again once it knows
+                if (lane == 0) {
+                    const std::uint32_t at = atomicAdd(args.ask_cursor, 1u);
+                    if (at < args.ask_cap)
+                        args.ask_slots[at] = slot, args.ask_keys[at] = ix.keys[slot];
+                }
+            } else {
+                ok = (args.allow_bits[word] & bit) != 0;
+            }
+        }
         return uniform_u32(ok ? 1u : 0u) != 0;
     };
 

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "placement.hpp"
 
 typedef char const* usearch_amd_error_t;
 namespace {
@@ -214,3 +215,31 @@ __attribute__((visibility("default"))) void usearch_amd_test_containers(uint32_t
 }
 
 } // extern "C"
+
+
+// ---- diagnostics of round 3 – 5's placement studies (scripts/placement_study.py, scripts/fragment_study.py): probes over the arrays a
+//      snapshot hands out through `usearch_amd_snapshot_arrays` (csrc/placement.hpp). Not product entry points.
+extern "C" __attribute__((visibility("default"))) float usearch_amd_test_gather_probe(const void* base, size_t bytes, size_t row_bytes,
+                                                                                      usearch_amd_error_t* error) {
+    float gbps = 0.f;
+    const hipError_t e = usearch_amd::gather_probe(base, bytes, row_bytes, &gbps);
+    if (e != hipSuccess)
+        fail(error, hipGetErrorString(e));
+    return gbps;
+}
+extern "C" __attribute__((visibility("default"))) float usearch_amd_test_translation_probe(const void* base, size_t bytes,
+                                                                                           usearch_amd_error_t* error) {
+    float rate = 0.f;
+    const hipError_t e = usearch_amd::translation_probe(base, bytes, &rate);
+    if (e != hipSuccess)
+        fail(error, hipGetErrorString(e));
+    return rate;
+}
+extern "C" __attribute__((visibility("default"))) float usearch_amd_test_latency_probe(const void* base, size_t bytes, size_t row_bytes,
+                                                                                       usearch_amd_error_t* error) {
+    float nanoseconds = 0.f;
+    const hipError_t e = usearch_amd::latency_probe(base, bytes, row_bytes, &nanoseconds);
+    if (e != hipSuccess)
+        fail(error, hipGetErrorString(e));
+    return nanoseconds;
+}

@@ -54,6 +54,12 @@ class Stats(C.Structure):
                 ("top_cells", C.c_uint32), ("probe_mode", C.c_uint32), ("seen_cells", C.c_uint32), ("claim_bits", C.c_uint32)]
 
 
+class Arrays(C.Structure):
+    """`usearch_amd_arrays_t`: device pointers and shapes of a snapshot's HBM arrays."""
+    _fields_ = [("vectors", C.c_void_p), ("level0", C.c_void_p), ("keys", C.c_void_p), ("size", C.c_uint64),
+                ("row_stride", C.c_uint32), ("level0_cells", C.c_uint32), ("device", C.c_int), ("reserved", C.c_uint32)]
+
+
 class BuildConfig(C.Structure):
     """`usearch_amd_build_config_t`; zeros = the reference's defaults."""
     _fields_ = [("connectivity", C.c_uint32), ("connectivity_base", C.c_uint32), ("expansion_add", C.c_uint32),
@@ -80,8 +86,8 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_snapshot_from_parts",
     "usearch_amd_snapshot_free", "usearch_amd_snapshot_size", "usearch_amd_snapshot_dimensions",
     "usearch_amd_snapshot_connectivity", "usearch_amd_snapshot_max_level", "usearch_amd_snapshot_bytes_per_vector",
-    "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_placement", "usearch_amd_snapshot_placement_incumbents",
-    "usearch_amd_note_device_free", "usearch_amd_settle", "usearch_amd_snapshot_settle_ms", "usearch_amd_snapshot_gather_probe", "usearch_amd_snapshot_translation_probe", "usearch_amd_snapshot_latency_probe",
+    "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_placement", "usearch_amd_snapshot_arrays",
+    "usearch_amd_note_device_free", "usearch_amd_settle", "usearch_amd_snapshot_settle_ms",
     "usearch_amd_snapshot_scalar_kind",
     "usearch_amd_snapshot_metric_kind", "usearch_amd_snapshot_lanes_per_row", "usearch_amd_snapshot_inline_rows",
     "usearch_amd_search_many",
@@ -151,8 +157,6 @@ def library() -> C.CDLL:
         f = getattr(L, f"usearch_amd_snapshot_{name}")
         f.restype = C.c_size_t
         f.argtypes = [C.c_void_p]
-    L.usearch_amd_snapshot_placement_incumbents.restype = None
-    L.usearch_amd_snapshot_placement_incumbents.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.usearch_amd_note_device_free.restype = None
     L.usearch_amd_note_device_free.argtypes = []
     L.usearch_amd_settle.restype = C.c_float
@@ -160,14 +164,10 @@ def library() -> C.CDLL:
     L.usearch_amd_snapshot_settle_ms.restype = C.c_float
     L.usearch_amd_snapshot_settle_ms.argtypes = [C.c_void_p]
     L.usearch_amd_snapshot_placement.restype = None
-    L.usearch_amd_snapshot_placement.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+    L.usearch_amd_snapshot_placement.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float),
                                                  C.POINTER(C.c_float), C.POINTER(C.c_float)]
-    L.usearch_amd_snapshot_latency_probe.restype = C.c_float
-    L.usearch_amd_snapshot_latency_probe.argtypes = [C.c_void_p, C.c_int, err_p]
-    L.usearch_amd_snapshot_translation_probe.restype = C.c_float
-    L.usearch_amd_snapshot_translation_probe.argtypes = [C.c_void_p, err_p]
-    L.usearch_amd_snapshot_gather_probe.restype = C.c_float
-    L.usearch_amd_snapshot_gather_probe.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, err_p]
+    L.usearch_amd_snapshot_arrays.restype = None
+    L.usearch_amd_snapshot_arrays.argtypes = [C.c_void_p, C.POINTER(Arrays)]
     for name in ("scalar_kind", "metric_kind"):
         f = getattr(L, f"usearch_amd_snapshot_{name}")
         f.restype = C.c_int
@@ -421,33 +421,47 @@ class Index:
         times of every trial; `draws == 0` before the first such launch and for arrays too small to bother."""
         draws, kept, probe_ms = C.c_uint32(), C.c_uint32(), C.c_float()
         rates, incumbents = (C.c_float * 8)(), (C.c_float * 8)()
-        library().usearch_amd_snapshot_placement(self._handle, C.byref(draws), C.byref(kept), rates, C.byref(probe_ms))
-        library().usearch_amd_snapshot_placement_incumbents(self._handle, incumbents)
+        library().usearch_amd_snapshot_placement(self._handle, C.byref(draws), C.byref(kept), rates, incumbents, C.byref(probe_ms))
         shown = min(int(draws.value), 8)
         return {"settle_ms": round(float(library().usearch_amd_snapshot_settle_ms(self._handle)), 1),
                 "draws": int(draws.value), "kept": int(kept.value), "probe_ms": round(float(probe_ms.value), 2),
                 "judge_ms": [round(float(rates[i]), 3) for i in range(shown)],
                 "incumbent_ms": [round(float(incumbents[i]), 3) for i in range(shown)]}
 
+    @property
+    def arrays(self) -> "Arrays":
+        """The HBM-resident arrays (`usearch_amd_snapshot_arrays`): device pointers of the padded matrix, the level-0 lists and the
+        keys, with their shapes — read-only, for a host's own kernels."""
+        out = Arrays()
+        library().usearch_amd_snapshot_arrays(self._handle, C.byref(out))
+        return out
+
+    # ---- diagnostics of the placement studies (scripts/placement_study.py, fragment_study.py): the probes live in the test-hooks
+    #      library, over the arrays above
     def latency_probe(self, lists: bool = False) -> float:
         """Nanoseconds per DEPENDENT read of a random stored row (or, `lists`, of a random level-0 neighbour list)."""
-        err = C.c_char_p()
-        value = library().usearch_amd_snapshot_latency_probe(self._handle, 1 if lists else 0, C.byref(err))
-        _raise(err, "usearch_amd_snapshot_latency_probe")
+        err, a = C.c_char_p(), self.arrays
+        base, row = (a.level0, a.level0_cells * 4) if lists else (a.vectors, a.row_stride)
+        value = test_hooks().usearch_amd_test_latency_probe(C.c_void_p(base), a.size * row, row, C.byref(err))
+        _raise(err, "usearch_amd_test_latency_probe")
         return float(value)
 
     def translation_probe(self) -> float:
         """Million random 4-KB pages of the resident matrix touched per second (16 bytes each): the address-translation path."""
-        err = C.c_char_p()
-        rate = library().usearch_amd_snapshot_translation_probe(self._handle, C.byref(err))
-        _raise(err, "usearch_amd_snapshot_translation_probe")
+        err, a = C.c_char_p(), self.arrays
+        rate = test_hooks().usearch_amd_test_translation_probe(C.c_void_p(a.vectors), a.size * a.row_stride, C.byref(err))
+        _raise(err, "usearch_amd_test_translation_probe")
         return float(rate)
 
     def gather_probe(self, first_row: int = 0, rows: int = 0) -> float:
-        """GB/s of the engine's placement probe — random stored rows, no dependencies — over rows [first_row, first_row + rows)."""
-        err = C.c_char_p()
-        rate = library().usearch_amd_snapshot_gather_probe(self._handle, first_row, rows, C.byref(err))
-        _raise(err, "usearch_amd_snapshot_gather_probe")
+        """GB/s of a dependency-free gather of random stored rows among rows [first_row, first_row + rows) (`rows` = 0: to the end)."""
+        err, a = C.c_char_p(), self.arrays
+        if first_row >= a.size:
+            return 0.0
+        rows = a.size - first_row if not rows or first_row + rows > a.size else rows
+        rate = test_hooks().usearch_amd_test_gather_probe(C.c_void_p((a.vectors or 0) + first_row * a.row_stride), rows * a.row_stride,
+                                                          a.row_stride, C.byref(err))
+        _raise(err, "usearch_amd_test_gather_probe")
         return float(rate)
 
     # ---- introspection (names of usearch.index.Index properties, index.py:1180-1300)
@@ -856,6 +870,11 @@ def test_hooks() -> C.CDLL:
         if not os.path.exists(TEST_HOOKS_PATH):
             raise RuntimeError(f"{TEST_HOOKS_PATH} is missing: build it with `make -C usearch_amd/csrc`")
         _test_hooks = C.CDLL(TEST_HOOKS_PATH, mode=os.RTLD_LOCAL)
+        for name, arguments in (("gather_probe", [C.c_void_p, C.c_size_t, C.c_size_t]), ("translation_probe", [C.c_void_p, C.c_size_t]),
+                                ("latency_probe", [C.c_void_p, C.c_size_t, C.c_size_t])):
+            probe = getattr(_test_hooks, f"usearch_amd_test_{name}")
+            probe.restype = C.c_float
+            probe.argtypes = arguments + [C.POINTER(C.c_char_p)]
         _test_hooks.usearch_amd_test_containers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
                                                             C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t),
                                                             C.POINTER(C.c_char_p)]
