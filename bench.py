@@ -280,7 +280,7 @@ def secondary_lines(presets, timeout_seconds: float) -> list:
     out = []
     for name in presets:
         command = [sys.executable, os.path.abspath(__file__), "--config", name, "--no-secondary", "--no-stress-rows", "--steps", "10",
-                   "--warmup", "2", "--cpu-seconds", "4", "--recall-queries", "2000", "--no-load-timing"]
+                   "--warmup", "2", "--cpu-seconds", "4", "--recall-queries", "2000", "--no-load-timing", "--no-condition"]
         t0 = time.time()
         entry = {"preset": name, "what": PRESETS[name]["what"], "command": " ".join(["python", "bench.py"] + command[2:])}
         try:
@@ -639,6 +639,8 @@ def main() -> None:
     parser.add_argument("--no-reload", action="store_true",
                         help="search the builder's own arrays instead of the saved image loaded back through the device loader "
                              "(the default walks what `usearch_load` would give a user: matrix placed after the settle window)")
+    parser.add_argument("--no-condition", action="store_true",
+                        help="do not condition the device's frame allocator before the image is loaded (usearch_amd_condition_device)")
     parser.add_argument("--no-secondary", action="store_true",
                         help="skip BASELINE.json's other configurations (c1, c2, c4, c5 — each in a process of its own, summarised "
                              "under config.secondary of the default line)")
@@ -727,14 +729,23 @@ def main() -> None:
             built = None
             torch.cuda.empty_cache()
             usearch_amd.note_device_free()  # torch's blocks went back through another allocator: the loader waits for them too
+            # ... and the device's frame allocator is put into its good state first (usearch_amd_condition_device: one allocation of
+            # all free memory, freed at once — what a service does once at start-up): which level a settled placement lands on
+            # otherwise depends on what ran on this box before (profiles/r06_settled/: 44.4 … 48.3 ms for the same batch)
+            conditioned = None
+            if not args.no_condition:
+                try:
+                    conditioned = round(usearch_amd.condition_device(local_rank), 2)
+                except RuntimeError as error:
+                    log(f"[bench] device not conditioned: {error}")
             t2 = time.time()
             index = usearch_amd.Index.restore(image, device=local_rank)
             torch.cuda.synchronize()
-            reload_seconds = {"save_buffer": round(t2 - t1, 2), "settle_and_load": round(time.time() - t2, 2),
+            reload_seconds = {"save_buffer": round(t2 - t1, 2), "condition_device": conditioned, "settle_and_load": round(time.time() - t2, 2),
                               "settle_ms": index.placement["settle_ms"]}
             if rank == 0:
-                log(f"[bench] image of {image.nbytes / 1e9:.1f} GB saved in {t2 - t1:.1f}s, loaded back in {time.time() - t2:.1f}s "
-                    f"(of which {index.placement['settle_ms']:.0f} ms waiting for freed frames)")
+                log(f"[bench] image of {image.nbytes / 1e9:.1f} GB saved in {t2 - t1:.1f}s, device conditioned in {conditioned}s, loaded back in "
+                    f"{time.time() - t2:.1f}s (of which {index.placement['settle_ms']:.0f} ms waiting for freed frames)")
             if world > 1 or (args.no_cpu_baseline and args.no_placement_check):
                 image = None  # only the reference leg and the second load (rank 0, N = 1) need it again
     else:
@@ -867,8 +878,9 @@ def main() -> None:
     #      (csrc/placement.hpp). The ENGINE tries placements inside the launches that fill the chip — the sweep above was made of such
     #      launches — and lets the walk itself judge them on the caller's queries: nothing to do here but to report what it did
     #      (read again after the timed steps: trials may still be under way during the warm-up).
-    placement_policy = ("settle, then allocate: the loader places the matrix once, after USEARCH_AMD_SETTLE_MS (1000) since the last big "
-                        "release (csrc/placement.hpp); no online trials (USEARCH_AMD_PLACEMENT_DRAWS > 1 turns them back on); the scratch "
+    placement_policy = ("condition, settle, then allocate: the device's frame allocator is conditioned once (one allocation of all free memory, "
+                        "freed at once: usearch_amd_condition_device), the loader places the matrix once, after USEARCH_AMD_SETTLE_MS (1000) "
+                        "since the last big release (csrc/placement.hpp); no online trials (USEARCH_AMD_PLACEMENT_DRAWS > 1 turns them back on); the scratch "
                         "block is drawn by run_ladder when a chip-filling launch needs a new one (<= 8 candidates timed by the launch's "
                         "first queries)")
     draws_before_timing = index.placement["draws"]

@@ -83,6 +83,7 @@ typedef struct usearch_amd_stats_t {
                                   swap only to claim, 2 = no atomic at all (loads, plain stores, claims settled by bits in LDS) */
     uint32_t seen_cells;     /**< … `seen` cells in LDS in front of the slab */
     uint32_t claim_bits;     /**< … claim bits in LDS (probe_mode 2) */
+    uint32_t early_rows;     /**< rows of ≤ 128 bytes: 1 = a hop's rows were gathered next to the probe of the visited set, not behind it */
 } usearch_amd_stats_t;
 
 /** Number of visible HIP devices; 0 (and an error) when the runtime finds none. */
@@ -139,7 +140,16 @@ USEARCH_AMD_EXPORT void usearch_amd_snapshot_placement(usearch_amd_snapshot_t sn
  *  host announces here after freeing device memory through ANOTHER allocator (`torch.cuda.empty_cache()`, `hipFree` of its own).
  *  `usearch_amd_settle` waits out the window explicitly (before a host's own big allocation) and returns the milliseconds waited;
  *  `usearch_amd_snapshot_settle_ms` = what this snapshot's matrix waited when it was allocated.
+ *
+ *  Conditioning. Inside a process the settled placement is reproducible; WHICH level it lands on depends on the state earlier
+ *  processes left the device's frame allocator in (the headline batch: 44.4 … 48.3 ms). `usearch_amd_condition_device` puts it into
+ *  its good state — one allocation of all free device memory but `spare_bytes` (at least 2 GiB), freed at once: the driver coalesces
+ *  and wipes everything, arrays placed afterwards get large contiguous blocks (44.4 ms, every time: profiles/r06_settled/) — at a cost
+ *  of 3 … 10 s, which is why it only happens on request: call it once at start-up before loading a big index (returns the seconds
+ *  spent, negative when nothing could be allocated), or set USEARCH_AMD_CONDITION=1 and the first array of ≥ 1 GiB this process places
+ *  does it first. Do not call it while other users of the device need memory.
  */
+USEARCH_AMD_EXPORT float usearch_amd_condition_device(int device, size_t spare_bytes, usearch_amd_error_t* error);
 USEARCH_AMD_EXPORT void usearch_amd_note_device_free(void);
 USEARCH_AMD_EXPORT float usearch_amd_settle(void);
 USEARCH_AMD_EXPORT float usearch_amd_snapshot_settle_ms(usearch_amd_snapshot_t snapshot);

@@ -20,6 +20,7 @@ def main() -> None:
     parser.add_argument("--queries", type=int, default=20_000)
     parser.add_argument("--timed-queries", type=int, default=100_000)
     parser.add_argument("--modes", type=int, nargs="+", default=[0, 1, 2])
+    parser.add_argument("--early", type=int, nargs="+", default=[0], help="USEARCH_AMD_EARLY_ROWS values to cross the modes with (G = 2 rows)")
     args = parser.parse_args()
     import torch
 
@@ -38,8 +39,10 @@ def main() -> None:
         outs = [torch.zeros((count, 10), dtype=torch.int64, device=device), torch.zeros((count, 10), dtype=torch.float32, device=device)] + \
                [torch.zeros(count, dtype=torch.int64, device=device) for _ in range(3)]
         answers = {}
-        for mode in args.modes:
+        combos = [(mode, early) for mode in args.modes for early in (args.early if dtype == "i8" else args.early[:1])]
+        for mode, early in combos:
             os.environ["USEARCH_AMD_PROBE_MODE"] = str(mode)
+            os.environ["USEARCH_AMD_EARLY_ROWS"] = str(early)
             got = index.search(queries[:args.queries], 10, expansion=expansion, dtype=dtype, tuning=Tuning(mode=2))
             times = []
             for _ in range(5):
@@ -47,20 +50,21 @@ def main() -> None:
                                             outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), outs[4].data_ptr(), timed=True,
                                             tuning=Tuning(mode=2))
                 times.append(stats.kernel_ms)
-            answers[mode] = (got, float(np.min(times[1:])), stats)
-        base = answers[args.modes[0]][0]
-        for mode in args.modes:
-            got, ms, stats = answers[mode]
+            answers[(mode, early)] = (got, float(np.min(times[1:])), stats)
+        base = answers[combos[0]][0]
+        for mode, early in combos:
+            got, ms, stats = answers[(mode, early)]
             same = (np.array_equal(base.keys, got.keys) and np.array_equal(base.distances.view(np.uint32), got.distances.view(np.uint32))
                     and np.array_equal(base.counts, got.counts) and np.array_equal(base.visited_per_query, got.visited_per_query)
                     and np.array_equal(base.computed_per_query, got.computed_per_query))
-            print(f"{n}x{dim} {dtype} {metric} ef {expansion}: probe mode {mode} (ran {stats.probe_mode}, scratch mode {stats.mode}, {stats.grid} waves, "
+            print(f"{n}x{dim} {dtype} {metric} ef {expansion}: probe mode {mode} early rows {early} (ran {stats.probe_mode} / {stats.early_rows}, scratch mode {stats.mode}, {stats.grid} waves, "
                   f"{stats.lds_bytes} B LDS/wave, seen {stats.seen_cells}, claim bits {stats.claim_bits}): {ms:.3f} ms for {args.timed_queries} queries = "
                   f"{args.timed_queries / ms / 1e3:.2f} M QPS; identical to mode {args.modes[0]} on {args.queries} queries (keys, bits, counts, both counters): {same}",
                   flush=True)
         del index, built, data
         torch.cuda.empty_cache()
     os.environ.pop("USEARCH_AMD_PROBE_MODE", None)
+    os.environ.pop("USEARCH_AMD_EARLY_ROWS", None)
 
 
 if __name__ == "__main__":

@@ -112,6 +112,7 @@ void stats_to_c(const search_stats_t& s, usearch_amd_stats_t* out) {
     out->probe_mode = s.probe_mode;
     out->seen_cells = s.seen_cells;
     out->claim_bits = s.claim_bits;
+    out->early_rows = s.early_rows;
 }
 
 void fail(usearch_amd_error_t* error, const char* message) {
@@ -247,6 +248,14 @@ void usearch_amd_snapshot_placement(usearch_amd_snapshot_t s, uint32_t* draws, u
             incumbent_ms[i] = placement.incumbent_ms[i];
     if (probe_ms)
         *probe_ms = placement.probe_ms;
+}
+float usearch_amd_condition_device(int device, size_t spare_bytes, usearch_amd_error_t* error) {
+    if (hipSetDevice(device) != hipSuccess)
+        return fail(error, "No such device"), -1.f;
+    const float seconds = condition_device(spare_bytes);
+    if (seconds < 0.f)
+        fail(error, "The device could not be conditioned: no large allocation succeeded");
+    return seconds;
 }
 void usearch_amd_note_device_free(void) { note_release((std::size_t)1 << 40); }
 float usearch_amd_settle(void) { return settle_before_placing(); }

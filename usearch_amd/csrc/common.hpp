@@ -135,13 +135,14 @@ struct search_args_t {
                                      ///< (`usearch_filtered_search`, index_dense.hpp:2071-2081)
     /// A predicate the host evaluates LAZILY (`usearch_filtered_search`'s callback, dropin.hip): `known_bits` says which members the
     /// host has been asked about already (their answer is in `allow_bits`); a member the walk wants to admit to `top` that is not
-    /// known yet is posted to `ask_slots` / `ask_keys` (cursor `ask_cursor`, room `ask_cap`) and treated as allowed — the host
-    /// evaluates what was asked and runs the query again until a run asks nothing: that run IS the reference's traversal.
+    /// known yet is posted to `ask_slots` / `ask_keys` (cursor `ask_cursor`, room `ask_cap`) and guessed (`guess_threshold`) — the
+    /// host evaluates what was asked and runs the query again until a run asks nothing: that run IS the reference's traversal.
     const std::uint32_t* known_bits;
     std::uint32_t* ask_slots;
     std::uint64_t* ask_keys;
     std::uint32_t* ask_cursor;
     std::uint32_t ask_cap;
+    std::uint32_t guess_threshold;   ///< an unknown member counts as allowed when slot · 0x9E3779B1 (mod 2³²) ≤ this: the share of "yes" so far
     std::uint32_t exclude_own;       ///< 1 = query q's own stored row (`query_ids[q]`) routes but never becomes a result candidate:
                                      ///< `search_to_update_` (index.hpp:4087-4170), the insertion search of a member that is
                                      ///< being re-linked in place
@@ -151,6 +152,8 @@ struct search_args_t {
                                     ///< persistent wave (how long the drain phase of a batch leaves the chip part-idle)
     std::uint32_t seen_offset;      ///< short rows with the visited set in a global slab: where in the wave's LDS the `seen` cells
     std::uint32_t seen_cells;       ///< sit, and how many (a power of two; 0 = none) — see `search_one`
+    std::uint32_t early_rows;       ///< rows of ≤ 128 bytes (G = 2): 1 = a hop's rows are gathered next to the probe of the visited set
+                                    ///< instead of behind it (`search_one`, the hop loop)
     std::uint32_t probe_mode;       ///< how those walks probe the slab (`probe_mode_t`): compare-and-swap, a load first and the swap
                                     ///< only to claim, or no atomic at all (loads + plain stores, claims settled in LDS)
     std::uint32_t claim_offset;     ///< `probe_plain_k`: where in the wave's LDS the claim bits sit, and how many (a power of two,

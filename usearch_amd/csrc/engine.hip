@@ -22,6 +22,8 @@ namespace usearch_amd {
 
 /// How the short-row walks probe their visited-set slabs unless USEARCH_AMD_PROBE_MODE says otherwise (common.hpp `probe_mode_t`).
 static constexpr std::uint32_t default_probe_mode_k = probe_swap_k;
+/// Rows of ≤ 128 bytes gathered next to the probe of the visited set (USEARCH_AMD_EARLY_ROWS = 0 | 1 overrides).
+static constexpr std::size_t default_early_rows_k = 0;
 
 /// The block of per-wave visited-set slabs. (Round 5's experiment — the block in uncached or fine-grained device memory, to see whether
 /// the two-microsecond trip of a probe belongs to the memory type: it does not, profiles/r05_short_rows/ — compiles in only with
@@ -887,7 +889,7 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
         args.allow_bits = extras->allow_bits;
         args.known_bits = extras->known_bits;
         args.ask_slots = extras->ask_slots, args.ask_keys = extras->ask_keys;
-        args.ask_cursor = extras->ask_cursor, args.ask_cap = extras->ask_cap;
+        args.ask_cursor = extras->ask_cursor, args.ask_cap = extras->ask_cap, args.guess_threshold = extras->guess_threshold;
         args.exclude_own = extras->exclude_own ? 1u : 0u;
     }
 
@@ -984,6 +986,9 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         // resident wave (the walk lives on its residency), at most 2 048; USEARCH_AMD_SEEN_CELLS forces a number (0 = none)
         args.seen_offset = 0, args.seen_cells = 0;
         args.probe_mode = probe_swap_k, args.claim_offset = 0, args.claim_bits = 0;
+        // rows of ≤ 128 bytes gathered next to the probe of the visited set instead of behind it (kernels.hpp, the hop loop)
+        args.early_rows = call.mode == scratch_hash_k && !params.team && lanes_ == 2 && env_size("USEARCH_AMD_EARLY_ROWS", default_early_rows_k) ? 1u : 0u;
+        call.stats.early_rows = args.early_rows;
         if (call.mode == scratch_hash_k && !params.team && lanes_ <= 2) {
             // how the slab is probed (common.hpp `probe_mode_t`): USEARCH_AMD_PROBE_MODE = 0 | 1 | 2
             // (USEARCH_AMD_PROBE_LOAD_FIRST=1, round 5's name for mode 1, still answers)

@@ -52,6 +52,7 @@ struct search_stats_t {
     std::uint32_t probe_mode = 0;        ///< short rows over a global slab: `probe_mode_t` of the last launch
     std::uint32_t seen_cells = 0;        ///< … its `seen` cells in LDS
     std::uint32_t claim_bits = 0;        ///< … its claim bits in LDS (`probe_plain_k`)
+    std::uint32_t early_rows = 0;        ///< rows of ≤ 128 bytes: 1 = gathered next to the probe of the visited set, not behind it
 };
 
 /// What index construction asks of the search on top of a plain query batch (see search_args_t).
@@ -67,6 +68,7 @@ struct search_extras_t {
     std::uint64_t* ask_keys = nullptr;
     std::uint32_t* ask_cursor = nullptr;
     std::uint32_t ask_cap = 0;
+    std::uint32_t guess_threshold = 0xFFFFFFFFu;
     bool reference_frontier = false;          ///< keep the reference's heap whatever the pair (index construction does)
     bool exclude_own = false;                 ///< `search_to_update_`: a query's own stored row routes, never becomes a candidate
 };

@@ -1276,8 +1276,11 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
         if (ok && args.allow_bits) {
             const std::uint32_t word = slot >> 5, bit = 1u << (slot & 31);
             if (args.known_bits && !(args.known_bits[word] & bit)) {
-                // the host has not been asked about this member yet (`search_args_t::known_bits`): ask, and go on as if it were
-                // allowed — this run's results are provisional, the host runs the query again once it knows
+                // the host has not been asked about this member yet (`search_args_t::known_bits`): ask, and go on with a GUESS — this
+                // run's results are provisional, the host runs the query again once it knows. The guess admits a member with the
+                // share of "yes" among the answers so far (a fixed pseudo-random draw per slot): a provisional `top` then fills about
+                // as fast as the true one, the walk reaches about as far, and the next run has little left to ask.
+                ok = slot * 0x9E3779B1u <= args.guess_threshold;
                 if (lane == 0) {
                     const std::uint32_t at = atomicAdd(args.ask_cursor, 1u);
                     if (at < args.ask_cap)
@@ -1374,6 +1377,9 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     constexpr bool inline_ak = lanes_ak == 1 && !global_ak;
     const bool inline_rows = inline_ak && ix.nbr0_rows != nullptr && !beam_level && cells <= 64 && ix.chunks == 1;
     uint4 ahead_row = {0u, 0u, 0u, 0u};
+    // rows of ≤ 128 bytes over a visited set in a global slab: gathered next to the probe instead of behind it (see the hop loop)
+    constexpr bool early_ak = lanes_ak == 2 && mode_ak == scratch_hash_k && team_ak == 1;
+    const bool early_rows = early_ak && args.early_rows != 0 && !inline_rows && cells <= 64;
     tick(0);
     // ---- a team over the in-`top` frontier with a wide `top` (≥ 8 cells per lane: expansions above 256, where a commit costs about
     // what measuring the hop's rows does) walks the beam as a PIPELINE (lists of ≤ 64 cells): the leader names the next member to
@@ -1612,6 +1618,10 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
             // visits.set(successor) for the whole tile at once; duplicates inside a list were removed on upload
             tick(1);
             bool fresh;
+            float early_mine = 0.f;          // inline rows: this lane's distance, computed in the shadow of the probe
+            bool early_done = false;
+            std::uint64_t asked_mask = 0;    // early rows: the lanes whose rows were gathered next to the probe, …
+            bool measured_early = false;     // … their distances waiting in `cand_distances` in that order
             if constexpr (mode_ak == scratch_global_k) {
                 fresh = visits_set<mode_ak>(visits, visits_mask, neighbor, present);
             } else {
@@ -1685,6 +1695,35 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                 }
                 if (!popped)
                     pop_now();
+                // ---- in the shadow of the probe's round trip (short rows, round 6). The walk of a short-row index is a chain of
+                //      dependent round trips per hop — list, probe of the visited set, rows, commit — and not bytes; what does not
+                //      NEED the probe's answer goes in front of the wait for it:
+                //       * rows that arrived with the list (`nbr0_rows`): every lane measures its neighbour now, fresh or not;
+                //       * rows of ≤ 128 bytes (G = 2; `args.early_rows`): the rows of every neighbour the probe asks about are
+                //         gathered NOW, next to the probe instead of behind it — one dependent round trip less per hop for about
+                //         two thirds more row traffic (four asked-about neighbours in ten turn out visited), on a walk that sits
+                //         at a quarter of the memory's bandwidth. Distances of visited neighbours are dropped; `computed` counts
+                //         the fresh ones as the reference does.
+                if constexpr (inline_ak) {
+                    if (inline_rows) {
+                        partial_t p;
+                        accumulate_chunk<metric_ak, scalar_ak>(p, query_lds, 0, inline_row);
+                        early_mine = finalize_distance<metric_ak, scalar_ak>(p, a2, ix.dimensions);
+                        early_done = true;
+                    }
+                }
+                if constexpr (early_ak) {
+                    if (early_rows && tile == 0) {
+                        asked_mask = ballot(asks);
+                        const std::uint32_t asked = popcount64(asked_mask);
+                        if (asks)
+                            cand_slots[rank_below(asked_mask, lane)] = neighbor;
+                        wave_sync<false>();
+                        if (asked)
+                            measure_rows<metric_ak, scalar_ak, lanes_ak, loads_ak, false, 1>(ix, query_lds, a2, cand_slots, cand_distances, asked);
+                        measured_early = true;
+                    }
+                }
                 while (old != none_slot_k && old != neighbor) { // linear probing, index.hpp:1085-1211
                     h = (h + 1) & visits_mask;
                     if (load_first) {
@@ -1714,13 +1753,24 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
             if (inline_rows) {
                 // the row arrived with the list: every fresh lane measures its own neighbour, nothing is staged or gathered
                 if constexpr (inline_ak) {
-                    partial_t p;
-                    accumulate_chunk<metric_ak, scalar_ak>(p, query_lds, 0, inline_row);
-                    mine = finalize_distance<metric_ak, scalar_ak>(p, a2, ix.dimensions);
+                    if (early_done) {
+                        mine = early_mine; // measured while the probe was in flight
+                    } else {
+                        partial_t p;
+                        accumulate_chunk<metric_ak, scalar_ak>(p, query_lds, 0, inline_row);
+                        mine = finalize_distance<metric_ak, scalar_ak>(p, a2, ix.dimensions);
+                    }
                 }
                 mine_slot = neighbor;
                 candidate = fresh;
                 computed += count;
+            } else if (measured_early) {
+                // the rows were gathered next to the probe: a fresh lane picks its distance up where the gather left it
+                mine = fresh ? cand_distances[rank_below(asked_mask, lane)] : 0.f;
+                mine_slot = neighbor;
+                candidate = fresh;
+                computed += count;
+                wave_sync<false>();
             } else {
                 if (fresh)
                     mem::store(cand_slots + rank_below(fresh_mask, lane), neighbor); // keeps list order

@@ -51,7 +51,8 @@ class Stats(C.Structure):
     _fields_ = [("passes", C.c_uint32), ("retried_lds", C.c_uint32), ("retried_global", C.c_uint32),
                 ("kernel_ms", C.c_float), ("mode", C.c_uint32), ("grid", C.c_uint32), ("lds_bytes", C.c_uint32),
                 ("frontier", C.c_uint32), ("variant", C.c_uint32), ("tail_idle", C.c_float), ("span_ms", C.c_float),
-                ("top_cells", C.c_uint32), ("probe_mode", C.c_uint32), ("seen_cells", C.c_uint32), ("claim_bits", C.c_uint32)]
+                ("top_cells", C.c_uint32), ("probe_mode", C.c_uint32), ("seen_cells", C.c_uint32), ("claim_bits", C.c_uint32),
+                ("early_rows", C.c_uint32)]
 
 
 class Arrays(C.Structure):
@@ -87,7 +88,7 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_snapshot_free", "usearch_amd_snapshot_size", "usearch_amd_snapshot_dimensions",
     "usearch_amd_snapshot_connectivity", "usearch_amd_snapshot_max_level", "usearch_amd_snapshot_bytes_per_vector",
     "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_placement", "usearch_amd_snapshot_arrays",
-    "usearch_amd_note_device_free", "usearch_amd_settle", "usearch_amd_snapshot_settle_ms",
+    "usearch_amd_note_device_free", "usearch_amd_settle", "usearch_amd_snapshot_settle_ms", "usearch_amd_condition_device",
     "usearch_amd_snapshot_scalar_kind",
     "usearch_amd_snapshot_metric_kind", "usearch_amd_snapshot_lanes_per_row", "usearch_amd_snapshot_inline_rows",
     "usearch_amd_search_many",
@@ -159,6 +160,8 @@ def library() -> C.CDLL:
         f.argtypes = [C.c_void_p]
     L.usearch_amd_note_device_free.restype = None
     L.usearch_amd_note_device_free.argtypes = []
+    L.usearch_amd_condition_device.restype = C.c_float
+    L.usearch_amd_condition_device.argtypes = [C.c_int, C.c_size_t, err_p]
     L.usearch_amd_settle.restype = C.c_float
     L.usearch_amd_settle.argtypes = []
     L.usearch_amd_snapshot_settle_ms.restype = C.c_float
@@ -833,6 +836,16 @@ def note_device_free() -> None:
     """Tells the engine that the host just released device memory through another allocator (`torch.cuda.empty_cache()`): the next
     loader or builder waits out the driver's settle window before it places its matrix (csrc/placement.hpp)."""
     library().usearch_amd_note_device_free()
+
+
+def condition_device(device: int = 0, spare_bytes: int = 6 << 30) -> float:
+    """One allocation of all free device memory but `spare_bytes`, freed at once (`usearch_amd_condition_device`): the driver's frame
+    allocator coalesces and wipes everything, and the arrays placed afterwards land on large contiguous blocks — the level the walk
+    runs at stops depending on what ran on the device before. 3 … 10 s; once, at start-up, before a big index is loaded."""
+    err = C.c_char_p()
+    seconds = library().usearch_amd_condition_device(device, spare_bytes, C.byref(err))
+    _raise(err, "usearch_amd_condition_device")
+    return float(seconds)
 
 
 def settle() -> float:
