@@ -14,7 +14,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 if [ -z "${PROFILE_EF:-}" ]; then
-  python "$REPO/bench.py" "$@" --no-cpu-baseline --no-stress-rows --no-placement-check --steps 5 --warmup 2 > "$OUT/pick.json" 2> "$OUT/pick.log"
+  python "$REPO/bench.py" "$@" --no-cpu-baseline --no-stress-rows --no-placement-check --no-secondary --no-condition --steps 5 --warmup 2 > "$OUT/pick.json" 2> "$OUT/pick.log"
   tail -4 "$OUT/pick.log"
   EF=$(python -c "import json; print(json.load(open('$OUT/pick.json'))['config']['expansion_search'])" 2>/dev/null || echo 256)
 else
@@ -23,8 +23,9 @@ fi
 # (PROFILE_WARMUP: enough warm-up launches for the engine's placement trials — up to 8 + 3 + 3, one per chip-filling launch — to be over
 #  before the timed steps: a trial inside them would put its judge launches among "the last launches" the trace is trimmed to)
 WARMUP=${PROFILE_WARMUP:-1}
-QUICK="$* --expansion $EF --recall-queries 0 --no-cpu-baseline --no-stress-rows --no-host-api --no-placement-check --steps 5 --warmup $WARMUP"
+QUICK="$* --expansion $EF --recall-queries 0 --no-cpu-baseline --no-stress-rows --no-host-api --no-placement-check --no-secondary --steps ${PROFILE_STEPS:-5} --warmup $WARMUP"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python "$REPO/bench.py" $QUICK > "$OUT/stats_bench.json" 2> "$OUT/stats.log"
+QUICK="$QUICK --no-condition"   # the counter passes: the level the placement lands on does not enter the bytes
 find "$OUT/stats" -name "*kernel_stats.csv" | head -1 | while read f; do cp "$f" "$OUT/kernel_stats.csv"; done
 # the timed launches alone (the whole-process average above also covers the placement draws' candidates)
 find "$OUT/stats" -name "*kernel_trace.csv" | head -1 | while read f; do
@@ -44,6 +45,6 @@ done
 rm -rf "$OUT/stats"
 python "$REPO/scripts/pmc_traffic.py" "$OUT/pmc_FETCH_SIZE.csv" "$OUT/pmc_WRITE_SIZE.csv" search_kernel "$OUT/stats_bench.json" \
     "$OUT/pmc_TCC_EA0_RDREQ_sum_TCC_EA0_RDREQ_32B_sum_.csv" "$OUT/pmc_TCC_EA0_WRREQ_sum_TCC_EA0_WRREQ_64B_sum_.csv" > "$OUT/traffic.json" && cat "$OUT/traffic.json"
-python "$REPO/bench.py" "$@" --expansion $EF --traffic-json "$OUT/traffic.json" --wave-clock --warmup $WARMUP > "$OUT/bench.json" 2> "$OUT/bench.log"
+python "$REPO/bench.py" "$@" --expansion $EF --traffic-json "$OUT/traffic.json" --wave-clock --no-secondary --warmup $WARMUP > "$OUT/bench.json" 2> "$OUT/bench.log"
 cat "$OUT/bench.json"
 du -sh "$OUT"; head -8 "$OUT/kernel_stats.csv"

@@ -32,6 +32,9 @@ def main():
     p.add_argument("--cache", default="/dev/shm/usearch_amd_settle_study.img")
     p.add_argument("--ef", type=int, default=608)
     p.add_argument("--tag", default="")
+    p.add_argument("--history", default="none", choices=["none", "datagen", "build", "build-small"],
+                   help="what this process does BEFORE it loads the image: nothing; generate the 15.4 GB of synthetic vectors with torch "
+                        "and free them; generate them and build the index on the device (then drop it); build a 1M-vector index")
     args = p.parse_args()
     os.environ["USEARCH_AMD_PLACEMENT_LOG"] = "0"
     import torch
@@ -56,6 +59,16 @@ def main():
         del built
         torch.cuda.empty_cache()
         image.tofile(args.cache)
+    if args.history != "none" and os.path.exists(args.cache):
+        count = 1_000_000 if args.history == "build-small" else 10_000_000
+        data = bench.synthetic_vectors_device(count, 768, "f16", 42, device)
+        if args.history.startswith("build"):
+            built = usearch_amd.build(None, "cos", "f16", device_pointer=data.data_ptr(), count=count, stride=data.stride(0), ndim=768)
+            built.close()
+            del built
+        del data
+        torch.cuda.empty_cache()
+        usearch_amd.note_device_free()
     q = 10_000
     queries = bench.synthetic_vectors_device(q, 768, "f16", 43, device)
     outs = [torch.zeros((q, 10), dtype=torch.int64, device=device), torch.zeros((q, 10), dtype=torch.float32, device=device)] + \
@@ -105,7 +118,7 @@ def main():
             if step >= 6:
                 times.append(stats.kernel_ms)
         results.append(float(np.mean(times)))
-        print(f"{args.tag or args.condition} copy {copy}: conditioning {conditioned:.2f}s, load {load_s:.2f}s (settled {index.placement['settle_ms']:.0f} ms), "
+        print(f"{args.tag or args.condition} [history {args.history}] copy {copy}: conditioning {conditioned:.2f}s, load {load_s:.2f}s (settled {index.placement['settle_ms']:.0f} ms), "
               f"batch {np.mean(times):.2f} ms", flush=True)
         index.close()
         del index

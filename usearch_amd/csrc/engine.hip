@@ -23,7 +23,7 @@ namespace usearch_amd {
 /// How the short-row walks probe their visited-set slabs unless USEARCH_AMD_PROBE_MODE says otherwise (common.hpp `probe_mode_t`).
 static constexpr std::uint32_t default_probe_mode_k = probe_swap_k;
 /// Rows of ≤ 128 bytes gathered next to the probe of the visited set (USEARCH_AMD_EARLY_ROWS = 0 | 1 overrides).
-static constexpr std::size_t default_early_rows_k = 0;
+static constexpr std::size_t default_early_rows_k = 1; // 20M x 96 i8: +6.4 % at ef 80, +5.1 % at ef 64, same keys / bits / counters (profiles/r06_short_rows/early_rows.log)
 
 /// The block of per-wave visited-set slabs. (Round 5's experiment — the block in uncached or fine-grained device memory, to see whether
 /// the two-microsecond trip of a probe belongs to the memory type: it does not, profiles/r05_short_rows/ — compiles in only with
