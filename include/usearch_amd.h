@@ -141,15 +141,20 @@ USEARCH_AMD_EXPORT void usearch_amd_snapshot_placement(usearch_amd_snapshot_t sn
  *  `usearch_amd_settle` waits out the window explicitly (before a host's own big allocation) and returns the milliseconds waited;
  *  `usearch_amd_snapshot_settle_ms` = what this snapshot's matrix waited when it was allocated.
  *
- *  Conditioning. Inside a process the settled placement is reproducible; WHICH level it lands on depends on the state earlier
- *  processes left the device's frame allocator in (the headline batch: 44.4 … 48.3 ms). `usearch_amd_condition_device` puts it into
- *  its good state — one allocation of all free device memory but `spare_bytes` (at least 2 GiB), freed at once: the driver coalesces
- *  and wipes everything, arrays placed afterwards get large contiguous blocks (44.4 ms, every time: profiles/r06_settled/) — at a cost
- *  of 3 … 10 s, which is why it only happens on request: call it once at start-up before loading a big index (returns the seconds
- *  spent, negative when nothing could be allocated), or set USEARCH_AMD_CONDITION=1 and the first array of ≥ 1 GiB this process places
- *  does it first. Do not call it while other users of the device need memory.
+ *  Tuning. The settle window makes a placement reproducible inside a process (the same image loaded twice runs the headline batch in
+ *  45.10 / 45.06 ms, or in 48.31 / 48.28 ms); WHICH level it lands on depends on the box and on what the process allocated before
+ *  (44.4 … 51.4 ms over the same bytes: profiles/r06_settled/), and only the walk itself tells placements apart. A host about to
+ *  serve one shape of batch hands a sample of it to `usearch_amd_snapshot_tune` (device-resident queries in the storage scalar kind,
+ *  as for `usearch_amd_search_many_device`): up to `max_trials` (≤ 8) fresh device-to-device copies of the matrix are placed one
+ *  after the other and timed against the incumbent on the sample's first queries at `expansion`; the faster stays, three wins of
+ *  the incumbent in a row end it early. Explicit and synchronous — no trial ever runs inside a search call (USEARCH_AMD_PLACEMENT_
+ *  DRAWS = 2 … 8 in the environment turns round 5's online trials back on) — and a second copy of the matrix exists in HBM only
+ *  during the call. Returns the trials made (0: the matrix is under 1 GiB, rows travel inline with the lists, or the sample does not
+ *  fill the chip twice over); `usearch_amd_snapshot_placement` reports every trial's two times.
  */
-USEARCH_AMD_EXPORT float usearch_amd_condition_device(int device, size_t spare_bytes, usearch_amd_error_t* error);
+USEARCH_AMD_EXPORT uint32_t usearch_amd_snapshot_tune(usearch_amd_snapshot_t snapshot, void const* queries_device, size_t queries_count,
+                                                      size_t queries_stride, size_t wanted, size_t expansion, uint32_t max_trials,
+                                                      usearch_amd_error_t* error);
 USEARCH_AMD_EXPORT void usearch_amd_note_device_free(void);
 USEARCH_AMD_EXPORT float usearch_amd_settle(void);
 USEARCH_AMD_EXPORT float usearch_amd_snapshot_settle_ms(usearch_amd_snapshot_t snapshot);

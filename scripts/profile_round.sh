@@ -14,7 +14,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 if [ -z "${PROFILE_EF:-}" ]; then
-  python "$REPO/bench.py" "$@" --no-cpu-baseline --no-stress-rows --no-placement-check --no-secondary --no-condition --steps 5 --warmup 2 > "$OUT/pick.json" 2> "$OUT/pick.log"
+  python "$REPO/bench.py" "$@" --no-cpu-baseline --no-stress-rows --no-placement-check --no-secondary --steps 5 --warmup 2 > "$OUT/pick.json" 2> "$OUT/pick.log"
   tail -4 "$OUT/pick.log"
   EF=$(python -c "import json; print(json.load(open('$OUT/pick.json'))['config']['expansion_search'])" 2>/dev/null || echo 256)
 else
@@ -25,7 +25,8 @@ fi
 WARMUP=${PROFILE_WARMUP:-1}
 QUICK="$* --expansion $EF --recall-queries 0 --no-cpu-baseline --no-stress-rows --no-host-api --no-placement-check --no-secondary --steps ${PROFILE_STEPS:-5} --warmup $WARMUP"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python "$REPO/bench.py" $QUICK > "$OUT/stats_bench.json" 2> "$OUT/stats.log"
-QUICK="$QUICK --no-condition"   # the counter passes: the level the placement lands on does not enter the bytes
+QUICK="$QUICK --no-tune"   # the counter passes: which level the placement lands on does not enter the bytes
+
 find "$OUT/stats" -name "*kernel_stats.csv" | head -1 | while read f; do cp "$f" "$OUT/kernel_stats.csv"; done
 # the timed launches alone (the whole-process average above also covers the placement draws' candidates)
 find "$OUT/stats" -name "*kernel_trace.csv" | head -1 | while read f; do

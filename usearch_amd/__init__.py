@@ -4,6 +4,6 @@
 walks it with hand-written gfx950 kernels. See DESIGN.md.
 """
 from .index import (BatchMatches, BuildConfig, BuildStats, BuiltIndex, Index, build, Matches, Stats, Tuning, cast, device_count, exact_search,  # noqa: F401
-                    library, merge_many, note_device_free, settle, condition_device, LIBRARY_PATH, EXPORTED_SYMBOLS)
+                    library, merge_many, note_device_free, settle, LIBRARY_PATH, EXPORTED_SYMBOLS)
 
-__all__ = ["Index", "BuiltIndex", "build", "Matches", "BatchMatches", "Tuning", "Stats", "cast", "device_count", "library", "note_device_free", "settle", "condition_device"]
+__all__ = ["Index", "BuiltIndex", "build", "Matches", "BatchMatches", "Tuning", "Stats", "cast", "device_count", "library", "note_device_free", "settle"]

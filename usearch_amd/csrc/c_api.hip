@@ -249,13 +249,14 @@ void usearch_amd_snapshot_placement(usearch_amd_snapshot_t s, uint32_t* draws, u
     if (probe_ms)
         *probe_ms = placement.probe_ms;
 }
-float usearch_amd_condition_device(int device, size_t spare_bytes, usearch_amd_error_t* error) {
-    if (hipSetDevice(device) != hipSuccess)
-        return fail(error, "No such device"), -1.f;
-    const float seconds = condition_device(spare_bytes);
-    if (seconds < 0.f)
-        fail(error, "The device could not be conditioned: no large allocation succeeded");
-    return seconds;
+uint32_t usearch_amd_snapshot_tune(usearch_amd_snapshot_t s, void const* queries, size_t count, size_t stride, size_t wanted,
+                                   size_t expansion, uint32_t max_trials, usearch_amd_error_t* error) try {
+    std::uint32_t made = 0;
+    if (const char* e = as_snapshot(s)->tune(queries, count, stride, wanted, expansion, max_trials, &made))
+        fail(error, e);
+    return made;
+} catch (...) {
+    return fail_from_exception(error), 0u;
 }
 void usearch_amd_note_device_free(void) { note_release((std::size_t)1 << 40); }
 float usearch_amd_settle(void) { return settle_before_placing(); }

@@ -992,9 +992,12 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         if (call.mode == scratch_hash_k && !params.team && lanes_ <= 2) {
             // how the slab is probed (common.hpp `probe_mode_t`): USEARCH_AMD_PROBE_MODE = 0 | 1 | 2
             // (USEARCH_AMD_PROBE_LOAD_FIRST=1, round 5's name for mode 1, still answers)
-            std::size_t probe_mode = env_size("USEARCH_AMD_PROBE_MODE", default_probe_mode_k);
+            std::size_t probe_mode = default_probe_mode_k;
+#ifdef USEARCH_AMD_EXPERIMENT_PROBE_MODES // `make EXTRA=-DUSEARCH_AMD_EXPERIMENT_PROBE_MODES OUT=… OBJ=…`: the copy scripts/probe_mode_check.py loads
+            probe_mode = env_size("USEARCH_AMD_PROBE_MODE", default_probe_mode_k);
             if (env_size("USEARCH_AMD_PROBE_LOAD_FIRST", 0))
                 probe_mode = probe_load_first_k;
+#endif
             if (probe_mode == probe_plain_k) {
                 // one claim bit per cell of the slab where that costs no resident wave, else as many as do not (a smaller bitmap only
                 // adds false alarms: a lane that loses a claim looks at its cell again); USEARCH_AMD_CLAIM_BITS forces a number
@@ -1006,7 +1009,7 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
                     while (bits > 512 && waves_for((wave_lds_bytes + 15) / 16 * 16 + bits / 8) < waves_for(wave_lds_bytes))
                         bits /= 2;
                 if ((wave_lds_bytes + 15) / 16 * 16 + bits / 8 <= lds_budget) {
-                    args.probe_mode = probe_plain_k;
+                    args.probe_mode = (std::uint32_t)probe_mode;
                     args.claim_offset = (std::uint32_t)((wave_lds_bytes + 15) / 16 * 16);
                     args.claim_bits = bits;
                     wave_lds_bytes = args.claim_offset + bits / 8ull;
@@ -1143,7 +1146,8 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         //      OFF unless USEARCH_AMD_PLACEMENT_DRAWS = 2 … 8 asks for them (round 6): the matrix is placed once, at load time, after
         //      the settle window (placement.hpp) — deterministic, no second copy of the matrix in HBM during a search call, nothing
         //      swapped under a reader. The trials stay for hosts whose matrix was allocated while other gigabytes were held.
-        const std::uint32_t matrix_draws = (std::uint32_t)std::min<std::size_t>(placement_max_draws_k, env_size("USEARCH_AMD_PLACEMENT_DRAWS", 1));
+        const std::uint32_t matrix_draws = tuning_trials_ ? tuning_trials_ + 1u + placement_.draws
+                                                          : (std::uint32_t)std::min<std::size_t>(placement_max_draws_k, env_size("USEARCH_AMD_PLACEMENT_DRAWS", 1));
         // A host that tunes its expansion walks up through the regimes (bench.py's recall sweep: 64, 96, 128 … 608): trials judged at a
         // small expansion — differences of hundredths of a millisecond — must not be the last word for launches several times as
         // wide. A launch more than twice as wide as the last trial's reopens a search that has ended, for three trials, twice at most.
@@ -1392,6 +1396,50 @@ const char* snapshot_t::search_device(const void* queries, std::size_t count, st
         return error;
     }
     return search_finish(call, stats);
+}
+
+const char* snapshot_t::tune(const void* queries, std::size_t count, std::size_t stride_bytes, std::size_t wanted, std::size_t expansion,
+                             std::uint32_t max_trials, std::uint32_t* trials_made) {
+    if (trials_made)
+        *trials_made = 0;
+    max_trials = std::min<std::uint32_t>(max_trials, (std::uint32_t)placement_max_draws_k);
+    if (!count || !wanted || !max_trials || !d_vectors_)
+        return nullptr;
+    UA_HIP(hipSetDevice(device_));
+    // the sample's results go nowhere: a scratch block for them
+    struct block_t {
+        void* p = nullptr;
+        ~block_t() { (void)hipFree(p); }
+    } results;
+    const std::size_t pad = 256, keys_bytes = (count * wanted * 8 + pad - 1) / pad * pad, distances_bytes = (count * wanted * 4 + pad - 1) / pad * pad,
+                      column = (count * 8 + pad - 1) / pad * pad;
+    UA_HIP(hipMalloc(&results.p, keys_bytes + distances_bytes + 3 * column));
+    std::uint8_t* base = static_cast<std::uint8_t*>(results.p);
+    const std::uint32_t before = placement_.draws;
+    {
+        std::lock_guard<std::mutex> lock(pool_mutex_);
+        tuning_trials_ = max_trials;
+        placement_trials_left_ = max_trials, placement_losses_ = 0, placement_reopens_ = 2; // no reopening: this call is the search
+    }
+    const char* failure = nullptr;
+    for (std::uint32_t launch = 0; launch < max_trials + 1u && !failure; ++launch) { // every chip-filling launch makes at most one trial
+        failure = search_device(queries, count, stride_bytes, wanted, expansion, reinterpret_cast<std::uint64_t*>(base),
+                                reinterpret_cast<float*>(base + keys_bytes), reinterpret_cast<std::uint64_t*>(base + keys_bytes + distances_bytes),
+                                reinterpret_cast<std::uint64_t*>(base + keys_bytes + distances_bytes + column),
+                                reinterpret_cast<std::uint64_t*>(base + keys_bytes + distances_bytes + 2 * column), nullptr, search_tuning_t{},
+                                nullptr, false);
+        std::lock_guard<std::mutex> lock(pool_mutex_);
+        if (!placement_trials_left_ || placement_.draws == before + launch) // over, or this launch could not make one (sample too small …)
+            break;
+    }
+    {
+        std::lock_guard<std::mutex> lock(pool_mutex_);
+        tuning_trials_ = 0;
+        placement_trials_left_ = 0;
+    }
+    if (trials_made)
+        *trials_made = placement_.draws - before;
+    return failure;
 }
 
 const char* snapshot_t::last_peaks(std::uint32_t* out, std::size_t queries) {

@@ -152,6 +152,21 @@ class snapshot_t {
                               const search_extras_t* extras = nullptr);
 
     /**
+     *  TUNES WHERE THE MATRIX SITS, on the caller's own sample batch (round 6; `usearch_amd_snapshot_tune`). Which frames of HBM the
+     *  matrix of stored rows received decides how fast the walk runs over it — 44.4 … 51.4 ms for the headline batch over the same
+     *  bytes, per box and per what the process allocated before (profiles/r06_settled/) — and nothing but the walk itself tells the
+     *  placements apart. So a host that is about to serve one shape of batch hands over a sample of it: up to `max_trials` times a
+     *  fresh device-to-device copy of the matrix is placed and timed against the incumbent on the sample's first queries (one per
+     *  resident wave, at the sample's expansion: `try_matrix_placement`), the faster stays, the other is freed — and because the
+     *  driver hands freed frames back late, consecutive copies land on different frames. Three wins of the incumbent in a row end
+     *  it early. EXPLICIT and synchronous: nothing of it ever happens inside a search call (round 5 ran these trials there; the
+     *  advisor's finding), a second copy of the matrix exists in HBM only during this call, and the matrix does not move afterwards.
+     *  Arrays under 1 GiB, inline-row snapshots and samples that do not fill the chip are left alone (returns 0 trials).
+     */
+    const char* tune(const void* queries, std::size_t count, std::size_t stride_bytes, std::size_t wanted, std::size_t expansion,
+                     std::uint32_t max_trials, std::uint32_t* trials_made);
+
+    /**
      *  The same search in two halves, for callers that append their own work to the stream before anybody waits (the
      *  sharded step: search → all-gather → merge, one stream, one wait): `search_begin` sizes the scratch, leases a
      *  workspace and launches; `search_finish` waits, and re-runs what outgrew its scratch (`reran` tells the caller that
@@ -296,6 +311,7 @@ class snapshot_t {
     std::uint32_t placement_losses_ = 0;                          ///< trials in a row the incumbent has won
     std::uint32_t placement_last_ef_ = 0, placement_reopens_ = 0; ///< the expansion of the last trial; how often a wider regime reopened the search
     bool placing_ = false;            ///< a trial owns the matrix: `take` waits (guarded by pool_mutex_)
+    std::uint32_t tuning_trials_ = 0; ///< > 0 only inside `tune`: the trials `run_ladder` may make there (0: the environment decides)
     std::size_t vectors_bytes_ = 0;   ///< bytes allocated behind d_vectors_
     int compute_units_ = 256;
     float last_distances_ms_ = 0.f;

@@ -1647,9 +1647,46 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                 //    to one address are served in issue order). The words touched go back to zero behind the ORs. A list holds every
                 //    slot once (duplicates were removed on upload), so no two lanes of a round insert the same slot. One round trip
                 //    per probe round, same members in the set, same answers (which CELL a member lands in is not observable).
+                bool shadow_done = false;
+                auto shadow_work = [&]() {
+                    if (shadow_done)
+                        return;
+                    shadow_done = true;
+                // ---- in the shadow of the probe's round trip (short rows, round 6). The walk of a short-row index is a chain of
+                //      dependent round trips per hop — list, probe of the visited set, rows, commit — and not bytes; what does not
+                //      NEED the probe's answer goes in front of the wait for it:
+                //       * rows that arrived with the list (`nbr0_rows`): every lane measures its neighbour now, fresh or not;
+                //       * rows of ≤ 128 bytes (G = 2; `args.early_rows`): the rows of every neighbour the probe asks about are
+                //         gathered NOW, next to the probe instead of behind it — one dependent round trip less per hop for about
+                //         two thirds more row traffic (four asked-about neighbours in ten turn out visited), on a walk that sits
+                //         at a quarter of the memory's bandwidth. Distances of visited neighbours are dropped; `computed` counts
+                //         the fresh ones as the reference does.
+                if constexpr (inline_ak) {
+                    if (inline_rows) {
+                        partial_t p;
+                        accumulate_chunk<metric_ak, scalar_ak>(p, query_lds, 0, inline_row);
+                        early_mine = finalize_distance<metric_ak, scalar_ak>(p, a2, ix.dimensions);
+                        early_done = true;
+                    }
+                }
+                if constexpr (early_ak) {
+                    if (early_rows && tile == 0) {
+                        asked_mask = ballot(asks);
+                        const std::uint32_t asked = popcount64(asked_mask);
+                        if (asks)
+                            cand_slots[rank_below(asked_mask, lane)] = neighbor;
+                        wave_sync<false>();
+                        if (asked)
+                            measure_rows<metric_ak, scalar_ak, lanes_ak, loads_ak, false, 1>(ix, query_lds, a2, cand_slots, cand_distances, asked);
+                        measured_early = true;
+                    }
+                }
+                };
                 std::uint32_t probe_mode = probe_swap_k;
+#ifdef USEARCH_AMD_EXPERIMENT_PROBE_MODES // modes 1 and 2 measured slower (profiles/r06_short_rows/): product builds compile them away
                 if constexpr (seen_ak)
                     probe_mode = args.probe_mode;
+#endif
                 const bool load_first = probe_mode == probe_load_first_k;
                 if (probe_mode == probe_plain_k) {
                     std::uint32_t* claim = reinterpret_cast<std::uint32_t*>(query_lds + args.claim_offset);
@@ -1661,6 +1698,7 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                             cell_value = __hip_atomic_load(visits + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (!popped)
                             pop_now(); // LDS and register work in the shadow of the first round trip
+                        shadow_work();
                         const bool wants = looking && cell_value == none_slot_k;
                         if (looking && cell_value == neighbor)
                             looking = false; // in the set (`old` still names the slot itself: not fresh)
@@ -1695,35 +1733,7 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                 }
                 if (!popped)
                     pop_now();
-                // ---- in the shadow of the probe's round trip (short rows, round 6). The walk of a short-row index is a chain of
-                //      dependent round trips per hop — list, probe of the visited set, rows, commit — and not bytes; what does not
-                //      NEED the probe's answer goes in front of the wait for it:
-                //       * rows that arrived with the list (`nbr0_rows`): every lane measures its neighbour now, fresh or not;
-                //       * rows of ≤ 128 bytes (G = 2; `args.early_rows`): the rows of every neighbour the probe asks about are
-                //         gathered NOW, next to the probe instead of behind it — one dependent round trip less per hop for about
-                //         two thirds more row traffic (four asked-about neighbours in ten turn out visited), on a walk that sits
-                //         at a quarter of the memory's bandwidth. Distances of visited neighbours are dropped; `computed` counts
-                //         the fresh ones as the reference does.
-                if constexpr (inline_ak) {
-                    if (inline_rows) {
-                        partial_t p;
-                        accumulate_chunk<metric_ak, scalar_ak>(p, query_lds, 0, inline_row);
-                        early_mine = finalize_distance<metric_ak, scalar_ak>(p, a2, ix.dimensions);
-                        early_done = true;
-                    }
-                }
-                if constexpr (early_ak) {
-                    if (early_rows && tile == 0) {
-                        asked_mask = ballot(asks);
-                        const std::uint32_t asked = popcount64(asked_mask);
-                        if (asks)
-                            cand_slots[rank_below(asked_mask, lane)] = neighbor;
-                        wave_sync<false>();
-                        if (asked)
-                            measure_rows<metric_ak, scalar_ak, lanes_ak, loads_ak, false, 1>(ix, query_lds, a2, cand_slots, cand_distances, asked);
-                        measured_early = true;
-                    }
-                }
+                shadow_work();
                 while (old != none_slot_k && old != neighbor) { // linear probing, index.hpp:1085-1211
                     h = (h + 1) & visits_mask;
                     if (load_first) {

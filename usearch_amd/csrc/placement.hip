@@ -301,32 +301,6 @@ float settle_before_placing() {
     return waited;
 }
 
-float condition_device(std::size_t spare_bytes) {
-    const auto started = std::chrono::steady_clock::now();
-    (void)hipDeviceSynchronize();
-    std::size_t free_bytes = 0, total_bytes = 0;
-    if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess)
-        return (void)hipGetLastError(), -1.f;
-    spare_bytes = std::max<std::size_t>(spare_bytes, (std::size_t)2 << 30);
-    if (free_bytes <= spare_bytes + ((std::size_t)4 << 30))
-        return -1.f;
-    void* block = nullptr;
-    std::size_t wanted = free_bytes - spare_bytes;
-    for (int attempt = 0; attempt < 8 && !block; ++attempt, wanted -= std::min<std::size_t>(wanted / 2, (std::size_t)4 << 30))
-        if (hipMalloc(&block, wanted) != hipSuccess) {
-            (void)hipGetLastError();
-            block = nullptr;
-        }
-    if (!block)
-        return -1.f;
-    (void)hipFree(block);
-    note_release(wanted);
-    const float seconds = std::chrono::duration<float>(std::chrono::steady_clock::now() - started).count();
-    if (env_size("USEARCH_AMD_PLACEMENT_LOG", 0))
-        std::fprintf(stderr, "[usearch_amd] device conditioned: one block of %.1f GB allocated and freed in %.1f s\n", wanted / 1e9, seconds);
-    return seconds;
-}
-
 void settle_totals(float* milliseconds, std::uint32_t* waits) {
     std::lock_guard<std::mutex> lock(settle_mutex);
     if (milliseconds)
@@ -461,9 +435,6 @@ hipError_t placed_malloc(void** out, std::size_t bytes, std::size_t, placement_t
     bytes = std::max<std::size_t>(bytes, 16);
     if (bytes < env_size("USEARCH_AMD_PLACEMENT_MIN_BYTES", (std::size_t)1 << 30))
         return block_malloc(out, bytes);
-    static std::atomic<bool> conditioned{false};
-    if (env_size("USEARCH_AMD_CONDITION", 0) && !conditioned.exchange(true))
-        (void)condition_device((std::size_t)6 << 30); // placement.hpp: once per process, on request only
     const float waited = settle_before_placing(); // placement.hpp: settle, then allocate
     if (report)
         report->settle_ms = waited;

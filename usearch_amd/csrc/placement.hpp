@@ -77,19 +77,7 @@ float settle_before_placing();
 /// Milliseconds `settle_before_placing` has waited in this process so far, and how often it had to.
 void settle_totals(float* milliseconds, std::uint32_t* waits);
 
-/**
- *  CONDITIONING (round 6, profiles/r06_settled/settle_study.log). The settle window makes a placement reproducible INSIDE a process
- *  (the same image loaded twice: 45.10 / 45.06 ms, 48.31 / 48.28 ms for the headline batch) — which level it lands on still differs
- *  from process to process on a box whose frame allocator earlier processes left shuffled (45.1 against 48.3 ms; the first process of
- *  a session 47.0 ms). What puts the allocator into its good state is ONE allocation of (nearly) all free device memory, freed at
- *  once: the driver coalesces and wipes everything, and every array placed afterwards — by this process and by the ones after it —
- *  gets the large contiguous cleared blocks (44.4 ms, eleven loads in six processes after the first conditioning; the same memory taken
- *  in 2-GB pieces does not do it: 45.3). It costs 3 … 10 s of allocation and wiping, so it is never done behind a caller's back: a host
- *  that loads a big index at start-up asks for it (`usearch_amd_condition_device`, or USEARCH_AMD_CONDITION=1 in the environment: the
- *  first array of ≥ USEARCH_AMD_PLACEMENT_MIN_BYTES placed by this process conditions the device first). `spare_bytes` stay free.
- *  Returns the seconds spent, < 0 when no allocation succeeded.
- */
-float condition_device(std::size_t spare_bytes);
+
 
 /// The probe alone: GB/s of a dependency-free gather of random `row_bytes`-byte rows of `base[0 .. bytes)`.
 hipError_t gather_probe(const void* base, std::size_t bytes, std::size_t row_bytes, float* gbps);

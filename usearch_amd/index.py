@@ -88,7 +88,7 @@ EXPORTED_SYMBOLS = [
     "usearch_amd_snapshot_free", "usearch_amd_snapshot_size", "usearch_amd_snapshot_dimensions",
     "usearch_amd_snapshot_connectivity", "usearch_amd_snapshot_max_level", "usearch_amd_snapshot_bytes_per_vector",
     "usearch_amd_snapshot_row_stride", "usearch_amd_snapshot_device_bytes", "usearch_amd_snapshot_placement", "usearch_amd_snapshot_arrays",
-    "usearch_amd_note_device_free", "usearch_amd_settle", "usearch_amd_snapshot_settle_ms", "usearch_amd_condition_device",
+    "usearch_amd_note_device_free", "usearch_amd_settle", "usearch_amd_snapshot_settle_ms", "usearch_amd_snapshot_tune",
     "usearch_amd_snapshot_scalar_kind",
     "usearch_amd_snapshot_metric_kind", "usearch_amd_snapshot_lanes_per_row", "usearch_amd_snapshot_inline_rows",
     "usearch_amd_search_many",
@@ -160,8 +160,8 @@ def library() -> C.CDLL:
         f.argtypes = [C.c_void_p]
     L.usearch_amd_note_device_free.restype = None
     L.usearch_amd_note_device_free.argtypes = []
-    L.usearch_amd_condition_device.restype = C.c_float
-    L.usearch_amd_condition_device.argtypes = [C.c_int, C.c_size_t, err_p]
+    L.usearch_amd_snapshot_tune.restype = C.c_uint32
+    L.usearch_amd_snapshot_tune.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, err_p]
     L.usearch_amd_settle.restype = C.c_float
     L.usearch_amd_settle.argtypes = []
     L.usearch_amd_snapshot_settle_ms.restype = C.c_float
@@ -430,6 +430,17 @@ class Index:
                 "draws": int(draws.value), "kept": int(kept.value), "probe_ms": round(float(probe_ms.value), 2),
                 "judge_ms": [round(float(rates[i]), 3) for i in range(shown)],
                 "incumbent_ms": [round(float(incumbents[i]), 3) for i in range(shown)]}
+
+    def tune_device(self, queries_ptr: int, queries_count: int, queries_stride: int, count: int, expansion: int, max_trials: int = 8) -> int:
+        """`usearch_amd_snapshot_tune`: places the matrix of stored rows by trial on a SAMPLE of the batches to come (device-resident
+        queries in the storage kind, as for `search_device`): up to `max_trials` fresh copies timed against the incumbent on the
+        sample's first queries at `expansion`, the faster stays. Explicit, synchronous, before serving; returns the trials made
+        (`placement` has their times)."""
+        err = C.c_char_p()
+        made = library().usearch_amd_snapshot_tune(self._handle, C.c_void_p(queries_ptr), queries_count, queries_stride, count, expansion,
+                                                   max_trials, C.byref(err))
+        _raise(err, "usearch_amd_snapshot_tune")
+        return int(made)
 
     @property
     def arrays(self) -> "Arrays":
@@ -836,16 +847,6 @@ def note_device_free() -> None:
     """Tells the engine that the host just released device memory through another allocator (`torch.cuda.empty_cache()`): the next
     loader or builder waits out the driver's settle window before it places its matrix (csrc/placement.hpp)."""
     library().usearch_amd_note_device_free()
-
-
-def condition_device(device: int = 0, spare_bytes: int = 6 << 30) -> float:
-    """One allocation of all free device memory but `spare_bytes`, freed at once (`usearch_amd_condition_device`): the driver's frame
-    allocator coalesces and wipes everything, and the arrays placed afterwards land on large contiguous blocks — the level the walk
-    runs at stops depending on what ran on the device before. 3 … 10 s; once, at start-up, before a big index is loaded."""
-    err = C.c_char_p()
-    seconds = library().usearch_amd_condition_device(device, spare_bytes, C.byref(err))
-    _raise(err, "usearch_amd_condition_device")
-    return float(seconds)
 
 
 def settle() -> float:
