@@ -90,3 +90,41 @@ def test_baseline_shapes_at_scale_match_the_reference(reference, n, dim, dtype, 
     again = restored.search(batch, k, expansion=expansion, dtype=dtype)
     assert np.array_equal(again.keys, got.keys) and util.same_float_bits(again.distances, got.distances)
     assert np.array_equal(again.computed_per_query, got.computed_per_query)
+
+
+def test_tuning_the_placement_moves_nothing_but_the_matrix(reference):
+    """`usearch_amd_snapshot_tune`: the host hands a sample batch, the engine times fresh copies of the matrix of
+    stored rows against the incumbent on the sample's first queries and keeps the fastest. Whatever it decides, the index answers as
+    before — keys, distance bits and both counters — every trial is reported, nothing is tried for arrays under 1 GiB or samples that do
+    not fill the chip, and no later search call runs a trial on its own."""
+    import torch
+
+    import bench
+    import usearch_amd
+    device = torch.device("cuda", 0)
+    n, dim, dtype, queries, k, expansion = 1_000_000, 768, "f32", 8192, 10, 64
+    data = bench.synthetic_vectors_device(n, dim, dtype, 42, device)
+    built = usearch_amd.build(None, "cos", dtype, device_pointer=data.data_ptr(), count=n, stride=data.stride(0), ndim=dim)
+    del data
+    torch.cuda.empty_cache()
+    index = usearch_amd.Index.restore(built.save_buffer())
+    built.close()
+    batch_device = bench.synthetic_vectors_device(queries, dim, dtype, 43, device)
+    batch = batch_device.cpu().numpy().view(bench.NUMPY_STORAGE[dtype])
+    before = index.search(batch, k, expansion=expansion, dtype=dtype)
+    assert index.placement["draws"] == 0, "no search call runs a placement trial on its own"
+    trials = index.tune_device(batch_device.data_ptr(), queries, batch_device.stride(0), k, expansion, max_trials=4)
+    report = index.placement
+    assert 1 <= trials <= 4 and report["draws"] == trials and len(report["judge_ms"]) == trials and 0 <= report["kept"] <= trials
+    assert all(ms > 0 for ms in report["judge_ms"] + report["incumbent_ms"])
+    after = index.search(batch, k, expansion=expansion, dtype=dtype)
+    assert np.array_equal(after.keys, before.keys) and util.same_float_bits(after.distances, before.distances)
+    assert np.array_equal(after.computed_per_query, before.computed_per_query) and np.array_equal(after.visited_per_query, before.visited_per_query)
+    assert index.placement["draws"] == trials, "… nor afterwards"
+    # a sample that does not fill the chip twice over is no judge: nothing is tried
+    assert index.tune_device(batch_device.data_ptr(), 256, batch_device.stride(0), k, expansion) == 0
+    # nor is anything tried for a matrix under 1 GiB
+    small_image, _, _ = util.build_image(3000, 96, "cos", "f16", seed=5)
+    small = usearch_amd.Index.restore(small_image)
+    small_batch = bench.synthetic_vectors_device(8192, 96, "f16", 44, device)
+    assert small.tune_device(small_batch.data_ptr(), 8192, small_batch.stride(0), k, expansion) == 0 and small.placement["draws"] == 0

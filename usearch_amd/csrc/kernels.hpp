@@ -1471,14 +1471,27 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                 }
                 ++cycles;
                 const bool present = neighbor != none_slot_k;
-                const std::uint32_t present_count = popcount64(ballot(present));
+                const std::uint64_t present_mask = ballot(present);
+                const std::uint32_t present_count = popcount64(present_mask);
                 std::uint32_t count = 0;
+                bool fresh = false;
                 tick(1);
                 if (present_count) {
                     if (visits_count + present_count > visits_limit) {
                         overflow = true;
                         break;
                     }
+                    // A team serves batches that leave the chip mostly idle (a `usearch_search` caller's single query above all):
+                    // bytes are free, the hop's chain of round trips is what the caller waits for. So the helpers get EVERY
+                    // neighbour of the list at once (round 6) — they gather and measure while the leader probes the visited set
+                    // (two or three dependent round trips to the slab), instead of waiting for the probe to name the fresh ones.
+                    // Four helpers of eight lane groups take 32 rows in one round either way; the distances of neighbours that
+                    // turn out visited are dropped, `computed` counts the fresh ones as the reference does.
+                    if (present)
+                        cand_slots[rank_below(present_mask, lane)] = neighbor; // list order
+                    if (lane == 0)
+                        team->count = present_count, team->leader_in = 0u, team->a2 = a2;
+                    team_barrier(); // the helpers fetch and measure the rows …
                     std::uint32_t h = hash_slot(neighbor) & visits_mask;
                     std::uint32_t old = neighbor; // an absent lane probes nothing
                     if (present)
@@ -1487,12 +1500,9 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                         h = (h + 1) & visits_mask;
                         old = atomicCAS(visits + h, none_slot_k, neighbor);
                     }
-                    const bool fresh = present && old == none_slot_k;
-                    const std::uint64_t fresh_mask = ballot(fresh);
-                    count = popcount64(fresh_mask);
+                    fresh = present && old == none_slot_k;
+                    count = popcount64(ballot(fresh));
                     visits_count += count;
-                    if (fresh)
-                        cand_slots[rank_below(fresh_mask, lane)] = neighbor; // keeps list order
                 }
                 // its list is requested now, a hop ahead (the commit below may still put a newcomer of the hop before in front of it) —
                 // and only now that this hop's own list has been consumed: loads return in order, and a wait for that list placed
@@ -1503,13 +1513,8 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                         ahead_cell = lane < cells ? list_of(likely)[lane] : none_slot_k;
                 }
                 tick(2);
-                if (count) {
-                    if (lane == 0)
-                        team->count = count, team->leader_in = 0u, team->a2 = a2;
-                    team_barrier(); // the helpers fetch and measure the rows …
-                }
                 if (pending)
-                    commit(from_lane); // … while the hop before lands in `top`
+                    commit(from_lane); // … while the leader probes and the hop before lands in `top`
                 // … and if that put a newcomer in front of the member whose list was just asked for, its list is asked for too
                 {
                     float ahead_distance;
@@ -1523,13 +1528,15 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                     }
                 }
                 tick(4);
-                if (count) {
+                if (present_count) {
                     team_barrier(); // every share is in LDS
-                    candidate = lane < count;
-                    mine = candidate ? cand_distances[lane] : 0.f;
-                    mine_slot = candidate ? cand_slots[lane] : 0u;
-                    computed += count;
-                    pending = true;
+                    if (count) {
+                        candidate = fresh; // lanes in list order, the visited ones among them skipped
+                        mine = fresh ? cand_distances[rank_below(present_mask, lane)] : 0.f;
+                        mine_slot = fresh ? neighbor : 0u;
+                        computed += count;
+                        pending = true;
+                    }
                 }
                 tick(3);
             }
