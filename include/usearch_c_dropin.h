@@ -191,11 +191,11 @@ USEARCH_EXPORT void usearch_search_exact_many(usearch_index_t index, void const*
  *  The reference runs it inside the traversal, for the members it is about to admit to the result buffer — a few hundred to a few
  *  thousand calls per query (index.hpp:4200-4205, 4236-4240). A host function cannot run on the device; this library evaluates it
  *  LAZILY (round 6, csrc/dropin.hip `lazy_predicate_t`): the walk runs with two bits per slot in HBM — "the host has answered for
- *  this member" and its answer — treats a member it wants to admit that is not known yet as allowed while posting its key to an ask
+ *  this member" and its answer — admits a member it has no answer for yet with the share of "yes" among the answers so far while posting its key to an ask
  *  list; the host answers what was asked and the query runs again, until a run asks nothing. That run has seen the true predicate
  *  wherever it looked: it is the reference's traversal (same keys, distances, counters). Every member is asked about at most once
  *  per call, and about as many as the reference asks about (tests/test_gpu_dropin.py: no more than twice its count at
- *  selectivities 1 … 1/20). A predicate that rejects nearly everything keeps pushing the walk outward: after 12 runs the rest is
+ *  selectivities 1 … 1/20). A predicate that rejects nearly everything keeps pushing the walk outward: after 48 runs (or a run that asks about more than 65 536 members) the rest is
  *  evaluated for every member (`USEARCH_AMD_FILTER_LAZY=0`, read at `usearch_init`, does that from the start: one callback per
  *  member per call, the behaviour up to round 5). A caller that searches more than once under one predicate, or that can say what
  *  the predicate IS, still does better with a filter made once: a bitmap (built by a kernel over the keys in HBM for ranges and key
