@@ -645,7 +645,7 @@ def main() -> None:
                         help="skip BASELINE.json's other configurations (c1, c2, c4, c5 — each in a process of its own, summarised "
                              "under config.secondary of the default line)")
     parser.add_argument("--secondary", default="c1,c2,c4,c5", help="which presets ride along with the default line")
-    parser.add_argument("--secondary-timeout", type=float, default=600.0, help="seconds one secondary configuration may take")
+    parser.add_argument("--secondary-timeout", type=float, default=420.0, help="seconds one secondary configuration may take")
     parser.add_argument("--exact", action="store_true",
                         help="time the exact (brute-force) search of the batch through the matrix-unit kernel instead of the graph walk")
     parser.add_argument("--max-batch", type=int, default=int(os.environ.get("BENCH_MAX_BATCH", 0)),
