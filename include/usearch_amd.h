@@ -84,6 +84,8 @@ typedef struct usearch_amd_stats_t {
     uint32_t seen_cells;     /**< … `seen` cells in LDS in front of the slab */
     uint32_t claim_bits;     /**< … claim bits in LDS (probe_mode 2) */
     uint32_t early_rows;     /**< rows of ≤ 128 bytes: 1 = a hop's rows were gathered next to the probe of the visited set, not behind it */
+    uint32_t plain;          /**< rows of ≤ 128 bytes: 1 = the launch ran the kernel build cut for plain batches (level 0, no predicate, no
+                                  tombstones, lists of ≤ 64 cells); USEARCH_AMD_NO_PLAIN=1 keeps the general build. Same results */
 } usearch_amd_stats_t;
 
 /** Number of visible HIP devices; 0 (and an error) when the runtime finds none. */

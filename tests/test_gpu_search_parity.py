@@ -482,3 +482,68 @@ def test_graph_only_image_with_the_callers_vectors(reference):
         parts = Index.restore(graph_only, vectors=matrix).search(queries, 10)
         assert np.array_equal(parts.keys, whole.keys) and util.same_float_bits(parts.distances, whole.distances)
         assert np.array_equal(parts.computed_per_query, whole.computed_per_query)
+
+
+# (metric, dtype, ndim, n, connectivity, k, expansion, queries, forced tuning, the plain build exists)
+PLAIN_CONFIGS = [
+    ("hamming", "b1", 128, 5000, 16, 10, 64, 300, {}, True),      # config 5's kernel: rows inline with the lists, one `top` cell per lane
+    ("hamming", "b1", 128, 5000, 16, 10, 100, 200, {}, True),     # two `top` cells per lane
+    ("hamming", "b1", 96, 3000, 5, 7, 32, 200, {}, True),         # lists of 10 cells
+    ("l2sq", "i8", 96, 4000, 16, 10, 64, 200, {}, True),          # config 4's rows (G = 2): gathered next to the probe
+    ("l2sq", "i8", 96, 4000, 16, 10, 80, 200, {}, True),          # config 4's kernel
+    ("cos", "i8", 96, 1500, 16, 10, 128, 80, {}, True),
+    ("ip", "i8", 16, 1200, 16, 10, 64, 100, {}, True),            # 16-byte rows of another pair inline
+    ("l2sq", "f16", 48, 1500, 16, 10, 64, 100, {"frontier": 1}, True),   # float pairs only when the heap is asked for
+    ("cos", "f32", 24, 1500, 16, 10, 64, 100, {"frontier": 1}, True),
+    ("l2sq", "f16", 48, 1500, 16, 10, 64, 100, {}, False),        # their default frontier rides in `top`: the general build
+    ("l2sq", "i8", 96, 1500, 40, 10, 64, 100, {}, False),         # lists of 80 cells: two tiles per hop
+    ("hamming", "b1", 128, 3000, 16, 10, 200, 100, {}, False),    # four `top` cells per lane
+    ("tanimoto", "b1", 128, 3000, 16, 10, 64, 100, {}, False),    # outside the common pairs
+]
+
+
+@pytest.mark.parametrize("metric,dtype,ndim,n,connectivity,k,expansion,nq,forced,exists", PLAIN_CONFIGS)
+def test_plain_build_of_the_short_row_walk(reference, monkeypatch, metric, dtype, ndim, n, connectivity, k, expansion, nq, forced, exists):
+    """Rows of ≤ 128 bytes over the global hash: a plain `search` batch runs the kernel build cut for it (kernels.hpp `plain_ak`:
+    level 0, no predicate / tombstones, lists of one tile, `seen` cells, rows inline or gathered next to the probe) wherever that
+    build exists, and the general build everywhere else. Both against the oracle bit for bit incl. both counters, against each
+    other, and against the compiled reference."""
+    from usearch_amd import Index, Tuning
+    image, vectors, ref_index = util.build_image(n, ndim, metric, dtype, seed=31, connectivity=connectivity)
+    queries = util.make_vectors(nq, ndim, dtype, seed=32, metric=metric)
+    queries[: nq // 4] = vectors[: nq // 4]
+    index = Index.restore(image)
+    assert index.lanes_per_row <= 2
+    monkeypatch.delenv("USEARCH_AMD_NO_PLAIN", raising=False)
+    first = check_against_oracle(index, image, queries, k, dtype, expansion, tuning=Tuning(mode=2, **forced))
+    assert first.stats.mode == 2 and first.stats.passes == 1
+    assert first.stats.plain == (1 if exists else 0)
+    monkeypatch.setenv("USEARCH_AMD_NO_PLAIN", "1")
+    general = check_against_oracle(index, image, queries, k, dtype, expansion, tuning=Tuning(mode=2, **forced))
+    assert general.stats.plain == 0 and general.stats.mode == 2
+    monkeypatch.delenv("USEARCH_AMD_NO_PLAIN")
+    assert np.array_equal(first.keys, general.keys) and util.same_float_bits(first.distances, general.distances)
+    assert np.array_equal(first.counts, general.counts)
+    assert np.array_equal(first.visited_per_query, general.visited_per_query)
+    assert np.array_equal(first.computed_per_query, general.computed_per_query)
+    if util.exact_pair(metric, dtype):
+        ref_index.expansion_search = expansion
+        rkeys, rdists, rcounts, rvisited, rcomputed = ref_index.search(queries, k, dtype=dtype, threads=1)
+        assert np.array_equal(first.keys, rkeys) and util.same_float_bits(first.distances, rdists)
+        assert np.array_equal(first.counts, rcounts)
+        assert np.array_equal(first.visited_per_query, rvisited) and np.array_equal(first.computed_per_query, rcomputed)
+
+
+def test_plain_build_steps_aside(reference):
+    """What the plain build takes for granted is checked per launch: a predicate, tombstones or a member's own row to leave out send the
+    same index through the general build (tests/test_gpu_filtered.py and test_gpu_build.py hold those against the oracle)."""
+    from usearch_amd import Index, Tuning
+    image, vectors, _ = util.build_image(4000, 128, "hamming", "b1", seed=33)
+    queries = util.make_vectors(128, 128, "b1", seed=34)
+    index = Index.restore(image)
+    assert index.search(queries, 10, expansion=64, dtype="b1", tuning=Tuning(mode=2)).stats.plain == 1
+    keys = np.arange(4000, dtype=np.uint64)
+    every_third = index.filter_keys(keys[keys % 3 == 0])
+    filtered = index.search(queries, 10, expansion=64, dtype="b1", tuning=Tuning(mode=2), filter=every_third)
+    assert filtered.stats.plain == 0 and filtered.stats.mode == 2
+    assert np.all(filtered.keys[np.arange(10)[None, :] < filtered.counts[:, None]] % 3 == 0)

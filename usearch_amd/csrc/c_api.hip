@@ -113,6 +113,7 @@ void stats_to_c(const search_stats_t& s, usearch_amd_stats_t* out) {
     out->seen_cells = s.seen_cells;
     out->claim_bits = s.claim_bits;
     out->early_rows = s.early_rows;
+    out->plain = s.plain;
 }
 
 void fail(usearch_amd_error_t* error, const char* message) {

@@ -1038,6 +1038,17 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
             call.stats.seen_cells = args.seen_cells;
             call.stats.claim_bits = args.claim_bits;
         }
+        // a plain `search` batch over short rows runs the build without the features it never uses (kernels.hpp `plain_ak`): the
+        // engine vouches here for everything that build takes for granted; USEARCH_AMD_NO_PLAIN=1 keeps the general build
+        params.plain = plain_build_exists(kernel_metric(metric_), scalar_, (int)lanes_, params.variant == variant_u4_w4_k,
+                                          call.mode == scratch_hash_k, (int)call.entries_per_lane, params.frontier == frontier_heap_k) &&
+                               !params.team && !view_.has_tombstones && view_.m0 <= 64 && view_.nbr0 && !args.query_ids && !args.beam_level &&
+                               !args.descent_only && !args.allow_bits && !args.exclude_own && args.seen_cells &&
+                               args.probe_mode == probe_swap_k && (lanes_ == 1 ? view_.nbr0_rows != nullptr && view_.chunks == 1 : args.early_rows != 0) &&
+                               !env_size("USEARCH_AMD_NO_PLAIN", 0)
+                           ? 1u
+                           : 0u;
+        call.stats.plain = params.plain;
         const std::uint64_t lds_bytes = params.team ? (wave_lds_bytes + 15) / 16 * 16 + team_bytes : wave_lds_bytes;
         args.team_offset = params.team ? (std::uint32_t)((wave_lds_bytes + 15) / 16 * 16) : 0u;
         const std::uint32_t grid = params.team ? pending
@@ -1246,6 +1257,7 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         args.wave_clock = nullptr;
         params.mode = scratch_global_k;
         params.team = 0;
+        params.plain = 0;
         params.entries_per_lane = 0;
         params.frontier = frontier_heap_k;
         params.grid = (std::uint32_t)chunk;

@@ -53,6 +53,7 @@ struct search_stats_t {
     std::uint32_t seen_cells = 0;        ///< … its `seen` cells in LDS
     std::uint32_t claim_bits = 0;        ///< … its claim bits in LDS (`probe_plain_k`)
     std::uint32_t early_rows = 0;        ///< rows of ≤ 128 bytes: 1 = gathered next to the probe of the visited set, not behind it
+    std::uint32_t plain = 0;             ///< short rows: 1 = the last launch ran the build cut for plain batches (kernels.hpp `plain_ak`)
 };
 
 /// What index construction asks of the search on top of a plain query batch (see search_args_t).
@@ -73,6 +74,14 @@ struct search_extras_t {
     bool exclude_own = false;                 ///< `search_to_update_`: a query's own stored row routes, never becomes a candidate
 };
 
+/// Whether an instantiation of the search kernel also exists in the cut for plain batches (kernels.hpp `plain_ak`; launch_impl.hpp
+/// instantiates exactly these): rows of ≤ 128 bytes of the common pairs, 4 loads in flight, the visited set in the global hash, `top` of
+/// one or two cells per lane, the reference's heap.
+inline constexpr bool plain_build_exists(metric_kind_t metric, scalar_kind_t scalar, int lanes, bool four_deep, bool global_hash,
+                                         int top_cells, bool heap) {
+    return all_kernel_builds(metric, scalar) && lanes <= 2 && four_deep && global_hash && (top_cells == 1 || top_cells == 2) && heap;
+}
+
 /// Per-scalar-kind launchers, one translation unit each (compile time): defined in search_<kind>.hip.
 struct launch_params_t {
     metric_kind_t metric;
@@ -85,6 +94,8 @@ struct launch_params_t {
     std::uint32_t lds_bytes;
     hipStream_t stream;
     std::uint32_t team = 0;       ///< 1 = five waves per query (team_search_kernel): small batches over long rows
+    std::uint32_t plain = 0;      ///< 1 = the short-row build cut for a plain `search` batch (kernels.hpp `plain_ak`): the engine vouches
+                                  ///< for level 0, no predicate / tombstones / own row, lists of ≤ 64 cells, `seen` cells, rows inline or early
 };
 
 /**

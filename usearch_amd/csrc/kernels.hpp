@@ -1163,12 +1163,21 @@ UA_DEVICE void team_share(const snapshot_view_t& ix, const std::uint8_t* query_l
  *  One query, start to finish. `heaps` = top/next/candidate arrays (LDS, or the slab in `scratch_global_k`), `visits` = the
  *  visited set (LDS hash, slab hash or slab bitmap). Returns false on scratch overflow (nothing written but `status`).
  */
-template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, int mode_ak, int epl_ak, int frontier_ak, int team_ak = 1>
+template <int metric_ak, int scalar_ak, int lanes_ak, int unroll_ak, int mode_ak, int epl_ak, int frontier_ak, int team_ak = 1,
+          bool plain_ak = false>
 UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, std::uint32_t q,
                           std::uint8_t* query_lds, std::uint8_t* heaps, std::uint32_t* visits, team_t* team = nullptr) {
     constexpr bool global_ak = mode_ak == scratch_global_k;
     constexpr bool in_top_ak = frontier_ak == frontier_top_k;
     static_assert(!in_top_ak || (epl_ak > 0 && !global_ak), "the frontier rides in the register layout of `top`");
+    // `plain_ak` (short rows, round 6): the walk of a plain `search` batch and nothing else — level 0, every member a result candidate
+    // (no predicate, no tombstones, no member's own row to leave out), lists of one tile, the `seen` cells in place, rows inline
+    // (G = 1) or gathered next to the probe (G = 2). The engine promises all of it (`launch_params_t::plain`) and the general build
+    // stays the one everything else runs. What it buys: the hop loop of the general build keeps ≈ 45 uniform values of features a
+    // plain batch never uses alive (the lazy predicate's six pointers, the beam level's lists, the modes' switches) — the b1 walk
+    // restored 89 spilled scalars per pass through its hop loop, every restore a vector-pipe instruction on SIMDs that are half
+    // issue-bound (profiles/r06_short_rows/README.md §3).
+    static_assert(!plain_ak || (lanes_ak <= 2 && mode_ak == scratch_hash_k && team_ak == 1 && !in_top_ak), "short rows over the global hash");
     using mem = scratch_gt<global_ak>;
     const std::uint32_t lane = lane_id();
     const std::uint32_t ef = args.ef, wanted = args.wanted;
@@ -1198,7 +1207,7 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
 #else
     auto tick = [](int) {};
 #endif
-    const std::uint64_t query_row = args.query_ids ? args.query_ids[q] : q;
+    const std::uint64_t query_row = !plain_ak && args.query_ids ? args.query_ids[q] : q;
     const query_norm_t a2 = stage_query<metric_ak, scalar_ak, lanes_ak>(
         ix, args.queries + query_row * args.query_stride, query_lds);
 
@@ -1228,14 +1237,14 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     std::uint32_t* seen = nullptr;
     std::uint32_t seen_mask = 0;
     if constexpr (seen_ak) {
-        if (args.seen_cells) {
+        if (plain_ak || args.seen_cells) {
             seen = reinterpret_cast<std::uint32_t*>(query_lds + args.seen_offset);
             seen_mask = args.seen_cells - 1;
             for (std::uint32_t i = lane; i < args.seen_cells; i += 64)
                 seen[i] = none_slot_k;
             wave_sync<false>();
         }
-        if (args.probe_mode == probe_plain_k) { // the claim bits (zero between probe rounds; zeroed once more per query: free)
+        if (!plain_ak && args.probe_mode == probe_plain_k) { // the claim bits (zero between probe rounds; zeroed once more per query: free)
             std::uint32_t* claim = reinterpret_cast<std::uint32_t*>(query_lds + args.claim_offset);
             for (std::uint32_t i = lane; i < args.claim_bits / 32; i += 64)
                 claim[i] = 0u;
@@ -1268,6 +1277,8 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     // index_dense.hpp:2071-2081: a member is a result candidate unless it is a tombstone or the caller's predicate
     // (evaluated on the host into one bit per slot) rejects it; it is traversed either way
     auto allowed = [&](std::uint32_t slot) -> bool {
+        if constexpr (plain_ak)
+            return true;
         if (!ix.has_tombstones && !args.allow_bits && !args.exclude_own)
             return true;
         bool ok = !(args.exclude_own && slot == (std::uint32_t)query_row); // index.hpp:4111, 4161: `updated_slot` never enters `top`
@@ -1300,7 +1311,7 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     wave_sync<global_ak>();
     measure(1);
     float closest_distance = uniform_f32(mem::load(cand_distances));
-    const std::uint32_t beam_level = args.beam_level; // 0 for search; the level being linked during construction
+    const std::uint32_t beam_level = plain_ak ? 0u : args.beam_level; // 0 for search; the level being linked during construction
     for (std::uint32_t level = ix.max_level; level > beam_level; --level) {
         bool changed;
         do {
@@ -1345,7 +1356,7 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     float radius = uniform_f32(mem::load(cand_distances));
     // index_gt::cluster (index.hpp:3089-3125) is the descent alone, down to `beam_level`, plus one more evaluation of the
     // winner's distance (3115) — the very evaluation the beam starts with: one result per query (`wanted` = 1)
-    if (args.descent_only) {
+    if (!plain_ak && args.descent_only) {
         if (lane == 0) {
             args.keys[q] = args.emit_slots ? (std::uint64_t)closest : ix.keys[closest];
             args.distances[q] = radius;
@@ -1367,19 +1378,21 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
         top.insert(radius, closest, ef, first_radius);
     }
 
-    const std::uint32_t cells = beam_level ? ix.m : ix.m0;
+    const std::uint32_t cells = plain_ak ? (ix.m0 < 64u ? ix.m0 : 64u) : beam_level ? ix.m : ix.m0;
     auto list_of = [&](std::uint32_t slot) -> const std::uint32_t* {
+        if constexpr (plain_ak)
+            return ix.nbr0 + (std::uint64_t)slot * ix.m0;
         return beam_level ? ix.upper + (std::uint64_t)(ix.upper_ref[slot] + (beam_level - 1)) * ix.m
                           : ix.nbr0 + (std::uint64_t)slot * ix.m0;
     };
     std::uint32_t ahead_slot = none_slot_k, ahead_cell = none_slot_k; // list tile requested ahead of its hop
     // rows stored next to the lists (`nbr0_rows`): one-chunk rows only, lists of one tile, level 0
     constexpr bool inline_ak = lanes_ak == 1 && !global_ak;
-    const bool inline_rows = inline_ak && ix.nbr0_rows != nullptr && !beam_level && cells <= 64 && ix.chunks == 1;
+    const bool inline_rows = plain_ak ? inline_ak : inline_ak && ix.nbr0_rows != nullptr && !beam_level && cells <= 64 && ix.chunks == 1;
     uint4 ahead_row = {0u, 0u, 0u, 0u};
     // rows of ≤ 128 bytes over a visited set in a global slab: gathered next to the probe instead of behind it (see the hop loop)
     constexpr bool early_ak = lanes_ak == 2 && mode_ak == scratch_hash_k && team_ak == 1;
-    const bool early_rows = early_ak && args.early_rows != 0 && !inline_rows && cells <= 64;
+    const bool early_rows = plain_ak ? early_ak : early_ak && args.early_rows != 0 && !inline_rows && cells <= 64;
     tick(0);
     // ---- a team over the in-`top` frontier with a wide `top` (≥ 8 cells per lane: expansions above 256, where a commit costs about
     // what measuring the hop's rows does) walks the beam as a PIPELINE (lists of ≤ 64 cells): the leader names the next member to
@@ -1637,7 +1650,7 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                 bool asks = present;
                 std::uint32_t seen_cell = 0;
                 if constexpr (seen_ak) {
-                    if (seen) { // a slot this query has probed before is in the set: no atomic for it
+                    if (plain_ak || seen) { // a slot this query has probed before is in the set: no atomic for it
                         seen_cell = ((neighbor * 0x9E3779B1u) >> 9) & seen_mask;
                         asks = present && seen[seen_cell] != neighbor;
                     }
@@ -1754,7 +1767,7 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                 }
                 fresh = present && old == none_slot_k;
                 if constexpr (seen_ak) {
-                    if (seen && asks)
+                    if ((plain_ak || seen) && asks)
                         seen[seen_cell] = neighbor; // probed (inserted or found): in the set from now on
                 }
             }
@@ -1919,7 +1932,7 @@ constexpr int kernel_waves(int variant, int epl, int frontier = 0, int lanes = 8
     return variant == variant_u4_w4_k ? (epl >= 8 ? 3 : 4) : variant == variant_u8_w3_k ? (epl >= 16 ? 2 : 3) : 2;
 }
 
-template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak, int frontier_ak>
+template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak, int frontier_ak, bool plain_ak = false>
 __global__ __launch_bounds__(64, kernel_waves(variant_ak, epl_ak, frontier_ak, lanes_ak)) void search_kernel(const snapshot_view_t ix,
                                                                                             const search_args_t args) {
     constexpr int unroll_ak = variant_unroll(variant_ak) + 100 * (variant_rows(variant_ak) - 1); // rows ride in the hundreds
@@ -1948,8 +1961,8 @@ __global__ __launch_bounds__(64, kernel_waves(variant_ak, epl_ak, frontier_ak, l
             if (ticket >= args.count)
                 break;
             const std::uint32_t q = args.todo ? args.todo[ticket] : ticket;
-            search_one<metric_ak, scalar_ak, lanes_ak, unroll_ak, mode_ak, epl_ak, frontier_ak>(ix, args, q, query_lds, heaps,
-                                                                                               visits);
+            search_one<metric_ak, scalar_ak, lanes_ak, unroll_ak, mode_ak, epl_ak, frontier_ak, 1, plain_ak>(ix, args, q, query_lds, heaps,
+                                                                                                             visits);
             wave_sync<false>();
         }
     }

@@ -8,6 +8,14 @@
 
 namespace usearch_amd {
 
+/// The instantiations that exist in the `plain_ak` cut as well: the short-row walks of the common pairs (expansion ≤ 128 over the
+/// global hash, the reference's heap) — what BASELINE's configs 4 and 5 run. `plain_build_exists` (engine.hpp) says the same to the engine.
+template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak, int frontier_ak>
+constexpr bool plain_build() {
+    return plain_build_exists((metric_kind_t)metric_ak, (scalar_kind_t)scalar_ak, lanes_ak, variant_ak == variant_u4_w4_k,
+                              mode_ak == scratch_hash_k, epl_ak, frontier_ak == frontier_heap_k);
+}
+
 template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak, int frontier_ak = frontier_heap_k>
 hipError_t launch_search_one(const launch_params_t& p, const snapshot_view_t& view, const search_args_t& args) {
     if (p.team) { // five waves per query: rows of ≥ 128 bytes, the 12-deep build of the common pairs, heaps in LDS
@@ -20,6 +28,15 @@ hipError_t launch_search_one(const launch_params_t& p, const snapshot_view_t& vi
                     return e;
             }
             hipLaunchKernelGGL(team_kernel, dim3(p.grid), dim3(64 * team_waves_k), p.lds_bytes, p.stream, view, args);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
+    if (p.plain) { // short rows, a plain `search` batch: the build without the features such a batch never uses (kernels.hpp `plain_ak`)
+        if constexpr (plain_build<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, epl_ak, frontier_ak>()) {
+            hipLaunchKernelGGL((search_kernel<metric_ak, scalar_ak, lanes_ak, variant_ak, mode_ak, epl_ak, frontier_ak, true>), dim3(p.grid),
+                               dim3(64), p.lds_bytes, p.stream, view, args);
             return hipGetLastError();
         } else {
             return hipErrorInvalidValue;
