@@ -1184,7 +1184,8 @@ def main() -> None:
                        "persistent_waves": stats.grid, "lds_bytes_per_wave": stats.lds_bytes,
                        "rows_inline_with_lists": inline_rows,
                        "visited_set_probe": {"mode": {0: "compare-and-swap", 1: "load, then compare-and-swap", 2: "loads and plain stores, no atomic"}.get(stats.probe_mode),
-                                             "seen_cells": stats.seen_cells, "claim_bits": stats.claim_bits} if stats.mode == 2 else None,
+                                             "seen_cells": stats.seen_cells, "claim_bits": stats.claim_bits,
+                                             "build_cut_for_plain_batches": bool(stats.plain)} if stats.mode == 2 else None,
                        "batch_tail_idle": float(np.mean(tails)) if args.wave_clock else None,
                        "host_buffer_api_qps_pcie_inclusive": host_api_qps,
                        "single_query_latency_us_host_api": single_query_us,
@@ -1196,10 +1197,10 @@ def main() -> None:
                          "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "search_kernel", "kernel_ms": kernel_s * 1e3,
                          # template arguments of the timed instantiation as rocprofv3 prints them: metric and scalar codes, lanes
-                         # per row, build, scratch mode, `top` cells per lane, frontier
+                         # per row, build, scratch mode, `top` cells per lane, frontier, the cut for plain batches (short rows)
                          "kernel_instantiation": (f"search_kernel<{ord({'tanimoto': 't', 'jaccard': 't'}.get(metric, {'cos': 'c', 'ip': 'i', 'l2sq': 'e', 'hamming': 'b', 'pearson': 'p', 'haversine': 'h', 'divergence': 'd', 'sorensen': 's'}.get(metric, '?')))}, "
                                                   f"{ {'b1': 1, 'bf16': 4, 'f64': 10, 'f32': 11, 'f16': 12, 'i8': 23}[args.dtype]}, {lanes_per_row}, "
-                                                  f"{stats.variant - 1}, {stats.mode - 1}, {stats.top_cells}, {stats.frontier - 1}>"),
+                                                  f"{stats.variant - 1}, {stats.mode - 1}, {stats.top_cells}, {stats.frontier - 1}, {'true' if stats.plain else 'false'}>"),
                          "algorithmic_bytes_per_launch": step_bytes,
                          "lines_touched_bytes_per_launch": touched_bytes,
                          "lines_touched_frac": touched_bytes / kernel_s / 1e9 / HBM_PEAK_GBPS if kernel_s > 0 else None,

@@ -72,6 +72,10 @@ def main() -> None:
                 and np.array_equal(base.counts, got.counts) and np.array_equal(base.visited_per_query, got.visited_per_query)
                 and np.array_equal(base.computed_per_query, got.computed_per_query))
         hops = float(got.visited_per_query.mean())
+        peaks = index.last_peaks(args.timed_queries)  # of the last timed launch: the frontier's peak size and the visited set's final size, per query
+        print(f"{n}x{dim} {dtype} ef {expansion}: frontier peak per query: median {int(np.median(peaks[:, 0]))}, 99.9 % {int(np.percentile(peaks[:, 0], 99.9))}, "
+              f"max {int(peaks[:, 0].max())}; visited set: median {int(np.median(peaks[:, 1]))}, max {int(peaks[:, 1].max())}; passes of the last launch {ran[1].passes}",
+              flush=True)
         for plain in (0, 1):
             stats = ran[plain]
             print(f"{n}x{dim} {dtype} {metric} ef {expansion}: plain build {'on' if plain else 'off'} (ran plain={stats.plain} / answers plain={answers[plain].stats.plain}, "

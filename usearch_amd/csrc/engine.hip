@@ -89,6 +89,10 @@ const char* upload_rows(std::uint8_t* device, std::uint32_t row_stride, const st
 }
 
 /// Jaccard over bit sets IS Tanimoto in the reference's dispatch (index_plugins.hpp:2003-2004): one kernel serves both.
+/// gfx950 hands LDS out in blocks of 320 dwords (160 KB = 128 of them). Round 6 measured it the hard way: a wave of 8 160 bytes "fits" 20
+/// times by a 1 024-byte count and runs as 18 (i8 × 96 at expansion 80 with 1 024 `seen` cells: 10.99 ms against 9.97 with 512).
+constexpr std::uint64_t lds_granule_k = 1280;
+
 static metric_kind_t kernel_metric(metric_kind_t metric) { return metric == metric_jaccard_k ? metric_tanimoto_k : metric; }
 
 bool kernel_available(metric_kind_t metric, scalar_kind_t scalar) {
@@ -749,8 +753,8 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
     }
     hash_cap = pow2_ceil(hash_cap);
     std::uint32_t next_cap = tuning.next_cap ? tuning.next_cap : (std::uint32_t)env_size("USEARCH_AMD_NEXT_CAP", 0);
-    if (!next_cap)
-        next_cap = std::max<std::uint32_t>(512, ef * 3 + 256);
+    if (!next_cap) // (peaks measured on 20M-vector slices, 100 000 queries: b1 × 128 at 64: median 158, maximum 317; i8 × 96 at 80: 220 / 360)
+        next_cap = std::max<std::uint32_t>(448, ef * 3 + 256);
     // never larger than the index could possibly need
     hash_cap = std::min<std::uint32_t>(hash_cap, pow2_ceil((std::uint32_t)std::min<std::uint64_t>(view_.size * 2 + 128, 1u << 30)));
     next_cap = (std::uint32_t)std::min<std::uint64_t>(next_cap, view_.size + 64);
@@ -807,7 +811,16 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
                       !tuning.waves_per_cu;
     if (team)
         variant = variant_u12_w2_k;
-    const std::uint32_t variant_waves_per_cu = 4u * (std::uint32_t)kernel_waves(variant, (int)entries_per_lane, frontier, (int)lanes_);
+    // whether this call can run the short-row build cut for plain batches (kernels.hpp `plain_ak`) as far as that is known here; the
+    // scratch mode, the `seen` cells and the early rows are settled per rung in run_ladder, which has the last word (`params.plain`)
+    call.plain_possible = !team && !view_.has_tombstones && view_.m0 <= 64 && view_.nbr0 &&
+                          !(extras && (extras->query_ids || extras->beam_level || extras->descent_only || extras->allow_bits || extras->exclude_own)) &&
+                          (lanes_ == 1 ? view_.nbr0_rows != nullptr && view_.chunks == 1 : lanes_ == 2) &&
+                          plain_build_exists(kernel_metric(metric_), scalar_, (int)lanes_, variant == variant_u4_w4_k, true, (int)entries_per_lane,
+                                             frontier == frontier_heap_k) &&
+                          !env_size("USEARCH_AMD_NO_PLAIN", 0);
+    const std::uint32_t variant_waves_per_cu =
+        4u * (std::uint32_t)kernel_waves(variant, (int)entries_per_lane, frontier, (int)lanes_, call.plain_possible);
     const std::uint32_t waves_cap = tuning.waves_per_cu ? tuning.waves_per_cu
                                                         : (std::uint32_t)env_size("USEARCH_AMD_WAVES_PER_CU", 32);
     call.waves_cap = std::min(waves_cap, variant_waves_per_cu);
@@ -820,7 +833,7 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
         return query_lds + l.total;
     };
     auto waves_for = [&](std::uint64_t lds_bytes) -> std::uint32_t {
-        const std::uint64_t granule = (lds_bytes + 1023) / 1024 * 1024; // LDS is allocated in coarse granules
+        const std::uint64_t granule = (lds_bytes + lds_granule_k - 1) / lds_granule_k * lds_granule_k; // LDS is allocated in coarse granules
         return (std::uint32_t)std::max<std::uint64_t>(
             1, std::min<std::uint64_t>(call.waves_cap, lds_budget / std::max<std::uint64_t>(granule, 1)));
     };
@@ -830,7 +843,7 @@ const char* snapshot_t::search_begin(search_call_t& call, const void* queries, s
     if (default_next_cap && next_cap && mode_request != 1 && mode_request != 3) {
         const std::uint32_t now = waves_for(lds_bytes_for(scratch_hash_k, next_cap, hash_cap));
         if (now < call.waves_cap) {
-            const std::uint64_t room = lds_budget / (now + 1) / 1024 * 1024;
+            const std::uint64_t room = lds_budget / (now + 1) / lds_granule_k * lds_granule_k;
             const std::uint64_t fixed = lds_bytes_for(scratch_hash_k, 0, hash_cap);
             if (room > fixed) {
                 const std::uint32_t trimmed = (std::uint32_t)((room - fixed) / 8 / 2 * 2);
@@ -941,7 +954,7 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         return call.query_lds + l.total;
     };
     auto waves_for = [&](std::uint64_t lds_bytes) -> std::uint32_t {
-        const std::uint64_t granule = (lds_bytes + 1023) / 1024 * 1024;
+        const std::uint64_t granule = (lds_bytes + lds_granule_k - 1) / lds_granule_k * lds_granule_k;
         return (std::uint32_t)std::max<std::uint64_t>(
             1, std::min<std::uint64_t>(call.waves_cap, lds_budget / std::max<std::uint64_t>(granule, 1)));
     };
@@ -1040,12 +1053,9 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         }
         // a plain `search` batch over short rows runs the build without the features it never uses (kernels.hpp `plain_ak`): the
         // engine vouches here for everything that build takes for granted; USEARCH_AMD_NO_PLAIN=1 keeps the general build
-        params.plain = plain_build_exists(kernel_metric(metric_), scalar_, (int)lanes_, params.variant == variant_u4_w4_k,
-                                          call.mode == scratch_hash_k, (int)call.entries_per_lane, params.frontier == frontier_heap_k) &&
-                               !params.team && !view_.has_tombstones && view_.m0 <= 64 && view_.nbr0 && !args.query_ids && !args.beam_level &&
-                               !args.descent_only && !args.allow_bits && !args.exclude_own && args.seen_cells &&
-                               args.probe_mode == probe_swap_k && (lanes_ == 1 ? view_.nbr0_rows != nullptr && view_.chunks == 1 : args.early_rows != 0) &&
-                               !env_size("USEARCH_AMD_NO_PLAIN", 0)
+        params.plain = call.plain_possible && call.mode == scratch_hash_k && !params.team && !args.query_ids && !args.beam_level &&
+                               !args.descent_only && !args.allow_bits && !args.exclude_own && args.seen_cells && args.probe_mode == probe_swap_k &&
+                               (lanes_ == 1 || args.early_rows != 0)
                            ? 1u
                            : 0u;
         call.stats.plain = params.plain;

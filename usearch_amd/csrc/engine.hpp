@@ -192,6 +192,7 @@ class snapshot_t {
         std::uint32_t ef = 0, hash_cap = 0, next_cap = 0, query_lds = 0, entries_per_lane = 0, waves_cap = 0;
         int mode = 0;
         bool timed = false, want_phases = false, want_clock = false, done = false, reran = false;
+        bool plain_possible = false; ///< short rows: nothing known at search_begin rules the build cut for plain batches out (`plain_ak`)
         bool keep_workspace = false; ///< search_finish leaves the workspace with the caller (who gives it back)
         float total_ms = 0.f;
         std::uint32_t passes = 0;

@@ -21,6 +21,7 @@
  *  No MFMA on purpose: every query gathers different rows (no operand reuse), ~3 FLOP per fetched byte.
  */
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include "common.hpp"
@@ -189,10 +190,12 @@ UA_DEVICE void heap_push_finish(cand_t* heap, std::uint32_t& size, const push_ti
     const std::uint32_t lane = lane_id();
     const std::uint64_t overtaken = ballot(ticket.has && cand_distance(ticket.ancestor) < key);
     const std::uint32_t rises = popcount64(overtaken);
-    if (ticket.has && lane <= rises)
-        mem::store(heap + ((ticket.leaf1 >> (lane - 1)) - 1), ticket.ancestor);
-    if (lane == 0)
-        mem::store(heap + ((ticket.leaf1 >> rises) - 1), make_cand(key, slot));
+    // ONE store: lanes 1 … rises move their ancestor one level down, lane 0 puts the key where the last of them was (`rises` never
+    // exceeds the number of ancestors, so every lane up to it holds one; the cells are distinct: levels 0 … rises of the path)
+    if (lane <= rises) {
+        const std::uint32_t up = lane == 0 ? rises : lane - 1;
+        mem::store(heap + ((ticket.leaf1 >> up) - 1), lane == 0 ? make_cand(key, slot) : ticket.ancestor);
+    }
     size = ticket.leaf1;
     wave_sync<global_ak>();
 }
@@ -242,6 +245,24 @@ template <bool global_ak> UA_DEVICE cand_t heap_pop_serial(cand_t* heap, std::ui
     return root;
 }
 
+/// The walk of one round of `heap_pop` through the five levels below the hole, on the two ballots re-indexed by the node's number
+/// `m` inside the block (the hole is 1, its children 2 and 3, … — lane = m − 2): while the node says "goes on", step to the child it
+/// names and mark it. Five scalar instructions per level — bit test, branch, bit test, add-with-carry (m ← 2m + turn), bit set —
+/// where the compiler's rendering of the same loop took thirteen; the pop runs once per hop and goes two rounds deep, on walks whose
+/// SIMDs are half issue-bound (short rows, profiles/r06_short_rows/README.md §3).
+UA_DEVICE void heap_pop_walk(std::uint64_t on_by_node, std::uint64_t right_by_node, std::uint32_t& m, std::uint64_t& path_by_node,
+                             std::uint32_t& settled) {
+#define USEARCH_AMD_POP_STEP                                                                                                                  \
+    "s_bitcmp1_b64 %[on], %[m]\n\ts_cbranch_scc0 9f\n\ts_bitcmp1_b64 %[right], %[m]\n\ts_addc_u32 %[m], %[m], %[m]\n\ts_bitset1_b64 %[path], %[m]\n\t"
+    asm volatile("s_mov_b32 %[settled], 1\n\t" USEARCH_AMD_POP_STEP USEARCH_AMD_POP_STEP USEARCH_AMD_POP_STEP USEARCH_AMD_POP_STEP USEARCH_AMD_POP_STEP
+                 "s_mov_b32 %[settled], 0\n"
+                 "9:\n\t"
+                 : [m] "+s"(m), [path] "+s"(path_by_node), [settled] "=&s"(settled)
+                 : [on] "s"(on_by_node), [right] "s"(right_by_node)
+                 : "scc");
+#undef USEARCH_AMD_POP_STEP
+}
+
 /**
  *  The same pop — the same decisions, the same final layout — five levels per scratch round trip, with the decisions taken
  *  by all lanes at once instead of one after the other. The 62 descendants of the hole within five levels are fetched in one
@@ -254,6 +275,8 @@ template <bool global_ak> UA_DEVICE cand_t heap_pop_serial(cand_t* heap, std::ui
  */
 template <bool global_ak> UA_DEVICE cand_t heap_pop(cand_t* heap, std::uint32_t& size) {
     using mem = scratch_gt<global_ak>;
+    // a frontier in LDS has far fewer than 2^27 cells: 32-bit positions; the all-global fallback holds up to one cell per member
+    using index_t = std::conditional_t<global_ak, std::uint64_t, std::uint32_t>;
     const std::uint32_t lane = lane_id();
     const cand_t root = mem::load(heap);
     const std::uint32_t n = size - 1;
@@ -263,9 +286,9 @@ template <bool global_ak> UA_DEVICE cand_t heap_pop(cand_t* heap, std::uint32_t&
     const std::uint32_t my_level = stands_for_hole ? 0u : 31u - (std::uint32_t)__clz((int)(lane + 2)); // lane 63: 6, unused
     const std::uint32_t my_offset = stands_for_hole ? 0u : lane + 2 - (1u << my_level);
     const std::uint32_t left_lane = (2u << my_level) - 2 + 2 * my_offset; // lane of my node's left child (levels 0 … 4)
-    std::uint32_t i = 0;
+    index_t i = 0;
     while (2 * i + 1 < n) {
-        const std::uint64_t my_index = (((std::uint64_t)i + 1) << my_level) - 1 + my_offset;
+        const index_t my_index = ((i + 1) << my_level) - 1 + my_offset;
         cand_t mine = 0;
         if (lane < 62 && my_index < n)
             mine = mem::load(heap + my_index);
@@ -283,24 +306,17 @@ template <bool global_ak> UA_DEVICE cand_t heap_pop(cand_t* heap, std::uint32_t&
             goes_on = goes_right;
         }
         const std::uint64_t on_mask = ballot(goes_on), right_mask = ballot(goes_right);
-        std::uint64_t path = 0; // lanes whose node moves up into its parent
-        std::uint32_t at = 62, level = 0, offset = 0;
-        bool settled = false;
-#pragma unroll
-        for (int step = 0; step < 5; ++step) {
-            if (!((on_mask >> at) & 1ull)) {
-                settled = true;
-                break;
-            }
-            const std::uint32_t turn = (std::uint32_t)((right_mask >> at) & 1ull);
-            at = (2u << level) - 2 + 2 * offset + turn;
-            path |= 1ull << at;
-            offset = 2 * offset + turn;
-            level += 1;
-            i = 2 * i + 1 + turn;
-        }
-        if ((path >> lane) & 1ull)
+        // the ballots by node number: node m ≥ 2 answered in lane m − 2, the hole (node 1) in lane 62
+        const std::uint64_t on_by_node = (on_mask << 2) | ((on_mask >> 61) & 2ull);
+        const std::uint64_t right_by_node = (right_mask << 2) | ((right_mask >> 61) & 2ull);
+        std::uint64_t path_by_node = 0; // nodes that move up into their parent
+        std::uint32_t m = 1, settled;
+        heap_pop_walk(on_by_node, right_by_node, m, path_by_node, settled);
+        if ((path_by_node >> (lane + 2)) & 1ull)
             mem::store(heap + ((my_index - 1) >> 1), mine);
+        // the hole went `steps` levels down to the node numbered m = 2^steps + its offset among that level's nodes
+        const std::uint32_t steps = 31u - (std::uint32_t)__clz((int)m);
+        i = ((i + 1) << steps) + (m - (1u << steps)) - 1;
         if (settled)
             break;
     }
@@ -428,22 +444,34 @@ template <int epl_ak, bool global_ak, bool flags_ak = false> struct top_gt {
             }
             // wave-uniform bookkeeping; none of it waits for the vector work above
             const bool full = uniform_u32(size) == uniform_u32(limit);
+            // (an expansion that is a multiple of the cells per lane — 64, 128, 256, 608 = 38 · 16 … — ends on a lane boundary: the cell
+            // to drop is the first of its lane, the radius sits in the last of the lane below; the other expansions pick the cell by
+            // number, which with 16 cells per lane compiles to a tree of branches and register moves, per insert)
             if (full && limit < 64u * epl_ak) { // what left cell `limit - 1` of a full buffer sits in cell `limit`: drop it
                 const std::uint32_t drop_lane = limit / epl_ak, drop_cell = limit % epl_ak;
+                if (drop_cell == 0) {
+                    d[0] = lane == drop_lane ? __builtin_inff() : d[0];
+                    s[0] = lane == drop_lane ? none_slot_k : s[0];
+                } else {
 #pragma unroll
-                for (int i = 0; i < epl_ak; ++i)
-                    if (drop_cell == (std::uint32_t)i) {
-                        d[i] = lane == drop_lane ? __builtin_inff() : d[i];
-                        s[i] = lane == drop_lane ? none_slot_k : s[i];
-                    }
+                    for (int i = 1; i < epl_ak; ++i)
+                        if (drop_cell == (std::uint32_t)i) {
+                            d[i] = lane == drop_lane ? __builtin_inff() : d[i];
+                            s[i] = lane == drop_lane ? none_slot_k : s[i];
+                        }
+                }
             }
             size += full ? 0u : 1u;
             if (size == limit) {
                 const std::uint32_t last_lane = (limit - 1) / epl_ak, last_cell = (limit - 1) % epl_ak;
+                if (last_cell == (std::uint32_t)(epl_ak - 1)) {
+                    radius = read_lane_f32(d[epl_ak - 1], last_lane);
+                } else {
 #pragma unroll
-                for (int i = 0; i < epl_ak; ++i)
-                    if (last_cell == (std::uint32_t)i)
-                        radius = read_lane_f32(d[i], last_lane);
+                    for (int i = 0; i < epl_ak - 1; ++i)
+                        if (last_cell == (std::uint32_t)i)
+                            radius = read_lane_f32(d[i], last_lane);
+                }
             }
             return true;
         }
@@ -1916,13 +1944,18 @@ enum kernel_variant_t : int {
 #ifndef USEARCH_AMD_SHORT_ROW_WAVES
 #define USEARCH_AMD_SHORT_ROW_WAVES 5
 #endif
+#ifndef USEARCH_AMD_PLAIN_TINY_ROW_WAVES // the cut for plain batches (`plain_ak`) needs fewer registers: its own residency
+#define USEARCH_AMD_PLAIN_TINY_ROW_WAVES USEARCH_AMD_TINY_ROW_WAVES
+#endif
 constexpr int variant_unroll(int v) { return v == variant_u4_w4_k ? 4 : v == variant_u8_w3_k ? 8 : 12; }
 constexpr int variant_rows(int v) { return v == variant_u12x2_w2_k ? 2 : 1; }
 /// Waves per SIMD the register budget of an instantiation is cut for (512 VGPRs per SIMD lane: 128 → 4, 168 → 3, 256 → 2);
 /// from the allocations the compiler reports for the widest rows (cos, G = 8) with `top` in `epl` register rows.
-constexpr int kernel_waves(int variant, int epl, int frontier = 0, int lanes = 8) {
+constexpr int kernel_waves(int variant, int epl, int frontier = 0, int lanes = 8, bool plain = false) {
     if (variant == variant_u12x2_w2_k)
         return 2;
+    if (plain && variant == variant_u4_w4_k && epl == 1 && lanes == 1)
+        return USEARCH_AMD_PLAIN_TINY_ROW_WAVES;
     if (variant == variant_u4_w4_k && epl == 1 && lanes <= 2)
         return lanes == 1 ? USEARCH_AMD_TINY_ROW_WAVES : USEARCH_AMD_SHORT_ROW_WAVES;
     if (variant == variant_u4_w4_k && epl == 2 && lanes <= 2) // expansion 65 … 128 on short rows (C4 needs 80)
@@ -1933,7 +1966,7 @@ constexpr int kernel_waves(int variant, int epl, int frontier = 0, int lanes = 8
 }
 
 template <int metric_ak, int scalar_ak, int lanes_ak, int variant_ak, int mode_ak, int epl_ak, int frontier_ak, bool plain_ak = false>
-__global__ __launch_bounds__(64, kernel_waves(variant_ak, epl_ak, frontier_ak, lanes_ak)) void search_kernel(const snapshot_view_t ix,
+__global__ __launch_bounds__(64, kernel_waves(variant_ak, epl_ak, frontier_ak, lanes_ak, plain_ak)) void search_kernel(const snapshot_view_t ix,
                                                                                             const search_args_t args) {
     constexpr int unroll_ak = variant_unroll(variant_ak) + 100 * (variant_rows(variant_ak) - 1); // rows ride in the hundreds
     extern __shared__ __attribute__((aligned(16))) std::uint8_t lds[];
