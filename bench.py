@@ -1185,7 +1185,7 @@ def main() -> None:
                        "rows_inline_with_lists": inline_rows,
                        "visited_set_probe": {"mode": {0: "compare-and-swap", 1: "load, then compare-and-swap", 2: "loads and plain stores, no atomic"}.get(stats.probe_mode),
                                              "seen_cells": stats.seen_cells, "claim_bits": stats.claim_bits,
-                                             "build_cut_for_plain_batches": bool(stats.plain)} if stats.mode == 2 else None,
+                                             "build_cut_for_plain_batches": bool(stats.plain), "aside_cells": stats.aside_cells} if stats.mode == 2 else None,
                        "batch_tail_idle": float(np.mean(tails)) if args.wave_clock else None,
                        "host_buffer_api_qps_pcie_inclusive": host_api_qps,
                        "single_query_latency_us_host_api": single_query_us,

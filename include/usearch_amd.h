@@ -86,6 +86,8 @@ typedef struct usearch_amd_stats_t {
     uint32_t early_rows;     /**< rows of ≤ 128 bytes: 1 = a hop's rows were gathered next to the probe of the visited set, not behind it */
     uint32_t plain;          /**< rows of ≤ 128 bytes: 1 = the launch ran the kernel build cut for plain batches (level 0, no predicate, no
                                   tombstones, lists of ≤ 64 cells); USEARCH_AMD_NO_PLAIN=1 keeps the general build. Same results */
+    uint32_t aside_cells;    /**< … and its LDS cells for the members whose home cell in the slab was taken (the slab is then probed at the
+                                  home cell only: one round trip per hop) */
 } usearch_amd_stats_t;
 
 /** Number of visible HIP devices; 0 (and an error) when the runtime finds none. */

@@ -79,7 +79,7 @@ def main() -> None:
         for plain in (0, 1):
             stats = ran[plain]
             print(f"{n}x{dim} {dtype} {metric} ef {expansion}: plain build {'on' if plain else 'off'} (ran plain={stats.plain} / answers plain={answers[plain].stats.plain}, "
-                  f"scratch mode {stats.mode}, {stats.grid} waves, {stats.lds_bytes} B LDS/wave, seen {stats.seen_cells}, early rows {stats.early_rows}): "
+                  f"scratch mode {stats.mode}, {stats.grid} waves, {stats.lds_bytes} B LDS/wave, seen {stats.seen_cells}, aside {stats.aside_cells}, early rows {stats.early_rows}): "
                   f"{' / '.join(f'{ms:.3f}' for ms in best[plain])} ms for {args.timed_queries} queries, best {min(best[plain]):.3f} ms = "
                   f"{args.timed_queries / min(best[plain]) / 1e3:.2f} M QPS", flush=True)
         print(f"{n}x{dim} {dtype} ef {expansion}: plain against general {min(best[0]) / min(best[1]):.4f} x; identical on {args.queries} queries "

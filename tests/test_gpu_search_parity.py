@@ -487,11 +487,13 @@ def test_graph_only_image_with_the_callers_vectors(reference):
 # (metric, dtype, ndim, n, connectivity, k, expansion, queries, forced tuning, the plain build exists)
 PLAIN_CONFIGS = [
     ("hamming", "b1", 128, 5000, 16, 10, 64, 300, {}, True),      # config 5's kernel: rows inline with the lists, one `top` cell per lane
-    ("hamming", "b1", 128, 5000, 16, 10, 100, 200, {}, True),     # two `top` cells per lane
+    ("hamming", "b1", 128, 5000, 16, 10, 72, 200, {}, True),      # two `top` cells per lane
+    ("hamming", "b1", 128, 5000, 16, 10, 100, 200, {}, True),
     ("hamming", "b1", 96, 3000, 5, 7, 32, 200, {}, True),         # lists of 10 cells
     ("l2sq", "i8", 96, 4000, 16, 10, 64, 200, {}, True),          # config 4's rows (G = 2): gathered next to the probe
     ("l2sq", "i8", 96, 4000, 16, 10, 80, 200, {}, True),          # config 4's kernel
-    ("cos", "i8", 96, 1500, 16, 10, 128, 80, {}, True),
+    ("cos", "i8", 96, 1500, 16, 10, 112, 80, {}, True),           # two `top` cells, the widest frontier that leaves LDS for `aside`
+    ("cos", "i8", 96, 1500, 16, 10, 128, 80, {}, False),          # … and one that does not: 512 cells more would cost a resident wave
     ("ip", "i8", 16, 1200, 16, 10, 64, 100, {}, True),            # 16-byte rows of another pair inline
     ("l2sq", "f16", 48, 1500, 16, 10, 64, 100, {"frontier": 1}, True),   # float pairs only when the heap is asked for
     ("cos", "f32", 24, 1500, 16, 10, 64, 100, {"frontier": 1}, True),
@@ -518,6 +520,8 @@ def test_plain_build_of_the_short_row_walk(reference, monkeypatch, metric, dtype
     first = check_against_oracle(index, image, queries, k, dtype, expansion, tuning=Tuning(mode=2, **forced))
     assert first.stats.mode == 2 and first.stats.passes == 1
     assert first.stats.plain == (1 if exists else 0)
+    # gathered rows (G = 2): the cut probes the slab at the home cell only and sets collided members aside in LDS
+    assert (first.stats.aside_cells > 0) == (bool(exists) and index.lanes_per_row == 2)
     monkeypatch.setenv("USEARCH_AMD_NO_PLAIN", "1")
     general = check_against_oracle(index, image, queries, k, dtype, expansion, tuning=Tuning(mode=2, **forced))
     assert general.stats.plain == 0 and general.stats.mode == 2
@@ -532,6 +536,28 @@ def test_plain_build_of_the_short_row_walk(reference, monkeypatch, metric, dtype
         assert np.array_equal(first.keys, rkeys) and util.same_float_bits(first.distances, rdists)
         assert np.array_equal(first.counts, rcounts)
         assert np.array_equal(first.visited_per_query, rvisited) and np.array_equal(first.computed_per_query, rcomputed)
+
+
+def test_plain_build_outgrows_its_room(reference, monkeypatch):
+    """Gathered rows (G = 2): the plain build probes the slab at a member's home cell only and sets what collides aside in LDS. A
+    table far too small for the walk (forced) fills up: the query is abandoned and run again by the retry ladder with more room —
+    same results, bit for bit, as the first try of a well-sized launch."""
+    from usearch_amd import Index, Tuning
+    for expansion in (64, 80):  # one and two `top` cells per lane
+        image, vectors, _ = util.build_image(6000, 96, "l2sq", "i8", seed=35)
+        queries = util.make_vectors(200, 96, "i8", seed=36)
+        index = Index.restore(image)
+        monkeypatch.delenv("USEARCH_AMD_ASIDE_CELLS", raising=False)
+        base = check_against_oracle(index, image, queries, 10, "i8", expansion, tuning=Tuning(mode=2))
+        assert base.stats.plain == 1 and base.stats.aside_cells == 512 and base.stats.passes == 1
+        monkeypatch.setenv("USEARCH_AMD_PLAIN_WHATEVER_THE_ROOM", "1")
+        monkeypatch.setenv("USEARCH_AMD_ASIDE_CELLS", "64")
+        tight = check_against_oracle(index, image, queries, 10, "i8", expansion, tuning=Tuning(mode=2))
+        assert tight.stats.passes >= 2, "64 cells (48 usable) were expected to overflow with the collisions of these walks"
+        assert np.array_equal(base.keys, tight.keys) and util.same_float_bits(base.distances, tight.distances)
+        assert np.array_equal(base.visited_per_query, tight.visited_per_query)
+        assert np.array_equal(base.computed_per_query, tight.computed_per_query)
+        monkeypatch.delenv("USEARCH_AMD_PLAIN_WHATEVER_THE_ROOM")
 
 
 def test_plain_build_steps_aside(reference):

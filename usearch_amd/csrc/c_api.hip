@@ -114,6 +114,7 @@ void stats_to_c(const search_stats_t& s, usearch_amd_stats_t* out) {
     out->claim_bits = s.claim_bits;
     out->early_rows = s.early_rows;
     out->plain = s.plain;
+    out->aside_cells = s.aside_cells;
 }
 
 void fail(usearch_amd_error_t* error, const char* message) {

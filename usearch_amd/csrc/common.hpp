@@ -158,6 +158,8 @@ struct search_args_t {
                                     ///< only to claim, or no atomic at all (loads + plain stores, claims settled in LDS)
     std::uint32_t claim_offset;     ///< `probe_plain_k`: where in the wave's LDS the claim bits sit, and how many (a power of two,
     std::uint32_t claim_bits;       ///< ≤ hash_cap; one bit per cell when equal, else cell & (bits − 1))
+    std::uint32_t aside_offset;     ///< the cut for plain batches (`plain_ak`): where in the wave's LDS the members sit whose home cell in the
+    std::uint32_t aside_cells;      ///< slab was taken, and how many cells (a power of two) — the slab is probed at the home cell only
 };
 
 enum : std::uint32_t { status_done_k = 0, status_overflow_k = 1 };

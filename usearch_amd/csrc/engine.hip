@@ -1000,6 +1000,7 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
         // short rows over a global visited set: `seen` cells in LDS in front of it (kernels.hpp `search_one`) — as many as cost no
         // resident wave (the walk lives on its residency), at most 2 048; USEARCH_AMD_SEEN_CELLS forces a number (0 = none)
         args.seen_offset = 0, args.seen_cells = 0;
+        args.aside_offset = 0, args.aside_cells = 0;
         args.probe_mode = probe_swap_k, args.claim_offset = 0, args.claim_bits = 0;
         // rows of ≤ 128 bytes gathered next to the probe of the visited set instead of behind it (kernels.hpp, the hop loop)
         args.early_rows = call.mode == scratch_hash_k && !params.team && lanes_ == 2 && env_size("USEARCH_AMD_EARLY_ROWS", default_early_rows_k) ? 1u : 0u;
@@ -1032,6 +1033,34 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
             } else if (probe_mode == probe_load_first_k) {
                 args.probe_mode = probe_load_first_k;
             }
+            // a plain `search` batch runs the build without the features it never uses (kernels.hpp `plain_ak`); the engine vouches here
+            // for everything that build takes for granted (USEARCH_AMD_NO_PLAIN=1 keeps the general build). That build never probes the
+            // slab past a member's home cell and sets what collides aside in LDS: about visits² / (2 · cells of the slab) members,
+            // visits ≈ 20 · expansion + 800 on the measured shapes (20M × 128 b1 at 64: median 1 521, maximum 2 225 of 100 000 queries;
+            // 20M × 96 i8 at 80: 1 742 / 2 281) — 512 cells at three quarters' load must take them, and must cost no resident wave;
+            // a query that outgrows them all the same is run again by the retry ladder
+            args.aside_offset = 0, args.aside_cells = 0;
+            const bool plain_wanted = call.plain_possible && !args.query_ids && !args.beam_level && !args.descent_only && !args.allow_bits &&
+                                      !args.exclude_own && args.probe_mode == probe_swap_k && (lanes_ == 1 || args.early_rows != 0);
+#ifdef USEARCH_AMD_EXPERIMENT_NO_ASIDE
+            const bool aside_wanted = false;
+#else
+            const bool aside_wanted = plain_wanted && lanes_ == 2; // (rows that travel with the lists gain nothing from it: kernels.hpp)
+#endif
+            if (aside_wanted) {
+                std::uint32_t aside_cells = 512;
+                if (const std::size_t forced_cells = env_size("USEARCH_AMD_ASIDE_CELLS", 0)) // tests: a table that is sure to fill up
+                    for (aside_cells = 64; aside_cells * 2 <= forced_cells && aside_cells < 2048; aside_cells *= 2) {}
+                const std::uint64_t expected_visits = std::min<std::uint64_t>((std::uint64_t)call.ef * 20 + 800, view_.size);
+                const bool room = expected_visits * expected_visits / (2ull * call.hash_cap) <= aside_cells * 3ull / 4 ||
+                                  env_size("USEARCH_AMD_PLAIN_WHATEVER_THE_ROOM", 0); // tests: a query that outgrows `aside` goes up the retry ladder
+                const std::uint64_t with_aside = (wave_lds_bytes + 15) / 16 * 16 + aside_cells * 4ull;
+                if (room && waves_for(with_aside) >= waves_for(wave_lds_bytes) && with_aside <= lds_budget) {
+                    args.aside_offset = (std::uint32_t)((wave_lds_bytes + 15) / 16 * 16);
+                    args.aside_cells = aside_cells;
+                    wave_lds_bytes = with_aside;
+                }
+            }
             const std::size_t forced = env_size("USEARCH_AMD_SEEN_CELLS", (std::size_t)-1);
             std::uint32_t cells = 0;
             if (forced != (std::size_t)-1) {
@@ -1051,14 +1080,18 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
             call.stats.seen_cells = args.seen_cells;
             call.stats.claim_bits = args.claim_bits;
         }
-        // a plain `search` batch over short rows runs the build without the features it never uses (kernels.hpp `plain_ak`): the
-        // engine vouches here for everything that build takes for granted; USEARCH_AMD_NO_PLAIN=1 keeps the general build
-        params.plain = call.plain_possible && call.mode == scratch_hash_k && !params.team && !args.query_ids && !args.beam_level &&
-                               !args.descent_only && !args.allow_bits && !args.exclude_own && args.seen_cells && args.probe_mode == probe_swap_k &&
-                               (lanes_ == 1 || args.early_rows != 0)
-                           ? 1u
-                           : 0u;
+        // decided with the LDS areas above (short rows over the global hash only): what the instantiation takes for granted must be there
+        params.plain = 0;
+        if (call.mode == scratch_hash_k && !params.team && lanes_ <= 2 && call.plain_possible && !args.query_ids && !args.beam_level &&
+            !args.descent_only && !args.allow_bits && !args.exclude_own && args.probe_mode == probe_swap_k && (lanes_ == 1 || args.early_rows != 0)) {
+#ifdef USEARCH_AMD_EXPERIMENT_NO_ASIDE
+            params.plain = args.seen_cells ? 1u : 0u;
+#else
+            params.plain = (lanes_ == 2 ? args.aside_cells : args.seen_cells) ? 1u : 0u;
+#endif
+        }
         call.stats.plain = params.plain;
+        call.stats.aside_cells = args.aside_cells;
         const std::uint64_t lds_bytes = params.team ? (wave_lds_bytes + 15) / 16 * 16 + team_bytes : wave_lds_bytes;
         args.team_offset = params.team ? (std::uint32_t)((wave_lds_bytes + 15) / 16 * 16) : 0u;
         const std::uint32_t grid = params.team ? pending

@@ -54,6 +54,7 @@ struct search_stats_t {
     std::uint32_t claim_bits = 0;        ///< … its claim bits in LDS (`probe_plain_k`)
     std::uint32_t early_rows = 0;        ///< rows of ≤ 128 bytes: 1 = gathered next to the probe of the visited set, not behind it
     std::uint32_t plain = 0;             ///< short rows: 1 = the last launch ran the build cut for plain batches (kernels.hpp `plain_ak`)
+    std::uint32_t aside_cells = 0;       ///< … and its LDS cells for the members whose home cell in the slab was taken
 };
 
 /// What index construction asks of the search on top of a plain query batch (see search_args_t).

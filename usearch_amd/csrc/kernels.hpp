@@ -67,8 +67,15 @@ UA_DEVICE float read_lane_f32(float v, std::uint32_t lane) {
 UA_DEVICE std::uint64_t ballot(bool p) { return __ballot(p); }
 UA_DEVICE std::uint32_t popcount64(std::uint64_t m) { return (std::uint32_t)__popcll(m); }
 UA_DEVICE std::uint32_t rank_below(std::uint64_t m, std::uint32_t lane) {
-    return popcount64(m & ((1ull << lane) - 1ull)); // lane < 64
+    // `v_mbcnt_lo` / `v_mbcnt_hi` count a mask's bits below the executing lane: two instructions and no per-lane constant — the
+    // shift-and-mask spelling kept (1 << lane) − 1 alive in two registers of every kernel for its whole life (round 6: the short-row
+    // cuts reloaded such constants from scratch inside the hop loop, each reload behind a wait for every load in flight)
+    (void)lane;
+    return __builtin_amdgcn_mbcnt_hi((std::uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((std::uint32_t)m, 0u));
 }
+/// Bit `lane` of a wave-uniform mask as this lane's predicate: the mask IS the predicate register, no instruction and no per-lane
+/// constant (the spelling (mask >> lane) & 1 compiles to an AND with a precomputed 1 << lane held in two registers).
+UA_DEVICE bool lane_bit(std::uint64_t uniform_mask) { return __builtin_amdgcn_inverse_ballot_w64(uniform_mask); }
 
 /// Lane `i` receives the value of lane `i ^ offset`. Inside a quad (offsets 1 and 2) that is one DPP `quad_perm` move on the
 /// vector ALU; wider exchanges go through the LDS crossbar (`ds_bpermute`). Same value either way: summation order untouched.
@@ -312,7 +319,7 @@ template <bool global_ak> UA_DEVICE cand_t heap_pop(cand_t* heap, std::uint32_t&
         std::uint64_t path_by_node = 0; // nodes that move up into their parent
         std::uint32_t m = 1, settled;
         heap_pop_walk(on_by_node, right_by_node, m, path_by_node, settled);
-        if ((path_by_node >> (lane + 2)) & 1ull)
+        if (lane_bit(path_by_node >> 2)) // node m answers in lane m − 2
             mem::store(heap + ((my_index - 1) >> 1), mine);
         // the hole went `steps` levels down to the node numbered m = 2^steps + its offset among that level's nodes
         const std::uint32_t steps = 31u - (std::uint32_t)__clz((int)m);
@@ -1261,11 +1268,36 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
     //      neighbour shared with a member expanded a few hops ago — and every slot a probe has asked about is remembered here,
     //      direct-mapped: a lane whose slot is in its cell KNOWS the answer (visited) and skips the atomic; any other lane probes
     //      the slab as before, which stays the authority. Same answers, fewer atomics.
+    //
+    // ---- `aside` (the cut for plain batches over gathered rows, `plain_ak` with G = 2): a second table in LDS (`args.aside_offset`,
+    //      `aside_cells`) holds the members whose HOME cell in the slab belongs to somebody else. The slab is then never probed past the home cell — ONE round
+    //      trip to the memory side per hop instead of 1.8 (at a tenth of the cells taken, some lane of twenty meets a taken cell on
+    //      nine hops in ten, and the whole wave waits for its second trip) — and what collides is settled in LDS, a compare-and-swap
+    //      with linear probing at LDS latency. A member is in the set iff it sits in its home cell or in `aside`: a home cell never
+    //      empties, so a member that found it taken finds it taken ever after. Exact; the room is checked before anything is set
+    //      aside (a query that outgrows it is run again by the retry ladder with four times the slab: a quarter of the collisions).
     constexpr bool seen_ak = lanes_ak <= 2 && mode_ak == scratch_hash_k && team_ak == 1;
+    // Measured on 20M-vector slices (profiles/r06_short_rows/README.md §4): i8 × 96 at expansion 80 +9.4 % over the general build
+    // (the cut with the `seen` cells alone: +3 %), at 64 +8.4 % (+4.9 %); b1 × 128, whose rows travel with the lists and whose hop has
+    // nothing to put in the shadow of a second probe round anyway, −1 … −3 %: that cut keeps the `seen` cells alone.
+#ifdef USEARCH_AMD_EXPERIMENT_NO_ASIDE // scripts/ A/B runs: the cut for plain batches with the `seen` cells alone
+    constexpr bool aside_ak = false;
+#else
+    constexpr bool aside_ak = plain_ak && lanes_ak == 2;
+#endif
     std::uint32_t* seen = nullptr;
     std::uint32_t seen_mask = 0;
+    std::uint32_t* aside = nullptr;
+    std::uint32_t aside_mask = 0, aside_count = 0;
+    if constexpr (aside_ak) {
+        aside = reinterpret_cast<std::uint32_t*>(query_lds + args.aside_offset);
+        aside_mask = args.aside_cells - 1;
+        for (std::uint32_t i = lane; i < args.aside_cells; i += 64)
+            aside[i] = none_slot_k;
+        wave_sync<false>();
+    }
     if constexpr (seen_ak) {
-        if (plain_ak || args.seen_cells) {
+        if (args.seen_cells) {
             seen = reinterpret_cast<std::uint32_t*>(query_lds + args.seen_offset);
             seen_mask = args.seen_cells - 1;
             for (std::uint32_t i = lane; i < args.seen_cells; i += 64)
@@ -1678,7 +1710,7 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                 bool asks = present;
                 std::uint32_t seen_cell = 0;
                 if constexpr (seen_ak) {
-                    if (plain_ak || seen) { // a slot this query has probed before is in the set: no atomic for it
+                    if (seen) { // a slot this query has probed before is in the set: no atomic for it
                         seen_cell = ((neighbor * 0x9E3779B1u) >> 9) & seen_mask;
                         asks = present && seen[seen_cell] != neighbor;
                     }
@@ -1782,7 +1814,28 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                 if (!popped)
                     pop_now();
                 shadow_work();
-                while (old != none_slot_k && old != neighbor) { // linear probing, index.hpp:1085-1211
+                if constexpr (aside_ak) {
+                    // the home cell belongs to another member: this one lives in `aside` (see above) — or moves in now
+                    bool taken = asks && old != none_slot_k && old != neighbor;
+                    const std::uint64_t taken_mask = ballot(taken);
+                    if (taken_mask) {
+                        if (aside_count + popcount64(taken_mask) > aside_mask - aside_mask / 4) { // 75 % of the cells
+                            overflow = true;
+                            break;
+                        }
+                        std::uint32_t cell = ((neighbor * 0x9E3779B1u) >> 11) & aside_mask;
+                        do {
+                            std::uint32_t there = neighbor;
+                            if (taken)
+                                there = atomicCAS(aside + cell, none_slot_k, neighbor);
+                            if (taken && (there == none_slot_k || there == neighbor))
+                                old = there, taken = false; // moved in (fresh) / found (visited)
+                            cell = (cell + 1) & aside_mask;
+                        } while (ballot(taken));
+                        aside_count += popcount64(ballot(lane_bit(taken_mask) && old == none_slot_k));
+                    }
+                }
+                while (!aside_ak && old != none_slot_k && old != neighbor) { // linear probing, index.hpp:1085-1211
                     h = (h + 1) & visits_mask;
                     if (load_first) {
                         old = __hip_atomic_load(visits + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1795,7 +1848,7 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                 }
                 fresh = present && old == none_slot_k;
                 if constexpr (seen_ak) {
-                    if ((plain_ak || seen) && asks)
+                    if (seen && asks)
                         seen[seen_cell] = neighbor; // probed (inserted or found): in the set from now on
                 }
             }

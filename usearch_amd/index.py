@@ -52,7 +52,7 @@ class Stats(C.Structure):
                 ("kernel_ms", C.c_float), ("mode", C.c_uint32), ("grid", C.c_uint32), ("lds_bytes", C.c_uint32),
                 ("frontier", C.c_uint32), ("variant", C.c_uint32), ("tail_idle", C.c_float), ("span_ms", C.c_float),
                 ("top_cells", C.c_uint32), ("probe_mode", C.c_uint32), ("seen_cells", C.c_uint32), ("claim_bits", C.c_uint32),
-                ("early_rows", C.c_uint32), ("plain", C.c_uint32)]
+                ("early_rows", C.c_uint32), ("plain", C.c_uint32), ("aside_cells", C.c_uint32)]
 
 
 class Arrays(C.Structure):
