@@ -266,3 +266,26 @@ def test_calls_in_flight_share_a_launch_under_the_thread_sanitizer():
     out = subprocess.run([binary], capture_output=True, text=True, timeout=300, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0"))
     assert "ThreadSanitizer" not in out.stderr, out.stderr[-3000:]
     assert out.returncode == 0 and "PASSED" in out.stdout, out.stdout + out.stderr[-1000:]
+
+
+def test_ctypes_mirrors_follow_the_header_field_by_field():
+    """The Python host side mirrors the plain structs of include/usearch_amd.h by hand; an out-struct that grew in the header and not in
+    the mirror would be written past the Python buffer. Scalar structs are compared name by name, type by type, in order."""
+    from usearch_amd import index as host
+    header = open(os.path.join(ROOT, "include", "usearch_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    ctype = {"uint32_t": C.c_uint32, "uint64_t": C.c_uint64, "float": C.c_float, "double": C.c_double, "int": C.c_int,
+             "size_t": C.c_size_t, "int32_t": C.c_int32, "int64_t": C.c_int64}
+    checked = 0
+    for c_name, mirror in (("usearch_amd_tuning_t", host.Tuning), ("usearch_amd_stats_t", host.Stats),
+                           ("usearch_amd_build_config_t", host.BuildConfig), ("usearch_amd_build_stats_t", host.BuildStats)):
+        found = re.search(r"typedef struct " + c_name + r"\s*\{(.*?)\}\s*" + c_name + r"\s*;", header, flags=re.S)
+        if not found:
+            continue
+        declared = []
+        for kind, names in re.findall(r"^\s*(\w+)\s+(\w+(?:\s*,\s*\w+)*)\s*;", found.group(1), flags=re.M):
+            declared += [(name.strip(), ctype[kind]) for name in names.split(",")]
+        assert declared, c_name
+        assert [(name, kind) for name, kind in mirror._fields_] == declared, f"{c_name} and its ctypes mirror differ"
+        checked += 1
+    assert checked >= 2, "the header's struct names changed: teach this test the new ones"
