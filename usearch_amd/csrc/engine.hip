@@ -978,7 +978,7 @@ const char* snapshot_t::run_ladder(search_call_t& call) {
     const std::uint32_t pending = call.have_todo ? (std::uint32_t)call.todo.size() : (std::uint32_t)call.count;
     // a team's workgroup adds its shared control block (16-byte alignment + 64 bytes) to the leader's areas: a size that only just
     // fits the budget alone must not become a launch failure — such a batch walks with one wave per query
-    const std::uint32_t team_bytes = 64;
+    const std::uint32_t team_bytes = team_block_bytes_k;
     if (params.team && call.mode != scratch_global_k &&
         (lds_bytes_for(call.mode, call.next_cap, call.hash_cap) + 15) / 16 * 16 + team_bytes > lds_budget) {
         params.team = 0;

@@ -1172,6 +1172,47 @@ struct team_t {
 };
 static_assert(sizeof(team_t) <= 64, "the engine reserves 64 bytes for the control block");
 constexpr std::uint32_t team_exit_k = 0xFFFFFFFFu;
+/// Behind the control block: the neighbour list of the member the walk is likeliest to expand NEXT (`team_ahead_rows_k` cells, absent
+/// ones `none_slot_k`), published by a pipelining leader before a hop's second barrier. The helpers touch those members' rows between
+/// that barrier and the next hop's first one — when they would wait for the leader to name and probe — so that the next gather finds
+/// its rows in the caches and its pages translated: a lone query's hop is the latency of that gather (2.7 µs of a 4.3-µs hop at
+/// expansion 608 over 10M × 768 f16, phase clock of round 6) and bytes are free on a chip that serves one query. Nothing is computed
+/// from the touched rows: results, counters and their order cannot change. Measured: 2.56 → 2.44 ms per query at expansion 608
+/// (profiles/r06_single_query/). Touching the LISTS of a hop's members as well — the next hop expands one of them a third of the time
+/// and nobody could ask for that list ahead — was tried in front of the gather and cost more than it saved (2.47 ms): the gather's
+/// loads return behind them.
+constexpr std::uint32_t team_ahead_rows_k = 32;
+constexpr std::uint32_t team_block_bytes_k = 64 + team_ahead_rows_k * 4;
+UA_DEVICE std::uint32_t* team_ahead_list(team_t* team) {
+    return reinterpret_cast<std::uint32_t*>(reinterpret_cast<std::uint8_t*>(team) + 64);
+}
+
+/// One helper's share of the warm-up: 8 lanes per row, the 64-byte halves `(lane & 7) + 8·k`, k = 0 … 2, of it — the memory side
+/// answers a lone 4-byte load with 64 bytes, not with the 128-byte line (profiles/r03_short_rows: request sizes), so a row of 1 536
+/// bytes takes 24 touches (rows of ≤ 1.5 KB are covered whole). The loads land in registers nobody reads; the caller keeps the
+/// registers allocated until its next gather has waited for its own — younger — loads (loads return in order), so a late arrival
+/// cannot land in a register that has a new owner.
+struct team_landing_t {
+    std::uint32_t cell[3] = {0, 0, 0};
+};
+UA_DEVICE void team_touch_rows(const snapshot_view_t& ix, const std::uint32_t* ahead, std::uint32_t helper, team_landing_t& landing) {
+    const std::uint32_t lane = lane_id();
+    const std::uint32_t row = helper * 8 + (lane >> 3);
+    const std::uint32_t slot = row < team_ahead_rows_k ? ahead[row] : none_slot_k;
+    const std::uint32_t halves = (ix.bytes_per_vector + 63u) / 64u;
+    const std::uint8_t* half = ix.vectors + (std::uint64_t)slot * ix.row_stride + (lane & 7u) * 64u;
+    if (slot != none_slot_k && (lane & 7u) < halves)
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(landing.cell[0]) : "v"(half) : "memory");
+    if (slot != none_slot_k && 8u + (lane & 7u) < halves)
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(landing.cell[1]) : "v"(half + 512) : "memory");
+    if (slot != none_slot_k && 16u + (lane & 7u) < halves)
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(landing.cell[2]) : "v"(half + 1024) : "memory");
+}
+/// Keeps the landing registers allocated up to this point of the program.
+UA_DEVICE void team_landing_alive(const team_landing_t& landing) {
+    asm volatile("" ::"v"(landing.cell[0]), "v"(landing.cell[1]), "v"(landing.cell[2]));
+}
+
 /// The leader and four helpers: 4 × 8 lane groups take the ≤ 32 rows of a hop in ONE round. (Two helpers per SIMD with four rows
 /// each were measured: 7 % slower — a helper's round is instruction issue, which a second wave on the SIMD doubles.)
 constexpr int team_waves_k = 5;
@@ -1602,6 +1643,10 @@ UA_DEVICE bool search_one(const snapshot_view_t& ix, const search_args_t& args, 
                 }
                 tick(4);
                 if (present_count) {
+                    // the list of the member likeliest to be expanded next, for the helpers to touch its members' rows (`team_ahead_list`);
+                    // the wait for that list sits where the leader would wait for the helpers anyway
+                    if (lane < team_ahead_rows_k)
+                        team_ahead_list(team)[lane] = ahead_slot != none_slot_k ? ahead_cell : none_slot_k;
                     team_barrier(); // every share is in LDS
                     if (count) {
                         candidate = fresh; // lanes in list order, the visited ones among them skipped
@@ -2103,6 +2148,10 @@ __global__ __launch_bounds__(64 * team_waves_k) void team_search_kernel(const sn
         // to the four SIMDs round-robin) last — it gets rows only when a hop gathers more than the others take in one round each,
         // and that matters: the leader's commit is all vector ALU work
         const std::uint32_t turn = wave - 1;
+        team_landing_t landing; // where the warm-up's loads land (team_touch_rows)
+        std::uint32_t* ahead = team_ahead_list(team);
+        if (lane_id() < team_ahead_rows_k / (team_waves_k - 1))
+            ahead[turn * (team_ahead_rows_k / (team_waves_k - 1)) + lane_id()] = none_slot_k; // until a pipelining leader publishes a list
 #ifdef USEARCH_AMD_PHASES // every helper's clock: what it spent between the two barriers of a hop
         std::uint64_t helper_mark = args.phases ? __builtin_amdgcn_s_memtime() : 0, helper_busy = 0, helper_idle = 0, helper_hops = 0;
 #endif
@@ -2130,7 +2179,9 @@ __global__ __launch_bounds__(64 * team_waves_k) void team_search_kernel(const sn
                 helper_busy += now - helper_mark, helper_mark = now, ++helper_hops;
             }
 #endif
+            team_landing_alive(landing); // past the gather's own waits
             team_barrier(); // every share is in LDS: the leader commits
+            team_touch_rows(ix, ahead, turn, landing);
         }
 #ifdef USEARCH_AMD_PHASES
         if (args.phases && lane_id() == 0) { // [11 … 14] what each helper spent measuring, [15] the first one's hops
